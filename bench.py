@@ -1,0 +1,184 @@
+#!/usr/bin/env python3
+"""bench.py -- frames/sec of the grid-vision per-frame hot path on MI355X.
+
+A "step" is one frame: points pass (transform + bin + ray ends + bbox test),
+Bresenham free-space ray-march, and the grid pass (decay, rectangles, hit/miss,
+clamp, sigmoid, int8 pack) over one synthetic cloud that is already resident in
+HBM when the timed region starts.
+
+N=1   BASELINE.json configs[2]: 1M-point cloud, 2000x2000 @ 0.1 m grid, 50
+      bboxes + 50 poses.
+N>1   configs[3]: one independent 1M-point frame stream per GPU (no data-path
+      collective; torch.distributed only for the barrier and the max-over-ranks).
+
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "grid-vision_amd"))
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--config", type=int, default=0, help="0 = 3 at N=1 / 4 at N>1")
+    ap.add_argument("--cloud", choices=["uniform", "lidar"], default="uniform")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    return ap.parse_args()
+
+
+def cpu_baseline(config, cloud_fn, tfs, bboxes, poses, budget_s):
+    """The CPU oracle (a port: the reference itself cannot be built here) timed on
+    this box's host cores, single thread like the reference node, on a bounded
+    sample: whole frames of the same workload until ~budget_s have elapsed."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as ol
+    from gvamd import synth
+    g = synth.CONFIGS[config]["grid"]
+    og = ol.OGrid(g.grid_x, g.grid_y, g.resolution)
+    x, y, z, _ = cloud_fn(config)
+    m_base = ol.tf_to_matrix4f(tfs["base_lidar"])
+    m_cam = ol.tf_to_matrix4f(tfs["cam_lidar"])
+    K = ol.set_intrinsic(synth.FX, synth.FY, synth.CX, synth.CY)
+
+    def frame():
+        hits, _ = og.bin_points(m_base, x, y, z)
+        miss, _ = og.raymarch(m_base, x, y, z, dedupe=False)   # per-point march, like a LineIterator user
+        cx, cy, cz = ol.transform_cloud(m_cam, x, y, z)
+        ol.extract_cloud_per_bbox(K, cx, cy, cz, bboxes, synth.IMG_W, synth.IMG_H)
+        og.frame_update(poses, hits, miss)
+        og.to_occupancy_grid()
+
+    frame()   # warm-up (page-in)
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        frame()
+        n += 1
+        if time.perf_counter() - t0 >= budget_s or n >= 50:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": f"{n} whole frames of the same workload (per-point Bresenham, no dedupe), {dt:.1f} s"}
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    n_gpus = max(a.gpus, 1)
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+        local_rank = 0
+
+    import gvamd
+    from gvamd import synth
+    config = a.config or (3 if n_gpus == 1 else 4)
+    cfg = synth.CONFIGS[config]
+    g = cfg["grid"]
+    cloud_fn = synth.cloud_uniform if a.cloud == "uniform" else synth.cloud_lidar_like
+    tfs = synth.transforms(perturbed=True)
+    bboxes = synth.detections(config)
+    poses = synth.lshape_poses(config)
+    x, y, z, _ = cloud_fn(config, seed_extra=rank)
+    N, G = len(x), g.nx * g.ny
+
+    h = gvamd.GridVisionHIP(g.grid_x, g.grid_y, g.resolution, device=local_rank)
+    h.set_transforms(tfs["cam_lidar"], tfs["base_cam"], tfs["base_lidar"])
+    h.upload_xyz(x, y, z)   # resident in HBM before the timed region
+    flags = gvamd.FRAME_BIN | gvamd.FRAME_RAYMARCH | gvamd.FRAME_BBOX_TEST
+    h.set_detections(flags, bboxes=bboxes, poses=poses)
+
+    def barrier():
+        h.synchronize()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        h.enqueue_frame()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        h.enqueue_frame()
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    frames = a.steps * world
+    fps = frames / dt
+
+    out = None
+    if rank == 0:
+        # per-kernel device time, HIP events on the handle's own stream
+        stages = h.time_frame_stages(max(10, min(a.steps, 50)))
+        n_rays, n_visits = h.ray_stats()
+        frame_ms = sum(stages.values())
+        alg = {"points": 12.0 * N, "finalize": 13.0 * G}
+        dom = max(stages, key=stages.get)
+        bytes_frame = 12.0 * N + 13.0 * G
+        # dominant kernel: its own algorithmic bytes where SURVEY 8(d) assigns any
+        # (points 12N, finalize 13G); the ray-march moves only intermediate grids,
+        # so it is priced with the whole frame's algorithmic bytes over ITS time
+        # share plus a Mcell-visits/s figure.
+        dom_bytes = alg.get(dom, bytes_frame)
+        dom_s = stages[dom] * 1e-3
+        roof = {"bound": "hbm", "kernel": dom, "achieved": dom_bytes / dom_s / 1e9, "peak": HBM_PEAK_GBPS,
+                "unit": "GB/s", "frac": dom_bytes / dom_s / 1e9 / HBM_PEAK_GBPS, "traffic": None,
+                "algorithmic_bytes": dom_bytes, "kernel_ms": stages[dom]}
+        out = {
+            "metric": "frames/sec into grid (1M-pt cloud / 2000x2000 @ 0.1 m grid)",
+            "value": fps, "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32 grid / f64 index / i32 counts", "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[{config - 1}]: {N}-point {a.cloud} cloud per GPU, "
+                                   f"{g.nx}x{g.ny} @ {g.resolution} m grid, {len(bboxes)} bboxes + {len(poses)} poses, "
+                                   "bin + ray-march + bbox test + grid pass",
+                       "points": N, "cells": G, "parallelism": f"frame-per-gpu x{world}"},
+            "mpoints_per_s": N * fps / 1e6,
+            "frame_roofline": {"algorithmic_bytes": bytes_frame, "achieved_GBps": bytes_frame * fps / world / 1e9,
+                               "frac_of_hbm_peak": bytes_frame * fps / world / 1e9 / HBM_PEAK_GBPS},
+            "stage_ms": stages, "stage_ms_sum": frame_ms,
+            "ray_march": {"rays": n_rays, "cell_visits": n_visits,
+                          "mcell_visits_per_s": (n_visits / (stages["ray_march"] * 1e-3) / 1e6) if stages["ray_march"] > 0 else None},
+            "roofline": roof,
+        }
+        if not a.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(config, cloud_fn, tfs, bboxes, poses, a.cpu_seconds)
+            out["gpu_over_cpu"] = fps / out["cpu_baseline"]["value"]
+        else:
+            out["cpu_baseline"] = None
+    h.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

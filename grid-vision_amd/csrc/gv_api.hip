@@ -1,0 +1,912 @@
+// gv_api.hip -- C ABI (include/gridvision_hip.h) over the gfx950 kernels.
+// One gv_context = one device + one stream + one resident grid.  No exception
+// leaves this file; every entry point returns a gv_status.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "gv_host_math.hpp"
+#include "gv_kernels.hpp"
+
+using namespace gv;
+
+struct gv_context {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  GridParams g{};
+  gv_cam_params cam{};
+  CamK camk{};
+  double K[9]{}, Kinv[9]{};
+
+  bool has_cl = false, has_bc = false, has_bl = false;
+  gv_transform tf_cl{}, tf_bc{}, tf_bl{};
+  Mat34f m_cam{}, m_base{};
+  Xform64 x_bc{};
+  RayOrigin org{};
+
+  // grid state (resident across frames)
+  float *log_odds = nullptr, *occupancy = nullptr;
+  int8_t *occ_i8 = nullptr;
+  // per-frame count grids
+  int32_t *hits = nullptr;
+  uint8_t *miss = nullptr, *clip_end = nullptr;
+  uint32_t *ray_list = nullptr;
+  uint32_t *ray_count = nullptr;            // [0] = number of list entries
+  unsigned long long *ray_stats = nullptr;  // [0] rays, [1] visits
+  int32_t *scratch_i32 = nullptr;           // G ints (miss read-back)
+
+  // resident cloud
+  float *cx = nullptr, *cy = nullptr, *cz = nullptr;
+  size_t n = 0, cap = 0;
+  float *tx = nullptr, *ty = nullptr, *tz = nullptr;   // transformed copy (A1 read-back)
+  size_t tcap = 0;
+  uint8_t *raw = nullptr;
+  size_t raw_cap = 0;
+  int32_t *cell_idx = nullptr, *bbox_id = nullptr;
+  size_t idx_cap = 0;
+
+  // detections of the current frame
+  gv_bbox *d_bboxes = nullptr;
+  gv_lshape_pose *d_poses = nullptr;
+  Rect *d_rects = nullptr;
+  float *d_orient = nullptr, *d_conf = nullptr, *d_dims = nullptr;
+  VisionOut *d_vout = nullptr;
+  double *d_pts = nullptr;
+  int32_t det_cap = 0;
+  uint32_t frame_flags = 0;
+  int32_t nb = 0, n_poses = 0;
+
+  bool counts_dirty = false;   // hits/miss/clip_end hold a kept frame
+  bool have_counts = false, have_cell_idx = false, have_bbox_id = false;
+
+  hipEvent_t ev[kNumStages + 1]{};
+  std::string err;
+};
+
+namespace {
+
+#define GV_HIP(call)                                                                          \
+  do {                                                                                        \
+    hipError_t e_ = (call);                                                                   \
+    if (e_ != hipSuccess) {                                                                   \
+      char buf_[256];                                                                         \
+      std::snprintf(buf_, sizeof(buf_), "%s:%d %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e_)); \
+      h->err = buf_;                                                                          \
+      return GV_ERR_HIP;                                                                      \
+    }                                                                                         \
+  } while (0)
+
+#define GV_TRY try {
+#define GV_CATCH                               \
+  }                                            \
+  catch (const std::bad_alloc &) {             \
+    if (h) h->err = "host allocation failed";  \
+    return GV_ERR_HIP;                         \
+  }                                            \
+  catch (...) {                                \
+    if (h) h->err = "unexpected exception";    \
+    return GV_ERR_HIP;                         \
+  }
+
+template <typename T>
+int grow(gv_context *h, T *&p, size_t &cap, size_t need)
+{
+  if (need <= cap) return GV_OK;
+  if (p) GV_HIP(hipFree(p));
+  p = nullptr;
+  cap = 0;
+  GV_HIP(hipMalloc(reinterpret_cast<void **>(&p), need * sizeof(T)));
+  cap = need;
+  return GV_OK;
+}
+
+int ensure_cloud(gv_context *h, size_t n)
+{
+  if (n > h->cap) {
+    const size_t want = n + n / 8 + 1024;
+    for (float **p : {&h->cx, &h->cy, &h->cz}) {
+      if (*p) GV_HIP(hipFree(*p));
+      *p = nullptr;
+    }
+    h->cap = 0;
+    GV_HIP(hipMalloc(reinterpret_cast<void **>(&h->cx), want * sizeof(float)));
+    GV_HIP(hipMalloc(reinterpret_cast<void **>(&h->cy), want * sizeof(float)));
+    GV_HIP(hipMalloc(reinterpret_cast<void **>(&h->cz), want * sizeof(float)));
+    h->cap = want;
+  }
+  if (n > h->idx_cap) {
+    const size_t want = n + n / 8 + 1024;
+    for (int32_t **p : {&h->cell_idx, &h->bbox_id}) {
+      if (*p) GV_HIP(hipFree(*p));
+      *p = nullptr;
+    }
+    h->idx_cap = 0;
+    GV_HIP(hipMalloc(reinterpret_cast<void **>(&h->cell_idx), want * sizeof(int32_t)));
+    GV_HIP(hipMalloc(reinterpret_cast<void **>(&h->bbox_id), want * sizeof(int32_t)));
+    h->idx_cap = want;
+  }
+  return GV_OK;
+}
+
+int ensure_det(gv_context *h, int32_t n)
+{
+  if (n <= h->det_cap) return GV_OK;
+  const int32_t want = std::max(n, 64);
+  auto re = [&](auto *&p, size_t bytes) -> int {
+    if (p) GV_HIP(hipFree(p));
+    p = nullptr;
+    GV_HIP(hipMalloc(reinterpret_cast<void **>(&p), bytes));
+    return GV_OK;
+  };
+  int rc;
+  if ((rc = re(h->d_bboxes, (size_t)want * sizeof(gv_bbox)))) return rc;
+  if ((rc = re(h->d_poses, (size_t)want * sizeof(gv_lshape_pose)))) return rc;
+  if ((rc = re(h->d_rects, (size_t)want * sizeof(Rect)))) return rc;
+  if ((rc = re(h->d_orient, (size_t)want * 4 * sizeof(float)))) return rc;
+  if ((rc = re(h->d_conf, (size_t)want * 2 * sizeof(float)))) return rc;
+  if ((rc = re(h->d_dims, (size_t)want * 3 * sizeof(float)))) return rc;
+  if ((rc = re(h->d_vout, (size_t)want * sizeof(VisionOut)))) return rc;
+  if ((rc = re(h->d_pts, (size_t)want * 3 * sizeof(double)))) return rc;
+  h->det_cap = want;
+  return GV_OK;
+}
+
+int use_device(gv_context *h)
+{
+  GV_HIP(hipSetDevice(h->device));
+  return GV_OK;
+}
+
+void refresh_origin(gv_context *h)
+{
+  // [EXTENSION] sensor origin = image of (0,0,0) under base<-lidar = fp32 translation column
+  h->org.ox = (double)h->m_base.m[3];
+  h->org.oy = (double)h->m_base.m[7];
+  int ix = 0, iy = 0;
+  h->org.valid = host::get_index(h->g, h->org.ox, h->org.oy, ix, iy) ? 1 : 0;
+  h->org.cx = ix;
+  h->org.cy = iy;
+}
+
+int clear_counts(gv_context *h)
+{
+  const size_t G = (size_t)h->g.G;
+  GV_HIP(hipMemsetAsync(h->hits, 0, G * sizeof(int32_t), h->stream));
+  GV_HIP(hipMemsetAsync(h->miss, 0, G, h->stream));
+  GV_HIP(hipMemsetAsync(h->clip_end, 0, G, h->stream));
+  h->counts_dirty = false;
+  return GV_OK;
+}
+
+// plain grid update (A7 / A8 / A10): rectangles already in d_rects
+int enqueue_plain_update(gv_context *h, int32_t n_rects)
+{
+  FinalizeArgs f{};
+  f.g = h->g;
+  f.log_odds = h->log_odds;
+  f.occupancy = h->occupancy;
+  f.occ_i8 = h->occ_i8;
+  f.rects = h->d_rects;
+  f.n_rects = n_rects;
+  f.hits = nullptr;
+  f.miss = nullptr;
+  f.clip_end = nullptr;
+  f.zero_counts = false;
+  f.cell_begin = 0;
+  f.cell_end = h->g.G;
+  launch_finalize(f, h->stream);
+  GV_HIP(hipGetLastError());
+  return GV_OK;
+}
+
+int enqueue_frame(gv_context *h, bool stage_events)
+{
+  const uint32_t fl = h->frame_flags;
+  const bool do_bin = fl & GV_FRAME_BIN, do_ray = fl & GV_FRAME_RAYMARCH, do_bbox = fl & GV_FRAME_BBOX_TEST;
+  const bool keep_cell = fl & GV_FRAME_KEEP_CELL_IDX, keep_counts = fl & GV_FRAME_KEEP_COUNTS;
+  const bool vision = fl & GV_FRAME_VISION_ORIENT;
+  if (do_ray && !do_bin) return GV_ERR_BAD_ARG;
+  if (do_bin && !h->has_bl) return GV_ERR_TF;
+  if (do_bbox && !h->has_cl) return GV_ERR_TF;
+  if (vision && !h->has_bc) return GV_ERR_TF;
+  if (h->counts_dirty) { int rc = clear_counts(h); if (rc) return rc; }
+  if (stage_events) GV_HIP(hipEventRecord(h->ev[0], h->stream));
+
+  // --- detections -> rectangles
+  int32_t n_rects = 0;
+  if (vision && h->nb > 0) {
+    launch_vision(h->d_orient, h->d_conf, h->d_dims, h->d_bboxes, h->nb, h->cam, h->d_vout, h->d_poses, h->stream);
+    launch_rects_from_poses(h->d_poses, h->nb, h->g, true, h->x_bc, h->d_rects, h->stream);
+    n_rects = h->nb;
+  } else if (h->n_poses > 0) {
+    launch_rects_from_poses(h->d_poses, h->n_poses, h->g, false, h->x_bc, h->d_rects, h->stream);
+    n_rects = h->n_poses;
+  }
+  if (stage_events) GV_HIP(hipEventRecord(h->ev[kStageDetections + 1], h->stream));
+
+  // --- points pass
+  if (do_bin || do_bbox) {
+    PointsArgs a{};
+    a.x = h->cx; a.y = h->cy; a.z = h->cz;
+    a.n = (uint32_t)h->n;
+    a.g = h->g;
+    a.m_base = h->m_base;
+    a.m_cam = h->m_cam;
+    a.cam = h->camk;
+    a.org = h->org;
+    a.bboxes = h->d_bboxes;
+    a.nb = h->nb;
+    a.hits = h->hits;
+    a.clip_end = h->clip_end;
+    a.cell_idx = keep_cell ? h->cell_idx : nullptr;
+    a.bbox_id = h->bbox_id;
+    a.do_bin = do_bin; a.do_ray = do_ray; a.do_bbox = do_bbox;
+    launch_points(a, h->stream);
+  }
+  if (stage_events) GV_HIP(hipEventRecord(h->ev[kStagePoints + 1], h->stream));
+
+  // --- ray march
+  if (do_ray && h->org.valid) {
+    GV_HIP(hipMemsetAsync(h->ray_count, 0, sizeof(uint32_t), h->stream));
+    GV_HIP(hipMemsetAsync(h->ray_stats, 0, 2 * sizeof(unsigned long long), h->stream));
+    launch_ray_compact(h->hits, h->clip_end, h->g, h->ray_list, h->ray_count, h->stream);
+    if (stage_events) GV_HIP(hipEventRecord(h->ev[kStageRayCompact + 1], h->stream));
+    launch_ray_march(h->ray_list, h->ray_count, h->g, h->org, h->miss, h->ray_stats, h->stream);
+    if (stage_events) GV_HIP(hipEventRecord(h->ev[kStageRayMarch + 1], h->stream));
+  } else if (stage_events) {
+    GV_HIP(hipEventRecord(h->ev[kStageRayCompact + 1], h->stream));
+    GV_HIP(hipEventRecord(h->ev[kStageRayMarch + 1], h->stream));
+  }
+
+  // --- one grid pass
+  FinalizeArgs f{};
+  f.g = h->g;
+  f.log_odds = h->log_odds;
+  f.occupancy = h->occupancy;
+  f.occ_i8 = h->occ_i8;
+  f.rects = h->d_rects;
+  f.n_rects = n_rects;
+  f.hits = do_bin ? h->hits : nullptr;
+  f.miss = h->miss;
+  f.clip_end = h->clip_end;
+  f.zero_counts = do_bin && !keep_counts;
+  f.cell_begin = 0;
+  f.cell_end = h->g.G;
+  launch_finalize(f, h->stream);
+  if (stage_events) GV_HIP(hipEventRecord(h->ev[kStageFinalize + 1], h->stream));
+  GV_HIP(hipGetLastError());
+
+  h->counts_dirty = do_bin && keep_counts;
+  h->have_counts = do_bin && keep_counts;
+  h->have_cell_idx = do_bin && keep_cell;
+  h->have_bbox_id = do_bbox;
+  return GV_OK;
+}
+
+int upload_bboxes(gv_context *h, const gv_bbox *b, int32_t nb)
+{
+  int rc = ensure_det(h, nb);
+  if (rc) return rc;
+  if (nb > 0) GV_HIP(hipMemcpyAsync(h->d_bboxes, b, (size_t)nb * sizeof(gv_bbox), hipMemcpyHostToDevice, h->stream));
+  return GV_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int gv_abi_version(void) { return 1; }
+
+int gv_create(gv_handle *out, uint8_t grid_x, uint8_t grid_y, double resolution, const gv_cam_params *cam,
+              int device_id)
+{
+  if (!out) return GV_ERR_BAD_ARG;
+  *out = nullptr;
+  if (!cam || grid_x == 0 || grid_y == 0 || !(resolution > 0.0)) return GV_ERR_BAD_ARG;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return GV_ERR_NO_DEVICE;
+  gv_context *h = new (std::nothrow) gv_context();
+  if (!h) return GV_ERR_HIP;
+  GV_TRY
+  if (device_id < 0) {
+    if (hipGetDevice(&device_id) != hipSuccess) device_id = 0;
+  }
+  if (device_id >= ndev) { delete h; return GV_ERR_NO_DEVICE; }
+  h->device = device_id;
+  // grid_map::GridMap::setGeometry + setPosition  (src/occupancy_grid.cpp:10-11)
+  GridParams &g = h->g;
+  g.res = resolution;
+  const double sx = std::round((double)grid_x / resolution), sy = std::round((double)grid_y / resolution);
+  if (!(sx >= 1.0 && sy >= 1.0) || sx * sy > (double)(1 << 30)) { delete h; return GV_ERR_BAD_ARG; }
+  g.nx = (int32_t)sx;
+  g.ny = (int32_t)sy;
+  g.G = g.nx * g.ny;
+  g.len_x = (double)g.nx * resolution;
+  g.len_y = (double)g.ny * resolution;
+  g.pos_x = (double)(grid_x / 3);   // uint8_t / int: integer division (:11)
+  g.pos_y = 0.0;
+  g.off_x = 0.5 * g.len_x;
+  g.off_y = 0.5 * g.len_y;
+  h->cam = *cam;
+  host::intrinsics((double)cam->fx, (double)cam->fy, (double)cam->cx, (double)cam->cy, h->K, h->Kinv);
+  for (int i = 0; i < 9; ++i) h->camk.k[i] = h->K[i];
+  h->camk.W = cam->orig_w;
+  h->camk.H = cam->orig_h;
+
+  auto fail = [&](int code) { gv_destroy(h); return code; };
+#define GV_C(call)                                           \
+  do {                                                       \
+    if ((call) != hipSuccess) return fail(GV_ERR_HIP);       \
+  } while (0)
+  GV_C(hipSetDevice(h->device));
+  GV_C(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+  const size_t G = (size_t)g.G;
+  GV_C(hipMalloc(reinterpret_cast<void **>(&h->log_odds), G * sizeof(float)));
+  GV_C(hipMalloc(reinterpret_cast<void **>(&h->occupancy), G * sizeof(float)));
+  GV_C(hipMalloc(reinterpret_cast<void **>(&h->occ_i8), G));
+  GV_C(hipMalloc(reinterpret_cast<void **>(&h->hits), G * sizeof(int32_t)));
+  GV_C(hipMalloc(reinterpret_cast<void **>(&h->miss), G + 16));
+  GV_C(hipMalloc(reinterpret_cast<void **>(&h->clip_end), G + 16));
+  GV_C(hipMalloc(reinterpret_cast<void **>(&h->ray_list), G * sizeof(uint32_t)));
+  GV_C(hipMalloc(reinterpret_cast<void **>(&h->ray_count), 4 * sizeof(uint32_t)));
+  GV_C(hipMalloc(reinterpret_cast<void **>(&h->ray_stats), 2 * sizeof(unsigned long long)));
+  GV_C(hipMalloc(reinterpret_cast<void **>(&h->scratch_i32), G * sizeof(int32_t)));
+  for (auto &e : h->ev) GV_C(hipEventCreate(&e));
+  GV_C(hipMemsetAsync(h->ray_count, 0, 4 * sizeof(uint32_t), h->stream));
+  GV_C(hipMemsetAsync(h->ray_stats, 0, 2 * sizeof(unsigned long long), h->stream));
+#undef GV_C
+  if (ensure_det(h, 64) != GV_OK) return fail(GV_ERR_HIP);
+  if (clear_counts(h) != GV_OK) return fail(GV_ERR_HIP);
+  *out = h;
+  int rc = gv_reset(h);
+  if (rc != GV_OK) { *out = nullptr; return fail(rc); }
+  return GV_OK;
+  GV_CATCH
+}
+
+int gv_destroy(gv_handle h)
+{
+  if (!h) return GV_ERR_BAD_ARG;
+  (void)hipSetDevice(h->device);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  void *bufs[] = {h->log_odds, h->occupancy, h->occ_i8, h->hits, h->miss, h->clip_end, h->ray_list, h->ray_count,
+                  h->ray_stats, h->scratch_i32, h->cx, h->cy, h->cz, h->tx, h->ty, h->tz, h->raw, h->cell_idx,
+                  h->bbox_id, h->d_bboxes, h->d_poses, h->d_rects, h->d_orient, h->d_conf, h->d_dims, h->d_vout,
+                  h->d_pts};
+  for (void *p : bufs)
+    if (p) (void)hipFree(p);
+  for (auto &e : h->ev)
+    if (e) (void)hipEventDestroy(e);
+  if (h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+  return GV_OK;
+}
+
+const char *gv_last_error(gv_handle h) { return h ? h->err.c_str() : "null handle"; }
+
+int gv_grid_geometry(gv_handle h, int32_t *nx, int32_t *ny, double *pos_x, double *pos_y)
+{
+  if (!h) return GV_ERR_BAD_ARG;
+  if (nx) *nx = h->g.nx;
+  if (ny) *ny = h->g.ny;
+  if (pos_x) *pos_x = h->g.pos_x;
+  if (pos_y) *pos_y = h->g.pos_y;
+  return GV_OK;
+}
+
+int gv_reset(gv_handle h)
+{
+  if (!h) return GV_ERR_BAD_ARG;
+  GV_TRY
+  int rc = use_device(h);
+  if (rc) return rc;
+  const size_t G = (size_t)h->g.G;
+  launch_fill_f32(h->log_odds, kLogOddsPrior, G, h->stream);      // :12
+  launch_fill_f32(h->occupancy, kInitProbability, G, h->stream);  // :13
+  // toOccupancyGrid of the initial layer: (int8)(0.5f*100) = 50
+  GV_HIP(hipMemsetAsync(h->occ_i8, 50, G, h->stream));
+  GV_HIP(hipGetLastError());
+  GV_HIP(hipStreamSynchronize(h->stream));
+  return GV_OK;
+  GV_CATCH
+}
+
+int gv_set_transforms(gv_handle h, const gv_transform *cl, const gv_transform *bc, const gv_transform *bl)
+{
+  if (!h) return GV_ERR_BAD_ARG;
+  GV_TRY
+  if (cl) { h->tf_cl = *cl; h->m_cam = host::pcl_matrix_from_tf(*cl); h->has_cl = true; }
+  if (bc) { h->tf_bc = *bc; h->x_bc = host::xform_from_tf(*bc); h->has_bc = true; }
+  if (bl) { h->tf_bl = *bl; h->m_base = host::pcl_matrix_from_tf(*bl); h->has_bl = true; refresh_origin(h); }
+  return GV_OK;
+  GV_CATCH
+}
+
+int gv_cloud_upload_xyz(gv_handle h, const float *x, const float *y, const float *z, size_t n)
+{
+  if (!h || (n && (!x || !y || !z)) || n > 0x7fffffffu) return GV_ERR_BAD_ARG;
+  GV_TRY
+  int rc = use_device(h);
+  if (rc) return rc;
+  if ((rc = ensure_cloud(h, n))) return rc;
+  if (n) {
+    GV_HIP(hipMemcpyAsync(h->cx, x, n * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    GV_HIP(hipMemcpyAsync(h->cy, y, n * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    GV_HIP(hipMemcpyAsync(h->cz, z, n * sizeof(float), hipMemcpyHostToDevice, h->stream));
+  }
+  GV_HIP(hipStreamSynchronize(h->stream));
+  h->n = n;
+  h->have_cell_idx = h->have_bbox_id = false;
+  return GV_OK;
+  GV_CATCH
+}
+
+int gv_cloud_upload_pointcloud2(gv_handle h, const uint8_t *data, size_t n, uint32_t point_step, uint32_t off_x,
+                                uint32_t off_y, uint32_t off_z)
+{
+  if (!h || (n && !data) || n > 0x7fffffffu) return GV_ERR_BAD_ARG;
+  if (point_step < 4 || off_x + 4 > point_step || off_y + 4 > point_step || off_z + 4 > point_step)
+    return GV_ERR_BAD_ARG;
+  GV_TRY
+  int rc = use_device(h);
+  if (rc) return rc;
+  if ((rc = ensure_cloud(h, n))) return rc;
+  const size_t bytes = n * (size_t)point_step;
+  if ((rc = grow(h, h->raw, h->raw_cap, bytes + 16))) return rc;
+  if (n) {
+    GV_HIP(hipMemcpyAsync(h->raw, data, bytes, hipMemcpyHostToDevice, h->stream));
+    launch_deinterleave(h->raw, (uint32_t)n, point_step, off_x, off_y, off_z, h->cx, h->cy, h->cz, h->stream);
+    GV_HIP(hipGetLastError());
+  }
+  GV_HIP(hipStreamSynchronize(h->stream));
+  h->n = n;
+  h->have_cell_idx = h->have_bbox_id = false;
+  return GV_OK;
+  GV_CATCH
+}
+
+int gv_transform_lidar_to_camera(gv_handle h, float *x_cam, float *y_cam, float *z_cam)
+{
+  if (!h || !x_cam || !y_cam || !z_cam) return GV_ERR_BAD_ARG;
+  if (!h->has_cl) return GV_ERR_TF;   // the reference returns nullptr (:292-297)
+  GV_TRY
+  int rc = use_device(h);
+  if (rc) return rc;
+  const size_t n = h->n;
+  if (n > h->tcap) {
+    for (float **p : {&h->tx, &h->ty, &h->tz}) {
+      if (*p) GV_HIP(hipFree(*p));
+      *p = nullptr;
+    }
+    h->tcap = 0;
+    GV_HIP(hipMalloc(reinterpret_cast<void **>(&h->tx), n * sizeof(float)));
+    GV_HIP(hipMalloc(reinterpret_cast<void **>(&h->ty), n * sizeof(float)));
+    GV_HIP(hipMalloc(reinterpret_cast<void **>(&h->tz), n * sizeof(float)));
+    h->tcap = n;
+  }
+  if (n) {
+    launch_transform_cloud(h->cx, h->cy, h->cz, (uint32_t)n, h->m_cam, h->tx, h->ty, h->tz, h->stream);
+    GV_HIP(hipGetLastError());
+    GV_HIP(hipMemcpyAsync(x_cam, h->tx, n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    GV_HIP(hipMemcpyAsync(y_cam, h->ty, n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    GV_HIP(hipMemcpyAsync(z_cam, h->tz, n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+  }
+  GV_HIP(hipStreamSynchronize(h->stream));
+  return GV_OK;
+  GV_CATCH
+}
+
+int gv_extract_cloud_per_bbox(gv_handle h, const gv_bbox *bboxes, int32_t nb, int32_t *bbox_id, int32_t *counts)
+{
+  if (!h || nb < 0 || (nb && !bboxes) || !bbox_id) return GV_ERR_BAD_ARG;
+  if (!h->has_cl) return GV_ERR_TF;
+  GV_TRY
+  int rc = use_device(h);
+  if (rc) return rc;
+  if ((rc = upload_bboxes(h, bboxes, nb))) return rc;
+  PointsArgs a{};
+  a.x = h->cx; a.y = h->cy; a.z = h->cz;
+  a.n = (uint32_t)h->n;
+  a.g = h->g;
+  a.m_cam = h->m_cam;
+  a.cam = h->camk;
+  a.bboxes = h->d_bboxes;
+  a.nb = nb;
+  a.bbox_id = h->bbox_id;
+  a.do_bbox = true;
+  launch_points(a, h->stream);
+  GV_HIP(hipGetLastError());
+  if (h->n) GV_HIP(hipMemcpyAsync(bbox_id, h->bbox_id, h->n * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+  GV_HIP(hipStreamSynchronize(h->stream));
+  h->have_bbox_id = true;
+  if (counts) {
+    for (int32_t b = 0; b < nb; ++b) counts[b] = 0;
+    for (size_t i = 0; i < h->n; ++i)
+      if (bbox_id[i] >= 0) counts[bbox_id[i]]++;
+  }
+  return GV_OK;
+  GV_CATCH
+}
+
+int gv_convert_pixels_to_3d(gv_handle h, const gv_bbox *bboxes, const float *depths, int32_t nb,
+                            double *base_points_xyz)
+{
+  if (!h || nb < 0 || (nb && (!bboxes || !depths || !base_points_xyz))) return GV_ERR_BAD_ARG;
+  if (!h->has_bc) return GV_ERR_TF;
+  GV_TRY
+  for (int32_t i = 0; i < nb; ++i) {
+    // grid_vision_node.cpp:320-322 pixel centre (cv::Point2f), :325 pixelTo3D, :328-329 to base
+    const float pcx = (float)(bboxes[i].x_min + ((bboxes[i].x_max - bboxes[i].x_min) / 2.0f));
+    const float pcy = (float)(bboxes[i].y_min + ((bboxes[i].y_max - bboxes[i].y_min) / 2.0f));
+    const double hx = pcx, hy = pcy, hz = 1.0;
+    const double d = depths[i];
+    double cam[3];
+    for (int r = 0; r < 3; ++r)
+      cam[r] = d * ((h->Kinv[r * 3] * hx + h->Kinv[r * 3 + 1] * hy) + h->Kinv[r * 3 + 2] * hz);   // cloud_detections.cpp:95
+    host::apply(h->x_bc, cam, &base_points_xyz[3 * i]);
+  }
+  return GV_OK;
+  GV_CATCH
+}
+
+int gv_vision_post_process(gv_handle h, const float *orient, const float *conf, const float *dims,
+                           const gv_bbox *bboxes, int32_t nb, gv_lshape_pose *poses_out, int32_t *n_out)
+{
+  if (!h || nb < 0 || !n_out || (nb && (!orient || !conf || !dims || !bboxes || !poses_out))) return GV_ERR_BAD_ARG;
+  GV_TRY
+  *n_out = 0;
+  if (nb == 0) return GV_OK;
+  int rc = use_device(h);
+  if (rc) return rc;
+  if ((rc = upload_bboxes(h, bboxes, nb))) return rc;
+  GV_HIP(hipMemcpyAsync(h->d_orient, orient, (size_t)nb * 4 * sizeof(float), hipMemcpyHostToDevice, h->stream));
+  GV_HIP(hipMemcpyAsync(h->d_conf, conf, (size_t)nb * 2 * sizeof(float), hipMemcpyHostToDevice, h->stream));
+  GV_HIP(hipMemcpyAsync(h->d_dims, dims, (size_t)nb * 3 * sizeof(float), hipMemcpyHostToDevice, h->stream));
+  launch_vision(h->d_orient, h->d_conf, h->d_dims, h->d_bboxes, nb, h->cam, h->d_vout, h->d_poses, h->stream);
+  GV_HIP(hipGetLastError());
+  std::vector<VisionOut> vo((size_t)nb);
+  GV_HIP(hipMemcpyAsync(vo.data(), h->d_vout, (size_t)nb * sizeof(VisionOut), hipMemcpyDeviceToHost, h->stream));
+  GV_HIP(hipStreamSynchronize(h->stream));
+  int32_t m = 0;
+  for (int32_t i = 0; i < nb; ++i) {
+    if (!vo[i].valid) continue;   // vision_orientation.cpp:496-499
+    gv_lshape_pose p;
+    p.px = vo[i].loc[0]; p.py = vo[i].loc[1]; p.pz = vo[i].loc[2];     // :434-436
+    const host::Quat q = host::quat_from_rpy(0, -vo[i].orient, 0);       // :440
+    p.qx = q.x; p.qy = q.y; p.qz = q.z; p.qw = q.w;
+    p.length = vo[i].dims[0]; p.width = vo[i].dims[1]; p.height = vo[i].dims[2];
+    poses_out[m++] = p;
+  }
+  *n_out = m;
+  return GV_OK;
+  GV_CATCH
+}
+
+int gv_transform_lshape_objects(gv_handle h, gv_lshape_pose *poses, int32_t n)
+{
+  if (!h || n < 0 || (n && !poses)) return GV_ERR_BAD_ARG;
+  if (!h->has_bc) return GV_ERR_TF;
+  GV_TRY
+  for (int32_t i = 0; i < n; ++i) host::transform_pose(h->tf_bc, poses[i]);
+  return GV_OK;
+  GV_CATCH
+}
+
+int gv_extract_bboxes(const float *boxes, const float *scores, int32_t n, int32_t c, double conf_threshold,
+                      double iou_threshold, int32_t orig_w, int32_t orig_h, int32_t resize, gv_bbox *out,
+                      int32_t *n_out)
+{
+  gv_context *h = nullptr;
+  if (!n_out || n < 0 || c <= 0 || resize <= 0 || (n && (!boxes || !scores || !out))) return GV_ERR_BAD_ARG;
+  GV_TRY
+  std::vector<gv_bbox> cand;
+  for (int32_t i = 0; i < n; ++i) {
+    int32_t best = 0;
+    float mx = scores[(size_t)i * c];
+    for (int32_t k = 1; k < c; ++k)
+      if (scores[(size_t)i * c + k] > mx) { mx = scores[(size_t)i * c + k]; best = k; }   // :121-122
+    if (mx >= conf_threshold) {                                                            // :125
+      gv_bbox b;
+      b.confidence = mx;
+      b.label = host::object_class(best);
+      b.x_min = boxes[i * 4 + 0]; b.y_min = boxes[i * 4 + 1];
+      b.x_max = boxes[i * 4 + 2]; b.y_max = boxes[i * 4 + 3];
+      cand.push_back(b);
+    }
+  }
+  std::vector<gv_bbox> kept = host::nms(std::move(cand), (float)iou_threshold);   // :142
+  host::denormalize(kept, orig_w, orig_h, resize);                                // :143
+  for (size_t i = 0; i < kept.size(); ++i) out[i] = kept[i];
+  *n_out = (int32_t)kept.size();
+  return GV_OK;
+  GV_CATCH
+}
+
+int gv_filter_bboxes(const gv_bbox *in, int32_t n, gv_bbox *static_out, int32_t *n_static, gv_bbox *dynamic_out,
+                     int32_t *n_dynamic)
+{
+  if (n < 0 || !n_static || !n_dynamic || (n && (!in || !static_out || !dynamic_out))) return GV_ERR_BAD_ARG;
+  int32_t ns = 0, nd = 0;
+  for (int32_t i = 0; i < n; ++i) {
+    const int32_t l = in[i].label;
+    if (l == 9 || l == 0 || l == 1 || l == 2) dynamic_out[nd++] = in[i];   // VEHICLE, BIKE, MOTORBIKE, PERSON
+    else static_out[ns++] = in[i];
+  }
+  *n_static = ns;
+  *n_dynamic = nd;
+  return GV_OK;
+}
+
+int gv_get_intrinsics(gv_handle h, double K[9], double K_inv[9])
+{
+  if (!h) return GV_ERR_BAD_ARG;
+  if (K) std::memcpy(K, h->K, sizeof(h->K));
+  if (K_inv) std::memcpy(K_inv, h->Kinv, sizeof(h->Kinv));
+  return GV_OK;
+}
+
+int gv_update_map(gv_handle h)
+{
+  if (!h) return GV_ERR_BAD_ARG;
+  GV_TRY
+  int rc = use_device(h);
+  if (rc) return rc;
+  if ((rc = enqueue_plain_update(h, 0))) return rc;
+  GV_HIP(hipStreamSynchronize(h->stream));
+  return GV_OK;
+  GV_CATCH
+}
+
+int gv_update_map_poses(gv_handle h, const gv_lshape_pose *poses, int32_t n)
+{
+  if (!h || n < 0 || (n && !poses)) return GV_ERR_BAD_ARG;
+  GV_TRY
+  int rc = use_device(h);
+  if (rc) return rc;
+  if ((rc = ensure_det(h, n))) return rc;
+  if (n) {
+    GV_HIP(hipMemcpyAsync(h->d_poses, poses, (size_t)n * sizeof(gv_lshape_pose), hipMemcpyHostToDevice, h->stream));
+    launch_rects_from_poses(h->d_poses, n, h->g, false, h->x_bc, h->d_rects, h->stream);
+  }
+  if ((rc = enqueue_plain_update(h, n))) return rc;
+  GV_HIP(hipStreamSynchronize(h->stream));
+  return GV_OK;
+  GV_CATCH
+}
+
+int gv_update_map_points(gv_handle h, const double *pts, const gv_bbox *bboxes, int32_t n)
+{
+  if (!h || n < 0 || (n && (!pts || !bboxes))) return GV_ERR_BAD_ARG;
+  GV_TRY
+  int rc = use_device(h);
+  if (rc) return rc;
+  if ((rc = upload_bboxes(h, bboxes, n))) return rc;
+  if (n) {
+    GV_HIP(hipMemcpyAsync(h->d_pts, pts, (size_t)n * 3 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    launch_rects_from_points(h->d_pts, h->d_bboxes, n, h->g, h->d_rects, h->stream);
+  }
+  if ((rc = enqueue_plain_update(h, n))) return rc;
+  GV_HIP(hipStreamSynchronize(h->stream));
+  return GV_OK;
+  GV_CATCH
+}
+
+int gv_to_occupancy_grid(gv_handle h, int8_t *data, gv_grid_info *info)
+{
+  if (!h || !data) return GV_ERR_BAD_ARG;
+  GV_TRY
+  int rc = use_device(h);
+  if (rc) return rc;
+  GV_HIP(hipMemcpyAsync(data, h->occ_i8, (size_t)h->g.G, hipMemcpyDeviceToHost, h->stream));
+  GV_HIP(hipStreamSynchronize(h->stream));
+  if (info) {
+    info->width = (uint32_t)h->g.nx;
+    info->height = (uint32_t)h->g.ny;
+    info->resolution = h->g.res;
+    info->origin_x = h->g.pos_x - 0.5 * h->g.len_x;
+    info->origin_y = h->g.pos_y - 0.5 * h->g.len_y;
+  }
+  return GV_OK;
+  GV_CATCH
+}
+
+static int copy_out(gv_context *h, void *dst, const void *src, size_t bytes)
+{
+  int rc = use_device(h);
+  if (rc) return rc;
+  GV_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, h->stream));
+  GV_HIP(hipStreamSynchronize(h->stream));
+  return GV_OK;
+}
+
+int gv_get_log_odds(gv_handle h, float *out)
+{
+  if (!h || !out) return GV_ERR_BAD_ARG;
+  return copy_out(h, out, h->log_odds, (size_t)h->g.G * sizeof(float));
+}
+
+int gv_get_occupancy(gv_handle h, float *out)
+{
+  if (!h || !out) return GV_ERR_BAD_ARG;
+  return copy_out(h, out, h->occupancy, (size_t)h->g.G * sizeof(float));
+}
+
+int gv_set_log_odds(gv_handle h, const float *in)
+{
+  if (!h || !in) return GV_ERR_BAD_ARG;
+  int rc = use_device(h);
+  if (rc) return rc;
+  GV_HIP(hipMemcpyAsync(h->log_odds, in, (size_t)h->g.G * sizeof(float), hipMemcpyHostToDevice, h->stream));
+  GV_HIP(hipStreamSynchronize(h->stream));
+  return GV_OK;
+}
+
+int gv_frame_set_detections(gv_handle h, const gv_frame_desc *d)
+{
+  if (!h || !d) return GV_ERR_BAD_ARG;
+  if (d->n_bboxes < 0 || d->n_poses < 0) return GV_ERR_BAD_ARG;
+  if (d->n_bboxes && !d->bboxes) return GV_ERR_BAD_ARG;
+  const bool vision = d->flags & GV_FRAME_VISION_ORIENT;
+  if (vision && d->n_bboxes && (!d->orient || !d->conf || !d->dims)) return GV_ERR_BAD_ARG;
+  if (!vision && d->n_poses && !d->poses) return GV_ERR_BAD_ARG;
+  GV_TRY
+  int rc = use_device(h);
+  if (rc) return rc;
+  const int32_t need = std::max(d->n_bboxes, d->n_poses);
+  if ((rc = ensure_det(h, need))) return rc;
+  if ((rc = upload_bboxes(h, d->bboxes, d->n_bboxes))) return rc;
+  if (vision && d->n_bboxes) {
+    const size_t nb = (size_t)d->n_bboxes;
+    GV_HIP(hipMemcpyAsync(h->d_orient, d->orient, nb * 4 * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    GV_HIP(hipMemcpyAsync(h->d_conf, d->conf, nb * 2 * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    GV_HIP(hipMemcpyAsync(h->d_dims, d->dims, nb * 3 * sizeof(float), hipMemcpyHostToDevice, h->stream));
+  } else if (!vision && d->n_poses) {
+    GV_HIP(hipMemcpyAsync(h->d_poses, d->poses, (size_t)d->n_poses * sizeof(gv_lshape_pose), hipMemcpyHostToDevice,
+                          h->stream));
+  }
+  GV_HIP(hipStreamSynchronize(h->stream));   // host buffers are free to reuse after return
+  h->frame_flags = d->flags;
+  h->nb = d->n_bboxes;
+  h->n_poses = vision ? 0 : d->n_poses;
+  return GV_OK;
+  GV_CATCH
+}
+
+int gv_frame_enqueue(gv_handle h)
+{
+  if (!h) return GV_ERR_BAD_ARG;
+  GV_TRY
+  int rc = use_device(h);
+  if (rc) return rc;
+  return enqueue_frame(h, false);
+  GV_CATCH
+}
+
+int gv_synchronize(gv_handle h)
+{
+  if (!h) return GV_ERR_BAD_ARG;
+  int rc = use_device(h);
+  if (rc) return rc;
+  GV_HIP(hipStreamSynchronize(h->stream));
+  return GV_OK;
+}
+
+int gv_process_frame(gv_handle h, const gv_frame_desc *desc)
+{
+  int rc = gv_frame_set_detections(h, desc);
+  if (rc) return rc;
+  if ((rc = gv_frame_enqueue(h))) return rc;
+  return gv_synchronize(h);
+}
+
+int gv_get_hits(gv_handle h, int32_t *out)
+{
+  if (!h || !out) return GV_ERR_BAD_ARG;
+  if (!h->have_counts) return GV_ERR_STATE;
+  return copy_out(h, out, h->hits, (size_t)h->g.G * sizeof(int32_t));
+}
+
+int gv_get_miss(gv_handle h, int32_t *out)
+{
+  if (!h || !out) return GV_ERR_BAD_ARG;
+  if (!h->have_counts) return GV_ERR_STATE;
+  int rc = use_device(h);
+  if (rc) return rc;
+  launch_u8_to_i32(h->miss, h->scratch_i32, (size_t)h->g.G, h->stream);
+  GV_HIP(hipGetLastError());
+  return copy_out(h, out, h->scratch_i32, (size_t)h->g.G * sizeof(int32_t));
+}
+
+int gv_get_cell_idx(gv_handle h, int32_t *out)
+{
+  if (!h || !out) return GV_ERR_BAD_ARG;
+  if (!h->have_cell_idx) return GV_ERR_STATE;
+  return copy_out(h, out, h->cell_idx, h->n * sizeof(int32_t));
+}
+
+int gv_get_bbox_id(gv_handle h, int32_t *out)
+{
+  if (!h || !out) return GV_ERR_BAD_ARG;
+  if (!h->have_bbox_id) return GV_ERR_STATE;
+  return copy_out(h, out, h->bbox_id, h->n * sizeof(int32_t));
+}
+
+int gv_get_ray_stats(gv_handle h, uint64_t *n_rays, uint64_t *n_visits)
+{
+  if (!h) return GV_ERR_BAD_ARG;
+  unsigned long long st[2] = {0, 0};
+  int rc = copy_out(h, st, h->ray_stats, sizeof(st));
+  if (rc) return rc;
+  if (n_rays) *n_rays = st[0];
+  if (n_visits) *n_visits = st[1];
+  return GV_OK;
+}
+
+void *gv_stream(gv_handle h) { return h ? (void *)h->stream : nullptr; }
+
+int gv_time_frames(gv_handle h, int32_t frames, float *ms_total)
+{
+  if (!h || frames <= 0 || !ms_total) return GV_ERR_BAD_ARG;
+  GV_TRY
+  int rc = use_device(h);
+  if (rc) return rc;
+  hipEvent_t e0 = h->ev[0], e1 = h->ev[kNumStages];
+  GV_HIP(hipEventRecord(e0, h->stream));
+  for (int32_t i = 0; i < frames; ++i)
+    if ((rc = enqueue_frame(h, false))) return rc;
+  GV_HIP(hipEventRecord(e1, h->stream));
+  GV_HIP(hipEventSynchronize(e1));
+  GV_HIP(hipEventElapsedTime(ms_total, e0, e1));
+  return GV_OK;
+  GV_CATCH
+}
+
+int gv_time_frame_stages(gv_handle h, int32_t frames, float *stage_ms)
+{
+  if (!h || frames <= 0 || !stage_ms) return GV_ERR_BAD_ARG;
+  GV_TRY
+  int rc = use_device(h);
+  if (rc) return rc;
+  for (int s = 0; s < kNumStages; ++s) stage_ms[s] = 0.0f;
+  for (int32_t i = 0; i < frames; ++i) {
+    if ((rc = enqueue_frame(h, true))) return rc;
+    GV_HIP(hipEventSynchronize(h->ev[kNumStages]));
+    for (int s = 0; s < kNumStages; ++s) {
+      float ms = 0.0f;
+      GV_HIP(hipEventElapsedTime(&ms, h->ev[s], h->ev[s + 1]));
+      stage_ms[s] += ms;
+    }
+  }
+  for (int s = 0; s < kNumStages; ++s) stage_ms[s] /= (float)frames;
+  return GV_OK;
+  GV_CATCH
+}
+
+// ---- entry points implemented in later milestones of this build ----
+static int not_built(gv_context *h, const char *what)
+{
+  if (h) h->err = std::string(what) + ": not implemented in this build";
+  return GV_ERR_STATE;
+}
+
+int gv_compute_depth_for_bboxes(gv_handle h, const gv_bbox *, int32_t, int32_t, float *, float *)
+{
+  return not_built(h, "gv_compute_depth_for_bboxes");
+}
+
+int gv_compute_bbox_pose(gv_handle h, const gv_bbox *, int32_t, gv_lshape_pose *, uint8_t *)
+{
+  return not_built(h, "gv_compute_bbox_pose");
+}
+
+int gv_comm_unique_id(uint8_t *) { return GV_ERR_STATE; }
+int gv_comm_init(gv_handle h, const uint8_t *, int32_t, int32_t) { return not_built(h, "gv_comm_init"); }
+int gv_comm_destroy(gv_handle h) { return not_built(h, "gv_comm_destroy"); }
+int gv_process_frame_sharded(gv_handle h, const gv_frame_desc *) { return not_built(h, "gv_process_frame_sharded"); }
+int gv_comm_band(gv_handle h, int64_t *, int64_t *) { return not_built(h, "gv_comm_band"); }
+
+}  // extern "C"

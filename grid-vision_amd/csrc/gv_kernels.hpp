@@ -1,0 +1,70 @@
+// gv_kernels.hpp -- launchers of the gfx950 kernels (defined in gv_kernels.hip).
+// Every launcher only enqueues work on `s`; none allocates or synchronises.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "gv_types.hpp"
+
+namespace gv {
+
+struct PointsArgs {
+  const float *x, *y, *z;
+  uint32_t n;
+  GridParams g;
+  Mat34f m_base;     // base <- lidar   (X1/X2)
+  Mat34f m_cam;      // camera <- lidar (A1/A5)
+  CamK cam;
+  RayOrigin org;
+  const gv_bbox *bboxes;
+  int32_t nb;
+  int32_t *hits;       // G
+  uint8_t *clip_end;   // G
+  int32_t *cell_idx;   // N or null
+  int32_t *bbox_id;    // N or null
+  bool do_bin, do_ray, do_bbox;
+};
+void launch_points(const PointsArgs &a, hipStream_t s);
+
+void launch_transform_cloud(const float *x, const float *y, const float *z, uint32_t n, const Mat34f &m,
+                            float *ox, float *oy, float *oz, hipStream_t s);
+void launch_deinterleave(const uint8_t *data, uint32_t n, uint32_t point_step, uint32_t off_x,
+                         uint32_t off_y, uint32_t off_z, float *x, float *y, float *z, hipStream_t s);
+
+// poses -> index rectangles (updateMap corners + updateGridCellsFast index part).
+// from_cam: poses are camera-frame, apply `bc` (base <- camera) to the position first.
+void launch_rects_from_poses(const gv_lshape_pose *poses, int32_t n, const GridParams &g, bool from_cam,
+                             const Xform64 &bc, Rect *rects, hipStream_t s);
+// dead-code overload: centre points + class depth (computeBoundingBox3D)
+void launch_rects_from_points(const double *pts_xyz, const gv_bbox *bboxes, int32_t n,
+                              const GridParams &g, Rect *rects, hipStream_t s);
+
+// vision-orientation geometry, one wavefront per bbox; also emits camera-frame
+// gv_lshape_pose (position + dims only; the quaternion is filled by the host)
+void launch_vision(const float *orient, const float *conf, const float *dims, const gv_bbox *bboxes,
+                   int32_t nb, const gv_cam_params &cam, VisionOut *out, gv_lshape_pose *poses_cam,
+                   hipStream_t s);
+
+void launch_ray_compact(const int32_t *hits, const uint8_t *clip_end, const GridParams &g,
+                        uint32_t *list, uint32_t *count, hipStream_t s);
+void launch_ray_march(const uint32_t *list, const uint32_t *count, const GridParams &g,
+                      const RayOrigin &org, uint8_t *miss, unsigned long long *stats, hipStream_t s);
+
+struct FinalizeArgs {
+  GridParams g;
+  float *log_odds, *occupancy;
+  int8_t *occ_i8;          // OccupancyGrid.data order (reversed linear)
+  const Rect *rects;
+  int32_t n_rects;
+  int32_t *hits;           // null => no hit/miss rule (plain updateMap)
+  uint8_t *miss;
+  uint8_t *clip_end;
+  bool zero_counts;        // clear hits/miss/clip_end for the next frame
+  int64_t cell_begin, cell_end;   // band of cells to finalise ([0,G) on one GPU)
+};
+void launch_finalize(const FinalizeArgs &a, hipStream_t s);
+
+void launch_fill_f32(float *p, float v, size_t n, hipStream_t s);
+void launch_u8_to_i32(const uint8_t *in, int32_t *out, size_t n, hipStream_t s);
+
+}  // namespace gv

@@ -1,0 +1,349 @@
+"""Python (ctypes) binding of the C ABI in include/gridvision_hip.h.
+
+This is host-side plumbing for tests and bench.py; all compute happens in
+libgridvision_hip.so (hand-written gfx950 kernels).  There is NO CPU fallback:
+if the library is missing or no GPU is present, construction raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import build as _build
+from .synth import BBOX_DTYPE, LSHAPE_DTYPE
+
+GV_OK = 0
+STATUS = {0: "GV_OK", 1: "GV_ERR_BAD_ARG", 2: "GV_ERR_HIP", 3: "GV_ERR_RCCL", 4: "GV_ERR_NO_DEVICE",
+          5: "GV_ERR_STATE", 6: "GV_ERR_TF"}
+
+FRAME_BIN = 1 << 0
+FRAME_RAYMARCH = 1 << 1
+FRAME_BBOX_TEST = 1 << 2
+FRAME_KEEP_CELL_IDX = 1 << 3
+FRAME_KEEP_COUNTS = 1 << 4
+FRAME_VISION_ORIENT = 1 << 5
+
+STAGES = ("detections", "points", "ray_compact", "ray_march", "finalize")
+
+# every symbol include/gridvision_hip.h declares
+ABI_SYMBOLS = [
+    "gv_create", "gv_destroy", "gv_last_error", "gv_abi_version", "gv_grid_geometry", "gv_reset",
+    "gv_set_transforms", "gv_cloud_upload_xyz", "gv_cloud_upload_pointcloud2",
+    "gv_transform_lidar_to_camera", "gv_extract_cloud_per_bbox", "gv_compute_depth_for_bboxes",
+    "gv_convert_pixels_to_3d", "gv_compute_bbox_pose", "gv_vision_post_process",
+    "gv_transform_lshape_objects", "gv_extract_bboxes", "gv_filter_bboxes", "gv_get_intrinsics",
+    "gv_update_map", "gv_update_map_poses", "gv_update_map_points", "gv_to_occupancy_grid",
+    "gv_get_log_odds", "gv_get_occupancy", "gv_set_log_odds", "gv_frame_set_detections",
+    "gv_frame_enqueue", "gv_synchronize", "gv_process_frame", "gv_get_hits", "gv_get_miss",
+    "gv_get_cell_idx", "gv_get_bbox_id", "gv_get_ray_stats", "gv_stream", "gv_time_frames",
+    "gv_time_frame_stages", "gv_comm_unique_id", "gv_comm_init", "gv_comm_destroy",
+    "gv_process_frame_sharded", "gv_comm_band",
+]
+
+
+class CamParams(C.Structure):
+    _fields_ = [("network_h", C.c_int32), ("network_w", C.c_int32), ("orig_h", C.c_int32),
+                ("orig_w", C.c_int32), ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float),
+                ("cy", C.c_float)]
+
+
+class Transform(C.Structure):
+    _fields_ = [(n, C.c_double) for n in ("qx", "qy", "qz", "qw", "tx", "ty", "tz")]
+
+
+class GridInfo(C.Structure):
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("resolution", C.c_double),
+                ("origin_x", C.c_double), ("origin_y", C.c_double)]
+
+
+class FrameDesc(C.Structure):
+    _fields_ = [("flags", C.c_uint32), ("bboxes", C.c_void_p), ("n_bboxes", C.c_int32),
+                ("poses", C.c_void_p), ("n_poses", C.c_int32), ("orient", C.c_void_p),
+                ("conf", C.c_void_p), ("dims", C.c_void_p)]
+
+
+class GVError(RuntimeError):
+    def __init__(self, code, where, detail=""):
+        super().__init__(f"{where}: {STATUS.get(code, code)} {detail}".strip())
+        self.code = code
+
+
+_LIB = None
+
+
+def lib_path() -> str:
+    return _build.LIB
+
+
+def load(build_if_missing: bool = True):
+    """Load libgridvision_hip.so (builds it with hipcc when stale/missing)."""
+    global _LIB
+    if _LIB is None:
+        path = _build.build() if build_if_missing else _build.LIB
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} is missing: build it with hipcc (python -m gvamd.build)")
+        _LIB = C.CDLL(path)
+        _LIB.gv_last_error.restype = C.c_char_p
+        _LIB.gv_stream.restype = C.c_void_p
+    return _LIB
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def make_tf(v):
+    return Transform(*[float(t) for t in v]) if v is not None else None
+
+
+def extract_bboxes(boxes, scores, conf_thr, iou_thr, orig_w, orig_h, resize):
+    """object_detection::extract_bboxes on precomputed detector outputs (host side)."""
+    boxes, scores = _f32(boxes), _f32(scores)
+    n, c = scores.shape
+    out = np.zeros(max(n, 1), dtype=BBOX_DTYPE)
+    m = C.c_int32(0)
+    rc = load().gv_extract_bboxes(_ptr(boxes), _ptr(scores), C.c_int32(n), C.c_int32(c), C.c_double(conf_thr),
+                                  C.c_double(iou_thr), C.c_int32(orig_w), C.c_int32(orig_h), C.c_int32(resize),
+                                  _ptr(out), C.byref(m))
+    if rc:
+        raise GVError(rc, "gv_extract_bboxes")
+    return out[:m.value].copy()
+
+
+def filter_bboxes(bboxes):
+    b = np.ascontiguousarray(bboxes, dtype=BBOX_DTYPE)
+    st = np.zeros(max(len(b), 1), dtype=BBOX_DTYPE)
+    dy = np.zeros(max(len(b), 1), dtype=BBOX_DTYPE)
+    ns, nd = C.c_int32(0), C.c_int32(0)
+    rc = load().gv_filter_bboxes(_ptr(b), C.c_int32(len(b)), _ptr(st), C.byref(ns), _ptr(dy), C.byref(nd))
+    if rc:
+        raise GVError(rc, "gv_filter_bboxes")
+    return st[:ns.value].copy(), dy[:nd.value].copy()
+
+
+class GridVisionHIP:
+    """One handle = one MI355X + one stream + one resident occupancy grid."""
+
+    def __init__(self, grid_x, grid_y, resolution, fx=320.0, fy=320.0, cx=320.0, cy=240.0,
+                 image_w=640, image_h=480, network_w=224, network_h=224, device=-1):
+        self._lib = load()
+        self._h = C.c_void_p()
+        cam = CamParams(network_h, network_w, image_h, image_w, fx, fy, cx, cy)
+        rc = self._lib.gv_create(C.byref(self._h), C.c_uint8(grid_x), C.c_uint8(grid_y), C.c_double(resolution),
+                                 C.byref(cam), C.c_int(device))
+        if rc:
+            self._h = C.c_void_p()
+            raise GVError(rc, "gv_create", "(no MI355X visible: this library has no CPU path)" if rc == 4 else "")
+        nx, ny = C.c_int32(), C.c_int32()
+        px, py = C.c_double(), C.c_double()
+        self._ck(self._lib.gv_grid_geometry(self._h, C.byref(nx), C.byref(ny), C.byref(px), C.byref(py)), "geometry")
+        self.nx, self.ny, self.pos_x, self.pos_y = nx.value, ny.value, px.value, py.value
+        self.G = self.nx * self.ny
+        self.n = 0
+
+    # ---- plumbing
+    def _ck(self, rc, where):
+        if rc:
+            raise GVError(rc, where, (self._lib.gv_last_error(self._h) or b"").decode())
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._lib.gv_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # ---- setup
+    def reset(self):
+        self._ck(self._lib.gv_reset(self._h), "gv_reset")
+
+    def set_transforms(self, cam_lidar=None, base_cam=None, base_lidar=None):
+        a, b, c = make_tf(cam_lidar), make_tf(base_cam), make_tf(base_lidar)
+        self._ck(self._lib.gv_set_transforms(self._h, C.byref(a) if a else None, C.byref(b) if b else None,
+                                             C.byref(c) if c else None), "gv_set_transforms")
+
+    def upload_xyz(self, x, y, z):
+        x, y, z = _f32(x), _f32(y), _f32(z)
+        self._ck(self._lib.gv_cloud_upload_xyz(self._h, _ptr(x), _ptr(y), _ptr(z), C.c_size_t(len(x))), "upload_xyz")
+        self.n = len(x)
+
+    def upload_pointcloud2(self, data: np.ndarray, n, point_step, off_x, off_y, off_z):
+        data = np.ascontiguousarray(data, dtype=np.uint8)
+        self._ck(self._lib.gv_cloud_upload_pointcloud2(self._h, _ptr(data), C.c_size_t(n), C.c_uint32(point_step),
+                                                       C.c_uint32(off_x), C.c_uint32(off_y), C.c_uint32(off_z)),
+                 "upload_pointcloud2")
+        self.n = n
+
+    # ---- reference-surface calls
+    def transform_lidar_to_camera(self):
+        x, y, z = (np.empty(self.n, np.float32) for _ in range(3))
+        self._ck(self._lib.gv_transform_lidar_to_camera(self._h, _ptr(x), _ptr(y), _ptr(z)), "transform")
+        return x, y, z
+
+    def extract_cloud_per_bbox(self, bboxes):
+        b = np.ascontiguousarray(bboxes, dtype=BBOX_DTYPE)
+        ids = np.empty(self.n, np.int32)
+        counts = np.zeros(max(len(b), 1), np.int32)
+        self._ck(self._lib.gv_extract_cloud_per_bbox(self._h, _ptr(b), C.c_int32(len(b)), _ptr(ids), _ptr(counts)),
+                 "extract_cloud_per_bbox")
+        return ids, counts[:len(b)]
+
+    def compute_depth_for_bboxes(self, bboxes, k):
+        b = np.ascontiguousarray(bboxes, dtype=BBOX_DTYPE)
+        depths = np.zeros(len(b), np.float32)
+        d2 = np.zeros((len(b), k), np.float32)
+        self._ck(self._lib.gv_compute_depth_for_bboxes(self._h, _ptr(b), C.c_int32(len(b)), C.c_int32(k),
+                                                       _ptr(depths), _ptr(d2)), "compute_depth_for_bboxes")
+        return depths, d2
+
+    def convert_pixels_to_3d(self, bboxes, depths):
+        b = np.ascontiguousarray(bboxes, dtype=BBOX_DTYPE)
+        d = _f32(depths)
+        out = np.zeros((len(b), 3), np.float64)
+        self._ck(self._lib.gv_convert_pixels_to_3d(self._h, _ptr(b), _ptr(d), C.c_int32(len(b)), _ptr(out)),
+                 "convert_pixels_to_3d")
+        return out
+
+    def compute_bbox_pose(self, bboxes):
+        b = np.ascontiguousarray(bboxes, dtype=BBOX_DTYPE)
+        poses = np.zeros(max(len(b), 1), dtype=LSHAPE_DTYPE)
+        valid = np.zeros(max(len(b), 1), np.uint8)
+        self._ck(self._lib.gv_compute_bbox_pose(self._h, _ptr(b), C.c_int32(len(b)), _ptr(poses), _ptr(valid)),
+                 "compute_bbox_pose")
+        return poses[:len(b)], valid[:len(b)]
+
+    def vision_post_process(self, orient, conf, dims, bboxes):
+        o, c, d = _f32(orient), _f32(conf), _f32(dims)
+        b = np.ascontiguousarray(bboxes, dtype=BBOX_DTYPE)
+        poses = np.zeros(max(len(b), 1), dtype=LSHAPE_DTYPE)
+        m = C.c_int32(0)
+        self._ck(self._lib.gv_vision_post_process(self._h, _ptr(o), _ptr(c), _ptr(d), _ptr(b), C.c_int32(len(b)),
+                                                  _ptr(poses), C.byref(m)), "vision_post_process")
+        return poses[:m.value].copy()
+
+    def transform_lshape_objects(self, poses):
+        p = np.ascontiguousarray(poses, dtype=LSHAPE_DTYPE).copy()
+        self._ck(self._lib.gv_transform_lshape_objects(self._h, _ptr(p), C.c_int32(len(p))), "transform_lshape")
+        return p
+
+    def intrinsics(self):
+        k, ki = np.zeros(9), np.zeros(9)
+        self._ck(self._lib.gv_get_intrinsics(self._h, _ptr(k), _ptr(ki)), "intrinsics")
+        return k, ki
+
+    def update_map(self):
+        self._ck(self._lib.gv_update_map(self._h), "gv_update_map")
+
+    def update_map_poses(self, poses):
+        p = np.ascontiguousarray(poses, dtype=LSHAPE_DTYPE)
+        self._ck(self._lib.gv_update_map_poses(self._h, _ptr(p), C.c_int32(len(p))), "gv_update_map_poses")
+
+    def update_map_points(self, pts, bboxes):
+        pts = np.ascontiguousarray(pts, dtype=np.float64)
+        b = np.ascontiguousarray(bboxes, dtype=BBOX_DTYPE)
+        self._ck(self._lib.gv_update_map_points(self._h, _ptr(pts), _ptr(b), C.c_int32(len(b))), "update_map_points")
+
+    def to_occupancy_grid(self):
+        data = np.empty(self.G, np.int8)
+        info = GridInfo()
+        self._ck(self._lib.gv_to_occupancy_grid(self._h, _ptr(data), C.byref(info)), "to_occupancy_grid")
+        return data, info
+
+    def log_odds(self):
+        out = np.empty(self.G, np.float32)
+        self._ck(self._lib.gv_get_log_odds(self._h, _ptr(out)), "get_log_odds")
+        return out
+
+    def occupancy(self):
+        out = np.empty(self.G, np.float32)
+        self._ck(self._lib.gv_get_occupancy(self._h, _ptr(out)), "get_occupancy")
+        return out
+
+    def set_log_odds(self, a):
+        a = _f32(a)
+        assert a.size == self.G
+        self._ck(self._lib.gv_set_log_odds(self._h, _ptr(a)), "set_log_odds")
+
+    # ---- fused frame
+    def _desc(self, flags, bboxes=None, poses=None, net=None):
+        self._keep = []
+        d = FrameDesc()
+        d.flags = flags
+        if bboxes is not None and len(bboxes):
+            b = np.ascontiguousarray(bboxes, dtype=BBOX_DTYPE)
+            self._keep.append(b)
+            d.bboxes, d.n_bboxes = b.ctypes.data, len(b)
+        if poses is not None and len(poses):
+            p = np.ascontiguousarray(poses, dtype=LSHAPE_DTYPE)
+            self._keep.append(p)
+            d.poses, d.n_poses = p.ctypes.data, len(p)
+        if net is not None:
+            o, c, dm = (_f32(t) for t in net)
+            self._keep += [o, c, dm]
+            d.orient, d.conf, d.dims = o.ctypes.data, c.ctypes.data, dm.ctypes.data
+        return d
+
+    def set_detections(self, flags, bboxes=None, poses=None, net=None):
+        d = self._desc(flags, bboxes, poses, net)
+        self._ck(self._lib.gv_frame_set_detections(self._h, C.byref(d)), "frame_set_detections")
+
+    def enqueue_frame(self):
+        self._ck(self._lib.gv_frame_enqueue(self._h), "frame_enqueue")
+
+    def synchronize(self):
+        self._ck(self._lib.gv_synchronize(self._h), "synchronize")
+
+    def process_frame(self, flags, bboxes=None, poses=None, net=None):
+        d = self._desc(flags, bboxes, poses, net)
+        self._ck(self._lib.gv_process_frame(self._h, C.byref(d)), "process_frame")
+
+    def hits(self):
+        out = np.empty(self.G, np.int32)
+        self._ck(self._lib.gv_get_hits(self._h, _ptr(out)), "get_hits")
+        return out
+
+    def miss(self):
+        out = np.empty(self.G, np.int32)
+        self._ck(self._lib.gv_get_miss(self._h, _ptr(out)), "get_miss")
+        return out
+
+    def cell_idx(self):
+        out = np.empty(self.n, np.int32)
+        self._ck(self._lib.gv_get_cell_idx(self._h, _ptr(out)), "get_cell_idx")
+        return out
+
+    def bbox_id(self):
+        out = np.empty(self.n, np.int32)
+        self._ck(self._lib.gv_get_bbox_id(self._h, _ptr(out)), "get_bbox_id")
+        return out
+
+    def ray_stats(self):
+        a, b = C.c_uint64(0), C.c_uint64(0)
+        self._ck(self._lib.gv_get_ray_stats(self._h, C.byref(a), C.byref(b)), "ray_stats")
+        return a.value, b.value
+
+    def time_frames(self, frames):
+        ms = C.c_float(0)
+        self._ck(self._lib.gv_time_frames(self._h, C.c_int32(frames), C.byref(ms)), "time_frames")
+        return ms.value
+
+    def time_frame_stages(self, frames):
+        ms = (C.c_float * len(STAGES))()
+        self._ck(self._lib.gv_time_frame_stages(self._h, C.c_int32(frames), ms), "time_frame_stages")
+        return dict(zip(STAGES, [float(v) for v in ms]))

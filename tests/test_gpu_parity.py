@@ -1,0 +1,359 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle on the
+same seeded inputs.  Integer/index results are bit-exact; log-odds and
+occupancy within 1e-5 (north_star), in practice bit-equal.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+from gvamd import synth
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LOG_ODDS_TOL = 1e-5   # north_star: "log-odds within 1e-5"
+OCC_TOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def gvamd():
+    import gvamd as m
+    m.load()
+    return m
+
+
+def make_handle(gvamd, config, perturbed=False):
+    cfg = synth.CONFIGS[config]
+    g = cfg["grid"]
+    h = gvamd.GridVisionHIP(g.grid_x, g.grid_y, g.resolution)
+    tfs = synth.transforms(perturbed)
+    h.set_transforms(tfs["cam_lidar"], tfs["base_cam"], tfs["base_lidar"])
+    return h, tfs
+
+
+def oracle_frame(og, tfs, x, y, z, bboxes=None, poses=None, raymarch=True):
+    m_base = ol.tf_to_matrix4f(tfs["base_lidar"])
+    m_cam = ol.tf_to_matrix4f(tfs["cam_lidar"])
+    hits, cell = og.bin_points(m_base, x, y, z)
+    miss, visits = og.raymarch(m_base, x, y, z) if raymarch else (None, 0)
+    ids = None
+    if bboxes is not None:
+        cx, cy, cz = ol.transform_cloud(m_cam, x, y, z)
+        K = ol.set_intrinsic(synth.FX, synth.FY, synth.CX, synth.CY)
+        ids = ol.extract_cloud_per_bbox(K, cx, cy, cz, bboxes, synth.IMG_W, synth.IMG_H)
+    og.frame_update(poses, hits, miss)
+    return hits, cell, miss, ids, visits
+
+
+def check_grid(h, og):
+    lo, occ = h.log_odds(), h.occupancy()
+    assert np.max(np.abs(lo - og.log_odds)) <= LOG_ODDS_TOL
+    assert np.max(np.abs(occ - og.occupancy)) <= OCC_TOL
+    data, info = h.to_occupancy_grid()
+    odata, oinfo = og.to_occupancy_grid()
+    # int8 = trunc(p*100): may differ by 1 only where p*100 sits on an integer boundary
+    diff = np.abs(data.astype(np.int16) - odata.astype(np.int16))
+    assert diff.max() <= 1
+    assert np.count_nonzero(diff) <= 1e-4 * data.size
+    assert [info.width, info.height, info.resolution, info.origin_x, info.origin_y] == oinfo.tolist()
+    return int(np.count_nonzero(lo != og.log_odds)), int(np.count_nonzero(occ != og.occupancy)), int(np.count_nonzero(diff))
+
+
+@pytest.mark.parametrize("config,perturbed", [(1, False), (1, True), (2, False), (2, True)])
+def test_frame_uniform_cloud(gvamd, config, perturbed):
+    """configs[0]/[1]: binning + DDA ray-march, cell indices and counts bit-exact."""
+    h, tfs = make_handle(gvamd, config, perturbed)
+    cfg = synth.CONFIGS[config]
+    g = cfg["grid"]
+    og = ol.OGrid(g.grid_x, g.grid_y, g.resolution)
+    x, y, z, _ = synth.cloud_uniform(config)
+    h.upload_xyz(x, y, z)
+    flags = gvamd.FRAME_BIN | gvamd.FRAME_RAYMARCH | gvamd.FRAME_KEEP_CELL_IDX | gvamd.FRAME_KEEP_COUNTS
+    for frame in range(3):
+        h.process_frame(flags)
+        hits, cell, miss, _, visits = oracle_frame(og, tfs, x, y, z)
+        assert np.array_equal(h.cell_idx(), cell)
+        assert np.array_equal(h.hits(), hits)
+        assert np.array_equal(h.miss(), miss.astype(np.int32))
+        assert hits.sum() == np.count_nonzero(cell >= 0)
+        nlo, nocc, ni8 = check_grid(h, og)
+        assert nlo == 0, "log-odds are adds + clamp: expected bit-equal"
+    h.close()
+
+
+def test_frame_with_detections_and_poses(gvamd):
+    """bbox first-match ids bit-exact; rectangle block adds; lidar-like contention."""
+    config = 2
+    h, tfs = make_handle(gvamd, config, perturbed=True)
+    g = synth.CONFIGS[config]["grid"]
+    og = ol.OGrid(g.grid_x, g.grid_y, g.resolution)
+    bboxes = synth.detections(3, 50)
+    poses = synth.lshape_poses(config, 50)
+    flags = (gvamd.FRAME_BIN | gvamd.FRAME_RAYMARCH | gvamd.FRAME_BBOX_TEST | gvamd.FRAME_KEEP_CELL_IDX
+             | gvamd.FRAME_KEEP_COUNTS)
+    for frame, gen in enumerate([synth.cloud_lidar_like, synth.cloud_uniform, synth.cloud_lidar_like]):
+        x, y, z, _ = gen(config, 60_000, seed_extra=frame)
+        h.upload_xyz(x, y, z)
+        h.process_frame(flags, bboxes=bboxes, poses=poses)
+        hits, cell, miss, ids, _ = oracle_frame(og, tfs, x, y, z, bboxes, poses)
+        assert np.array_equal(h.cell_idx(), cell)
+        assert np.array_equal(h.hits(), hits)
+        assert np.array_equal(h.miss(), miss.astype(np.int32))
+        assert np.array_equal(h.bbox_id(), ids)
+        assert (ids >= 0).sum() > 100, "fixture must put points inside bboxes"
+        nlo, _, _ = check_grid(h, og)
+        assert nlo == 0
+    h.close()
+
+
+def test_counts_not_kept_matches_kept(gvamd):
+    """the production path (counts cleared inside the finalise pass) gives the same grid."""
+    config = 1
+    x, y, z, _ = synth.cloud_uniform(config)
+    outs = []
+    for keep in (True, False):
+        h, tfs = make_handle(gvamd, config)
+        h.upload_xyz(x, y, z)
+        flags = gvamd.FRAME_BIN | gvamd.FRAME_RAYMARCH | (gvamd.FRAME_KEEP_COUNTS if keep else 0)
+        h.set_detections(flags)
+        for _ in range(4):
+            h.enqueue_frame()
+        h.synchronize()
+        outs.append((h.log_odds(), h.occupancy(), h.to_occupancy_grid()[0]))
+        h.close()
+    for a, b in zip(*outs):
+        assert np.array_equal(a, b)
+
+
+def test_transform_lidar_to_camera_bit_exact(gvamd):
+    h, tfs = make_handle(gvamd, 1, perturbed=True)
+    x, y, z, _ = synth.cloud_uniform(1)
+    h.upload_xyz(x, y, z)
+    gx, gy, gz = h.transform_lidar_to_camera()
+    ox, oy, oz = ol.transform_cloud(ol.tf_to_matrix4f(tfs["cam_lidar"]), x, y, z)
+    assert np.array_equal(gx, ox) and np.array_equal(gy, oy) and np.array_equal(gz, oz)
+    h.close()
+
+
+def test_extract_cloud_per_bbox_api(gvamd):
+    h, tfs = make_handle(gvamd, 2, perturbed=False)
+    x, y, z, _ = synth.cloud_lidar_like(2, 50_000)
+    bboxes = synth.detections(3, 50)
+    h.upload_xyz(x, y, z)
+    ids, counts = h.extract_cloud_per_bbox(bboxes)
+    cx, cy, cz = ol.transform_cloud(ol.tf_to_matrix4f(tfs["cam_lidar"]), x, y, z)
+    K = ol.set_intrinsic(synth.FX, synth.FY, synth.CX, synth.CY)
+    exp = ol.extract_cloud_per_bbox(K, cx, cy, cz, bboxes, synth.IMG_W, synth.IMG_H)
+    assert np.array_equal(ids, exp)
+    assert np.array_equal(counts, np.bincount(exp[exp >= 0], minlength=len(bboxes)))
+    h.close()
+
+
+def test_known_answers_through_abi(gvamd):
+    """SURVEY 8(c) sequences through the C ABI (default yaml grid)."""
+    with open(os.path.join(HERE, "golden", "known_answers.json")) as f:
+        ka = json.load(f)
+    h = gvamd.GridVisionHIP(50, 20, 0.1)
+    assert (h.nx, h.ny, h.pos_x) == (500, 200, 16.0)
+    assert np.all(h.log_odds() == 0.0) and np.all(h.occupancy() == 0.5)
+    seq = []
+    for k in range(12):
+        h.update_map()
+        lo = h.log_odds()
+        assert np.all(lo == lo[0])
+        seq.append(lo[0])
+    assert np.array(seq, np.float32).tolist() == np.array(ka["empty_frame_log_odds"], np.float32).tolist()
+    assert np.all(h.to_occupancy_grid()[0] == ka["empty_frame_saturated"]["int8"])
+    assert abs(h.occupancy()[0] - ka["empty_frame_saturated"]["occupancy"]) < 1e-7
+    h.reset()
+    pose = np.zeros(1, dtype=synth.LSHAPE_DTYPE)
+    pose["px"], pose["py"], pose["length"], pose["width"], pose["qw"] = 16.0, 0.0, 2.0, 1.0, 1.0
+    k = 100 * 500 + 250
+    seq = []
+    for _ in range(7):
+        h.update_map_poses(pose)
+        seq.append(h.log_odds()[k])
+    assert np.array(seq, np.float32).tolist() == np.array(ka["object_every_frame_log_odds"], np.float32).tolist()
+    data, _ = h.to_occupancy_grid()
+    assert data[h.G - 1 - k] == ka["object_saturated"]["int8"]
+    h.close()
+
+
+def test_update_map_poses_and_points_vs_oracle(gvamd):
+    g = synth.CONFIGS[2]["grid"]
+    h = gvamd.GridVisionHIP(g.grid_x, g.grid_y, g.resolution)
+    og = ol.OGrid(g.grid_x, g.grid_y, g.resolution)
+    for frame in range(8):
+        poses = synth.lshape_poses(2, 37, seed_extra=frame)
+        h.update_map_poses(poses)
+        og.update_map_poses(poses)
+    nlo, nocc, ni8 = check_grid(h, og)
+    assert nlo == 0
+    # dead-code overload (occupancy_grid.cpp:33-63): centre points + class depth
+    pts = np.stack([poses["px"], poses["py"], poses["pz"]], axis=1)
+    bboxes = synth.detections(3, 37)
+    h.update_map_points(pts, bboxes)
+    og.update_map_points(pts, bboxes)
+    nlo, _, _ = check_grid(h, og)
+    assert nlo == 0
+    h.close()
+
+
+def test_edge_cases(gvamd):
+    h, tfs = make_handle(gvamd, 1)
+    g = synth.CONFIGS[1]["grid"]
+    og = ol.OGrid(g.grid_x, g.grid_y, g.resolution)
+    flags = gvamd.FRAME_BIN | gvamd.FRAME_RAYMARCH | gvamd.FRAME_KEEP_CELL_IDX | gvamd.FRAME_KEEP_COUNTS
+    nan, inf = np.float32(np.nan), np.float32(np.inf)
+    clouds = [
+        # non-finite points, map edges (+edge inside, -edge outside), far-away points
+        (np.array([nan, 1, inf, 83.0, -17.0, 0, 0, 1e30, -1e30, 5, 33.0], np.float32),
+         np.array([0, nan, 0, 0, 0, 50.0, -50.0, 1e30, 3, -inf, 0.0], np.float32),
+         np.array([0, 0, 0, 0, 0, 0, 0, 0, nan, 0, 0], np.float32)),
+        # all points outside the map
+        (np.full(100, 500.0, np.float32), np.linspace(-300, 300, 100).astype(np.float32), np.zeros(100, np.float32)),
+        # every point in the sensor's own cell (zero-length rays)
+        (np.zeros(64, np.float32), np.zeros(64, np.float32), np.zeros(64, np.float32)),
+        # empty cloud
+        (np.zeros(0, np.float32),) * 3,
+    ]
+    for x, y, z in clouds:
+        h.upload_xyz(x, y, z)
+        h.process_frame(flags)
+        hits, cell, miss, _, _ = oracle_frame(og, tfs, x, y, z)
+        if len(x):
+            assert np.array_equal(h.cell_idx(), cell)
+        assert np.array_equal(h.hits(), hits)
+        assert np.array_equal(h.miss(), miss.astype(np.int32))
+        nlo, _, _ = check_grid(h, og)
+        assert nlo == 0
+    h.close()
+
+
+def test_origin_outside_map_casts_no_rays(gvamd):
+    g = synth.CONFIGS[1]["grid"]
+    h = gvamd.GridVisionHIP(g.grid_x, g.grid_y, g.resolution)
+    og = ol.OGrid(g.grid_x, g.grid_y, g.resolution)
+    tfs = synth.transforms()
+    tfs["base_lidar"] = np.array([0, 0, 0, 1, -500.0, 0.0, 1.8])
+    h.set_transforms(tfs["cam_lidar"], tfs["base_cam"], tfs["base_lidar"])
+    x, y, z, _ = synth.cloud_uniform(1)
+    x = x + np.float32(500.0)
+    h.upload_xyz(x, y, z)
+    h.process_frame(gvamd.FRAME_BIN | gvamd.FRAME_RAYMARCH | gvamd.FRAME_KEEP_COUNTS)
+    hits, cell, miss, _, _ = oracle_frame(og, tfs, x, y, z)
+    assert miss.sum() == 0 and hits.sum() > 0
+    assert np.array_equal(h.hits(), hits)
+    assert h.miss().sum() == 0
+    check_grid(h, og)
+    h.close()
+
+
+def test_pointcloud2_ingest(gvamd):
+    """sensor_msgs/PointCloud2 bytes (PointXYZI, point_step 16 and a padded 32) -> same result as SoA."""
+    h, tfs = make_handle(gvamd, 1)
+    x, y, z, inten = synth.cloud_uniform(1)
+    n = len(x)
+    h.upload_xyz(x, y, z)
+    ref = h.transform_lidar_to_camera()
+    for step, offs in [(16, (0, 4, 8)), (32, (0, 4, 8)), (19, (1, 5, 9))]:
+        raw = np.zeros((n, step), np.uint8)
+        for arr, o in zip((x, y, z), offs):
+            raw[:, o:o + 4] = arr.view(np.uint8).reshape(n, 4)
+        h.upload_pointcloud2(raw.reshape(-1), n, step, *offs)
+        got = h.transform_lidar_to_camera()
+        for a, b in zip(got, ref):
+            assert np.array_equal(a, b)
+    h.close()
+
+
+def test_vision_post_process_tolerance(gvamd):
+    """A13/A14: 64-combination least squares per bbox, one wavefront each.
+    Tolerance 1e-4 relative on the location: device libm and
+    reduction order differ from the host's by ulps; near-tied constraint sets
+    may flip, so the residual is compared too."""
+    h, tfs = make_handle(gvamd, 2)
+    nb = 50
+    bboxes = synth.detections(3, nb)
+    orient, conf, dims = synth.network_outputs(nb)
+    cam = ol.make_cam()
+    exp = ol.post_process(cam, orient, conf, dims, bboxes)
+    got = h.vision_post_process(orient, conf, dims, bboxes)
+    assert len(got) == len(exp) > 0
+    n_close = 0
+    for gpose, epose in zip(got, exp):
+        for k in ("length", "width", "height"):
+            assert gpose[k] == epose[k]
+        gl = np.array([gpose["px"], gpose["py"], gpose["pz"]])
+        el = np.array([epose["px"], epose["py"], epose["pz"]])
+        if np.allclose(gl, el, rtol=1e-3, atol=1e-3):
+            n_close += 1
+        gq = np.array([gpose[q] for q in ("qx", "qy", "qz", "qw")])
+        eq = np.array([epose[q] for q in ("qx", "qy", "qz", "qw")])
+        assert np.allclose(gq, eq, atol=1e-6)
+    assert n_close >= len(exp) - 2, f"only {n_close}/{len(exp)} locations agree"
+    # base-frame transform of the poses (A15) is host fp64: exact vs oracle
+    tb = h.transform_lshape_objects(exp)
+    for i, e in enumerate(exp):
+        pose7 = [e[k] for k in ("px", "py", "pz", "qx", "qy", "qz", "qw")]
+        o = ol.tf_pose(tfs["base_cam"], pose7)
+        assert [tb[i][k] for k in ("px", "py", "pz", "qx", "qy", "qz", "qw")] == o.tolist()
+    h.close()
+
+
+def test_frame_vision_orient_path(gvamd):
+    """use_vision_orientation=true path fused on device: net outputs -> poses -> rectangles."""
+    config = 2
+    h, tfs = make_handle(gvamd, config)
+    g = synth.CONFIGS[config]["grid"]
+    og = ol.OGrid(g.grid_x, g.grid_y, g.resolution)
+    nb = 20
+    bboxes = synth.detections(3, nb)
+    orient, conf, dims = synth.network_outputs(nb)
+    got = h.vision_post_process(orient, conf, dims, bboxes)      # device poses (camera frame)
+    base = h.transform_lshape_objects(got)
+    x, y, z, _ = synth.cloud_uniform(config, 20_000)
+    h.upload_xyz(x, y, z)
+    h.process_frame(gvamd.FRAME_BIN | gvamd.FRAME_RAYMARCH | gvamd.FRAME_VISION_ORIENT | gvamd.FRAME_KEEP_COUNTS,
+                    bboxes=bboxes, net=(orient, conf, dims))
+    # oracle grid update fed with the device's own poses: checks the fused plumbing
+    m_base = ol.tf_to_matrix4f(tfs["base_lidar"])
+    hits, _ = og.bin_points(m_base, x, y, z)
+    miss, _ = og.raymarch(m_base, x, y, z)
+    og.frame_update(base, hits, miss)
+    nlo, _, _ = check_grid(h, og)
+    assert nlo == 0
+    h.close()
+
+
+def test_object_detection_host_side(gvamd):
+    st = synth.Stream(1234, 9)
+    n, c = 300, 10
+    ctr = st.uniform(2 * n, 0.2, 0.8).reshape(n, 2)
+    wh = st.uniform(2 * n, 0.02, 0.3).reshape(n, 2)
+    boxes = np.concatenate([ctr - wh / 2, ctr + wh / 2], axis=1).astype(np.float32)
+    scores = st.uniform(n * c, 0.0, 1.0).reshape(n, c).astype(np.float32)
+    got = gvamd.extract_bboxes(boxes, scores, 0.6, 0.6, 640, 480, 416)
+    exp = ol.extract_bboxes(boxes, scores, 0.6, 0.6, 640, 480, 416)
+    assert len(got) == len(exp) > 5
+    assert got.tobytes() == exp.tobytes()
+    gs, gd = gvamd.filter_bboxes(got)
+    es, ed = ol.filter_bboxes(exp)
+    assert gs.tobytes() == es.tobytes() and gd.tobytes() == ed.tobytes()
+    h = gvamd.GridVisionHIP(50, 20, 0.1)
+    k, ki = h.intrinsics()
+    assert k.tolist() == ol.set_intrinsic(320.0, 320.0, 320.0, 240.0).tolist()
+    assert ki.tolist() == ol.k_inverse(k).tolist()
+    depths = np.linspace(3, 40, len(gs)).astype(np.float32)
+    tfs = synth.transforms()
+    h.set_transforms(tfs["cam_lidar"], tfs["base_cam"], tfs["base_lidar"])
+    pts = h.convert_pixels_to_3d(gs, depths)
+    for i, b in enumerate(gs):
+        pcx = np.float32(b["x_min"] + ((b["x_max"] - b["x_min"]) / np.float32(2.0)))
+        pcy = np.float32(b["y_min"] + ((b["y_max"] - b["y_min"]) / np.float32(2.0)))
+        cam = ol.pixel_to_3d(pcx, pcy, depths[i], ki)
+        assert pts[i].tolist() == ol.tf_point(tfs["base_cam"], cam).tolist()
+    h.close()
