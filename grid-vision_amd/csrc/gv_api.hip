@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -38,6 +39,15 @@ struct gv_context {
   uint32_t *ray_count = nullptr;            // [0] = number of list entries
   unsigned long long *ray_stats = nullptr;  // [0] rays, [1] visits
   int32_t *scratch_i32 = nullptr;           // G ints (miss read-back)
+  // sector/gather ray stage
+  uint8_t *missT = nullptr;                 // G bytes, [x][y]
+  uint32_t *hitN = nullptr, *clipN = nullptr, *hitT = nullptr, *clipT = nullptr;
+  int32_t nxw = 0, nyw = 0, nx_pad = 0, ny_pad = 0;
+  bool tile_path = false;                   // nx % 4 == 0 and the grid fits the packed (a,b) fields
+  bool force_simple = false;                // GV_RAY_IMPL=simple
+  int32_t last_log2s = 0, last_cap = 0;
+  size_t stat_slots = 1;                    // ray_stats slots written by the last frame
+  int32_t env_log2s = 0, env_cap = 0, env_ablate = 0;   // GV_LOG2S / GV_CAP / GV_ABLATE (experiments)
 
   // resident cloud
   float *cx = nullptr, *cy = nullptr, *cz = nullptr;
@@ -56,6 +66,10 @@ struct gv_context {
   float *d_orient = nullptr, *d_conf = nullptr, *d_dims = nullptr;
   VisionOut *d_vout = nullptr;
   double *d_pts = nullptr;
+  float4 *d_bbox_f = nullptr;                // float thresholds of the bbox test
+  unsigned long long *d_tile_mask = nullptr; // candidate masks per 16x16-pixel tile
+  size_t tile_mask_cap = 0;
+  int32_t tiles_x = 0, tiles_y = 0, mask_words = 1;
   int32_t det_cap = 0;
   uint32_t frame_flags = 0;
   int32_t nb = 0, n_poses = 0;
@@ -68,6 +82,8 @@ struct gv_context {
 };
 
 namespace {
+
+constexpr size_t kMaxStatSlots = 8u << 12;   // one (rays, visits) slot per sector workgroup
 
 #define GV_HIP(call)                                                                          \
   do {                                                                                        \
@@ -151,6 +167,7 @@ int ensure_det(gv_context *h, int32_t n)
   if ((rc = re(h->d_dims, (size_t)want * 3 * sizeof(float)))) return rc;
   if ((rc = re(h->d_vout, (size_t)want * sizeof(VisionOut)))) return rc;
   if ((rc = re(h->d_pts, (size_t)want * 3 * sizeof(double)))) return rc;
+  if ((rc = re(h->d_bbox_f, (size_t)want * sizeof(float4)))) return rc;
   h->det_cap = want;
   return GV_OK;
 }
@@ -178,6 +195,7 @@ int clear_counts(gv_context *h)
   GV_HIP(hipMemsetAsync(h->hits, 0, G * sizeof(int32_t), h->stream));
   GV_HIP(hipMemsetAsync(h->miss, 0, G, h->stream));
   GV_HIP(hipMemsetAsync(h->clip_end, 0, G, h->stream));
+  GV_HIP(hipMemsetAsync(h->missT, 0, G, h->stream));
   h->counts_dirty = false;
   return GV_OK;
 }
@@ -185,6 +203,27 @@ int clear_counts(gv_context *h)
 // plain grid update (A7 / A8 / A10): rectangles already in d_rects
 int enqueue_plain_update(gv_context *h, int32_t n_rects)
 {
+  if (h->tile_path) {
+    FinalizeTileArgs t{};
+    t.g = h->g;
+    t.log_odds = h->log_odds;
+    t.occupancy = h->occupancy;
+    t.occ_i8 = h->occ_i8;
+    t.rects = h->d_rects;
+    t.n_rects = n_rects;
+    t.hitN = h->hitN;
+    t.nxw = h->nxw;
+    t.ny_pad = h->ny_pad;
+    t.missN = h->miss;
+    t.missT = h->missT;
+    t.counts = false;
+    t.zero = false;
+    t.y_begin = 0;
+    t.y_end = h->g.ny;
+    launch_finalize_tiles(t, h->stream);
+    GV_HIP(hipGetLastError());
+    return GV_OK;
+  }
   FinalizeArgs f{};
   f.g = h->g;
   f.log_odds = h->log_odds;
@@ -240,6 +279,9 @@ int enqueue_frame(gv_context *h, bool stage_events)
     a.org = h->org;
     a.bboxes = h->d_bboxes;
     a.nb = h->nb;
+    a.bbox_f = h->d_bbox_f;
+    a.tile_mask = h->d_tile_mask;
+    a.tiles_x = h->tiles_x; a.tiles_y = h->tiles_y; a.mask_words = h->mask_words;
     a.hits = h->hits;
     a.clip_end = h->clip_end;
     a.cell_idx = keep_cell ? h->cell_idx : nullptr;
@@ -249,10 +291,80 @@ int enqueue_frame(gv_context *h, bool stage_events)
   }
   if (stage_events) GV_HIP(hipEventRecord(h->ev[kStagePoints + 1], h->stream));
 
-  // --- ray march
+  const bool sectors = h->tile_path && !h->force_simple;
+  if (sectors) {
+    // --- end bitmaps (both orientations), sector gather, tile grid pass
+    if (do_bin) {
+      BitmapArgs b{};
+      b.nx = h->g.nx; b.ny = h->g.ny;
+      b.hits = h->hits; b.clip_end = h->clip_end;
+      b.hitN = h->hitN; b.clipN = h->clipN; b.hitT = h->hitT; b.clipT = h->clipT;
+      b.nxw = h->nxw; b.nyw = h->nyw; b.nx_pad = h->nx_pad; b.ny_pad = h->ny_pad;
+      b.zero_hits = !keep_counts;
+      launch_build_bitmaps(b, h->stream);
+    }
+    if (stage_events) GV_HIP(hipEventRecord(h->ev[kStageRayCompact + 1], h->stream));
+    if (do_ray && h->org.valid) {
+      SectorArgs sa{};
+      sa.g = h->g;
+      sa.org = h->org;
+      // sectors per octant: wedge width <= 32 cells (imax <= 30*S) and ~<= cap ends per sector
+      const int imax = std::max(std::max(h->org.cx, h->g.nx - 1 - h->org.cx), std::max(h->org.cy, h->g.ny - 1 - h->org.cy));
+      int log2s = 8;
+      while ((30 << log2s) < imax) ++log2s;
+      const double dens = std::min((double)h->n, (double)h->g.G) / (double)h->g.G;
+      double est = 0.0;
+      for (;;) {
+        est = 1.5 * dens * (double)imax * (double)imax / (double)(2 << log2s);
+        if (est <= 4096.0 || log2s >= 12) break;
+        ++log2s;
+      }
+      // prefer more sectors over bigger LDS chunks: cap 2048 keeps ~5 workgroups per CU
+      while (est > 1800.0 && log2s < 12) {
+        ++log2s;
+        est *= 0.5;
+      }
+      if (h->env_log2s > 0) log2s = h->env_log2s;
+      sa.log2s = log2s;
+      sa.cap = h->env_cap > 0 ? h->env_cap : ((est <= 1800.0 || h->env_log2s > 0) ? 2048 : 4096);
+      sa.ablate = h->env_ablate;
+      sa.marks_words = (std::max(h->g.nx, h->g.ny) + 2) & ~1;
+      sa.hitN = h->hitN; sa.clipN = h->clipN; sa.hitT = h->hitT; sa.clipT = h->clipT;
+      sa.nxw = h->nxw; sa.nyw = h->nyw; sa.nx_pad = h->nx_pad; sa.ny_pad = h->ny_pad;
+      sa.missN = h->miss;
+      sa.missT = h->missT;
+      sa.stats = h->ray_stats;
+      h->last_log2s = sa.log2s;
+      h->last_cap = sa.cap;
+      h->stat_slots = (size_t)8 << sa.log2s;
+      launch_ray_sectors(sa, h->stream);
+    }
+    if (stage_events) GV_HIP(hipEventRecord(h->ev[kStageRayMarch + 1], h->stream));
+    FinalizeTileArgs t{};
+    t.g = h->g;
+    t.log_odds = h->log_odds;
+    t.occupancy = h->occupancy;
+    t.occ_i8 = h->occ_i8;
+    t.rects = h->d_rects;
+    t.n_rects = n_rects;
+    t.hitN = h->hitN;
+    t.nxw = h->nxw;
+    t.ny_pad = h->ny_pad;
+    t.missN = h->miss;
+    t.missT = h->missT;
+    t.counts = do_bin;
+    t.zero = do_bin && !keep_counts;
+    t.y_begin = 0;
+    t.y_end = h->g.ny;
+    launch_finalize_tiles(t, h->stream);
+    if (stage_events) GV_HIP(hipEventRecord(h->ev[kStageFinalize + 1], h->stream));
+    GV_HIP(hipGetLastError());
+  } else {
+  // --- ray march (generic path: any grid shape)
   if (do_ray && h->org.valid) {
     GV_HIP(hipMemsetAsync(h->ray_count, 0, sizeof(uint32_t), h->stream));
     GV_HIP(hipMemsetAsync(h->ray_stats, 0, 2 * sizeof(unsigned long long), h->stream));
+    h->stat_slots = 1;
     launch_ray_compact(h->hits, h->clip_end, h->g, h->ray_list, h->ray_count, h->stream);
     if (stage_events) GV_HIP(hipEventRecord(h->ev[kStageRayCompact + 1], h->stream));
     launch_ray_march(h->ray_list, h->ray_count, h->g, h->org, h->miss, h->ray_stats, h->stream);
@@ -279,6 +391,7 @@ int enqueue_frame(gv_context *h, bool stage_events)
   launch_finalize(f, h->stream);
   if (stage_events) GV_HIP(hipEventRecord(h->ev[kStageFinalize + 1], h->stream));
   GV_HIP(hipGetLastError());
+  }
 
   h->counts_dirty = do_bin && keep_counts;
   h->have_counts = do_bin && keep_counts;
@@ -291,7 +404,39 @@ int upload_bboxes(gv_context *h, const gv_bbox *b, int32_t nb)
 {
   int rc = ensure_det(h, nb);
   if (rc) return rc;
-  if (nb > 0) GV_HIP(hipMemcpyAsync(h->d_bboxes, b, (size_t)nb * sizeof(gv_bbox), hipMemcpyHostToDevice, h->stream));
+  // float thresholds + tile candidate masks for the first-match test (extractCloudPerBBox)
+  h->tiles_x = (h->cam.orig_w + 15) / 16;
+  h->tiles_y = (h->cam.orig_h + 15) / 16;
+  if (h->tiles_x < 1) h->tiles_x = 1;
+  if (h->tiles_y < 1) h->tiles_y = 1;
+  h->mask_words = std::max(1, (nb + 63) / 64);
+  const size_t nmask = (size_t)h->tiles_x * h->tiles_y * h->mask_words;
+  if ((rc = grow(h, h->d_tile_mask, h->tile_mask_cap, nmask))) return rc;
+  std::vector<float4> bf((size_t)std::max(nb, 1));
+  std::vector<unsigned long long> masks(nmask, 0ull);
+  for (int32_t i = 0; i < nb; ++i) {
+    float4 f;
+    f.x = host::ceil_to_float(b[i].x_min);
+    f.y = host::ceil_to_float(b[i].y_min);
+    f.z = host::floor_to_float(b[i].x_max);
+    f.w = host::floor_to_float(b[i].y_max);
+    bf[i] = f;
+    if (!(f.x <= f.z && f.y <= f.w)) continue;   // empty or NaN box never matches
+    // tiles whose pixel range [16t, 16t+16) can contain a u in [f.x, f.z]
+    int tx0 = (int)std::floor(std::max(f.x, 0.0f) / 16.0f), tx1 = (int)std::floor(std::min(f.z, 16.0f * h->tiles_x - 1.0f) / 16.0f);
+    int ty0 = (int)std::floor(std::max(f.y, 0.0f) / 16.0f), ty1 = (int)std::floor(std::min(f.w, 16.0f * h->tiles_y - 1.0f) / 16.0f);
+    tx0 = std::max(tx0, 0); ty0 = std::max(ty0, 0);
+    tx1 = std::min(tx1, h->tiles_x - 1); ty1 = std::min(ty1, h->tiles_y - 1);
+    for (int ty = ty0; ty <= ty1; ++ty)
+      for (int tx = tx0; tx <= tx1; ++tx)
+        masks[((size_t)ty * h->tiles_x + tx) * h->mask_words + (i >> 6)] |= 1ull << (i & 63);
+  }
+  if (nb > 0) {
+    GV_HIP(hipMemcpyAsync(h->d_bboxes, b, (size_t)nb * sizeof(gv_bbox), hipMemcpyHostToDevice, h->stream));
+    GV_HIP(hipMemcpyAsync(h->d_bbox_f, bf.data(), (size_t)nb * sizeof(float4), hipMemcpyHostToDevice, h->stream));
+  }
+  GV_HIP(hipMemcpyAsync(h->d_tile_mask, masks.data(), nmask * sizeof(unsigned long long), hipMemcpyHostToDevice, h->stream));
+  GV_HIP(hipStreamSynchronize(h->stream));   // bf / masks are stack-owned
   return GV_OK;
 }
 
@@ -353,11 +498,36 @@ int gv_create(gv_handle *out, uint8_t grid_x, uint8_t grid_y, double resolution,
   GV_C(hipMalloc(reinterpret_cast<void **>(&h->clip_end), G + 16));
   GV_C(hipMalloc(reinterpret_cast<void **>(&h->ray_list), G * sizeof(uint32_t)));
   GV_C(hipMalloc(reinterpret_cast<void **>(&h->ray_count), 4 * sizeof(uint32_t)));
-  GV_C(hipMalloc(reinterpret_cast<void **>(&h->ray_stats), 2 * sizeof(unsigned long long)));
+  GV_C(hipMalloc(reinterpret_cast<void **>(&h->ray_stats), kMaxStatSlots * 2 * sizeof(unsigned long long)));
   GV_C(hipMalloc(reinterpret_cast<void **>(&h->scratch_i32), G * sizeof(int32_t)));
+  GV_C(hipMalloc(reinterpret_cast<void **>(&h->missT), G + 16));
+  h->nxw = 2 * ((g.nx + 63) / 64);
+  h->nyw = 2 * ((g.ny + 63) / 64);
+  h->nx_pad = 64 * ((g.nx + 63) / 64);
+  h->ny_pad = 64 * ((g.ny + 63) / 64);
+  {
+    const size_t nN = (size_t)h->ny_pad * h->nxw + 4, nT = (size_t)h->nx_pad * h->nyw + 4;
+    GV_C(hipMalloc(reinterpret_cast<void **>(&h->hitN), nN * sizeof(uint32_t)));
+    GV_C(hipMalloc(reinterpret_cast<void **>(&h->clipN), nN * sizeof(uint32_t)));
+    GV_C(hipMalloc(reinterpret_cast<void **>(&h->hitT), nT * sizeof(uint32_t)));
+    GV_C(hipMalloc(reinterpret_cast<void **>(&h->clipT), nT * sizeof(uint32_t)));
+    GV_C(hipMemsetAsync(h->hitN, 0, nN * sizeof(uint32_t), h->stream));
+    GV_C(hipMemsetAsync(h->clipN, 0, nN * sizeof(uint32_t), h->stream));
+    GV_C(hipMemsetAsync(h->hitT, 0, nT * sizeof(uint32_t), h->stream));
+    GV_C(hipMemsetAsync(h->clipT, 0, nT * sizeof(uint32_t), h->stream));
+  }
+  // packed (a,b) fields hold 13 bits each; vector stores need nx % 4 == 0
+  h->tile_path = (g.nx % 4 == 0) && g.nx <= 8000 && g.ny <= 8000;
+  {
+    const char *impl = std::getenv("GV_RAY_IMPL");
+    h->force_simple = impl && std::strcmp(impl, "simple") == 0;
+    if (const char *e = std::getenv("GV_LOG2S")) h->env_log2s = std::atoi(e);
+    if (const char *e = std::getenv("GV_CAP")) h->env_cap = std::atoi(e);
+    if (const char *e = std::getenv("GV_ABLATE")) h->env_ablate = std::atoi(e);
+  }
   for (auto &e : h->ev) GV_C(hipEventCreate(&e));
   GV_C(hipMemsetAsync(h->ray_count, 0, 4 * sizeof(uint32_t), h->stream));
-  GV_C(hipMemsetAsync(h->ray_stats, 0, 2 * sizeof(unsigned long long), h->stream));
+  GV_C(hipMemsetAsync(h->ray_stats, 0, kMaxStatSlots * 2 * sizeof(unsigned long long), h->stream));
 #undef GV_C
   if (ensure_det(h, 64) != GV_OK) return fail(GV_ERR_HIP);
   if (clear_counts(h) != GV_OK) return fail(GV_ERR_HIP);
@@ -374,9 +544,9 @@ int gv_destroy(gv_handle h)
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   void *bufs[] = {h->log_odds, h->occupancy, h->occ_i8, h->hits, h->miss, h->clip_end, h->ray_list, h->ray_count,
-                  h->ray_stats, h->scratch_i32, h->cx, h->cy, h->cz, h->tx, h->ty, h->tz, h->raw, h->cell_idx,
+                  h->ray_stats, h->scratch_i32, h->missT, h->hitN, h->clipN, h->hitT, h->clipT, h->cx, h->cy, h->cz, h->tx, h->ty, h->tz, h->raw, h->cell_idx,
                   h->bbox_id, h->d_bboxes, h->d_poses, h->d_rects, h->d_orient, h->d_conf, h->d_dims, h->d_vout,
-                  h->d_pts};
+                  h->d_pts, h->d_bbox_f, h->d_tile_mask};
   for (void *p : bufs)
     if (p) (void)hipFree(p);
   for (auto &e : h->ev)
@@ -516,6 +686,9 @@ int gv_extract_cloud_per_bbox(gv_handle h, const gv_bbox *bboxes, int32_t nb, in
   a.cam = h->camk;
   a.bboxes = h->d_bboxes;
   a.nb = nb;
+  a.bbox_f = h->d_bbox_f;
+  a.tile_mask = h->d_tile_mask;
+  a.tiles_x = h->tiles_x; a.tiles_y = h->tiles_y; a.mask_words = h->mask_words;
   a.bbox_id = h->bbox_id;
   a.do_bbox = true;
   launch_points(a, h->stream);
@@ -816,7 +989,10 @@ int gv_get_miss(gv_handle h, int32_t *out)
   if (!h->have_counts) return GV_ERR_STATE;
   int rc = use_device(h);
   if (rc) return rc;
-  launch_u8_to_i32(h->miss, h->scratch_i32, (size_t)h->g.G, h->stream);
+  if (h->tile_path && !h->force_simple)
+    launch_miss_to_i32(h->miss, h->missT, h->g.nx, h->g.ny, h->scratch_i32, h->stream);
+  else
+    launch_u8_to_i32(h->miss, h->scratch_i32, (size_t)h->g.G, h->stream);
   GV_HIP(hipGetLastError());
   return copy_out(h, out, h->scratch_i32, (size_t)h->g.G * sizeof(int32_t));
 }
@@ -838,12 +1014,16 @@ int gv_get_bbox_id(gv_handle h, int32_t *out)
 int gv_get_ray_stats(gv_handle h, uint64_t *n_rays, uint64_t *n_visits)
 {
   if (!h) return GV_ERR_BAD_ARG;
-  unsigned long long st[2] = {0, 0};
-  int rc = copy_out(h, st, h->ray_stats, sizeof(st));
+  GV_TRY
+  std::vector<unsigned long long> st(2 * h->stat_slots, 0ull);
+  int rc = copy_out(h, st.data(), h->ray_stats, st.size() * sizeof(unsigned long long));
   if (rc) return rc;
-  if (n_rays) *n_rays = st[0];
-  if (n_visits) *n_visits = st[1];
+  unsigned long long rays = 0, visits = 0;
+  for (size_t i = 0; i < h->stat_slots; ++i) { rays += st[2 * i]; visits += st[2 * i + 1]; }
+  if (n_rays) *n_rays = rays;
+  if (n_visits) *n_visits = visits;
   return GV_OK;
+  GV_CATCH
 }
 
 void *gv_stream(gv_handle h) { return h ? (void *)h->stream : nullptr; }

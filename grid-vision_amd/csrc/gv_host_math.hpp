@@ -197,6 +197,21 @@ inline void denormalize(std::vector<gv_bbox> &b, int orig_w, int orig_h, int res
   }
 }
 
+// (double)u >= lo  <=>  u >= ceil_f(lo);   (double)u <= hi  <=>  u <= floor_f(hi)
+// for every float u (NaN bounds stay NaN: both forms are then always false).
+inline float ceil_to_float(double v)
+{
+  float f = (float)v;
+  if ((double)f < v) f = std::nextafterf(f, INFINITY);
+  return f;
+}
+inline float floor_to_float(double v)
+{
+  float f = (float)v;
+  if ((double)f > v) f = std::nextafterf(f, -INFINITY);
+  return f;
+}
+
 // host getIndex (same arithmetic as the device one) for geometry-only queries
 inline bool get_index(const GridParams &g, double x, double y, int &ix, int &iy)
 {

@@ -117,12 +117,22 @@ __global__ void __launch_bounds__(256) k_points(PointsArgs a)
         const float u = (float)(krow(a.cam.k, 0, X, Y, Z) / iz);   // :268-272
         const float v = (float)(krow(a.cam.k, 1, X, Y, Z) / iz);   // :273
         if (!(u < 0 || u >= (float)a.cam.W || v < 0 || v >= (float)a.cam.H)) {   // :276
-          const double ud = (double)u, vd = (double)v;
-          for (int b = 0; b < a.nb; ++b) {   // :280-288 first match wins
-            const gv_bbox bb = a.bboxes[b];
-            if (ud >= bb.x_min && ud <= bb.x_max && vd >= bb.y_min && vd <= bb.y_max) {
-              id = b;
-              break;
+          // :280-288 first match wins.  The reference compares (double)u against the
+          // double bounds; bbox_f holds the float thresholds with the identical truth
+          // table (host: smallest float >= x_min, largest float <= x_max), and the
+          // tile masks only prune boxes that cannot contain this pixel, in index order.
+          const int tx = (int)u >> 4, ty = (int)v >> 4;
+          const unsigned long long *tm = a.tile_mask + ((size_t)ty * a.tiles_x + tx) * a.mask_words;
+          for (int wd = 0; wd < a.mask_words && id < 0; ++wd) {
+            unsigned long long m = tm[wd];
+            while (m) {
+              const int b = wd * 64 + (__ffsll((long long)m) - 1);
+              m &= m - 1;
+              const float4 f = a.bbox_f[b];
+              if (u >= f.x && u <= f.z && v >= f.y && v <= f.w) {
+                id = b;
+                break;
+              }
             }
           }
         }

@@ -18,6 +18,10 @@ struct PointsArgs {
   RayOrigin org;
   const gv_bbox *bboxes;
   int32_t nb;
+  // exact fp32 form of the bbox test + per-16x16-pixel-tile candidate masks (host built)
+  const float4 *bbox_f;          // (x_min, y_min, x_max, y_max) as float thresholds
+  const unsigned long long *tile_mask;   // [tiles_y][tiles_x][mask_words]
+  int32_t tiles_x, tiles_y, mask_words;
   int32_t *hits;       // G
   uint8_t *clip_end;   // G
   int32_t *cell_idx;   // N or null
@@ -66,5 +70,50 @@ void launch_finalize(const FinalizeArgs &a, hipStream_t s);
 
 void launch_fill_f32(float *p, float v, size_t n, hipStream_t s);
 void launch_u8_to_i32(const uint8_t *in, int32_t *out, size_t n, hipStream_t s);
+
+// ---- sector/gather ray stage + tile grid pass (gv_raysector.hip) ----
+struct BitmapArgs {
+  int32_t nx, ny;
+  int32_t *hits;          // G   (cleared here when zero_hits)
+  uint8_t *clip_end;      // G   (always cleared here)
+  uint32_t *hitN, *clipN; // bits along x; word(x>>5, y) at (x>>5)*ny_pad + y
+  uint32_t *hitT, *clipT; // bits along y; word(y>>5, x) at (y>>5)*nx_pad + x
+  int32_t nxw, nyw;       // words along x / y (even)
+  int32_t nx_pad, ny_pad; // nx, ny rounded up to 64
+  bool zero_hits;
+};
+void launch_build_bitmaps(const BitmapArgs &a, hipStream_t s);
+
+struct SectorArgs {
+  GridParams g;
+  RayOrigin org;
+  int32_t log2s;          // sectors per octant = 1 << log2s
+  int32_t cap;            // ends per LDS chunk (power of two, >= 2048)
+  int32_t marks_words;    // >= max(nx, ny) + 1
+  const uint32_t *hitN, *clipN, *hitT, *clipT;
+  int32_t nxw, nyw, nx_pad, ny_pad;
+  uint8_t *missN;         // G bytes, [y][x]
+  uint8_t *missT;         // G bytes, [x][y]
+  unsigned long long *stats;
+  int32_t ablate;         // timing experiments only: 1 skip sort, 2 skip gather, 4 skip flush
+};
+size_t sector_lds_bytes(int cap, int marks_words);
+void launch_ray_sectors(const SectorArgs &a, hipStream_t s);
+
+struct FinalizeTileArgs {
+  GridParams g;
+  float *log_odds, *occupancy;
+  int8_t *occ_i8;
+  const Rect *rects;
+  int32_t n_rects;
+  const uint32_t *hitN;
+  int32_t nxw, ny_pad;
+  uint8_t *missN, *missT;
+  bool counts;            // apply the hit/miss rule
+  bool zero;              // clear the miss grids while reading them
+  int32_t y_begin, y_end; // rows to finalise ([0, ny) on one GPU)
+};
+void launch_finalize_tiles(const FinalizeTileArgs &a, hipStream_t s);
+void launch_miss_to_i32(const uint8_t *mN, const uint8_t *mT, int nx, int ny, int32_t *out, hipStream_t s);
 
 }  // namespace gv

@@ -357,3 +357,141 @@ def test_object_detection_host_side(gvamd):
         cam = ol.pixel_to_3d(pcx, pcy, depths[i], ki)
         assert pts[i].tolist() == ol.tf_point(tfs["base_cam"], cam).tolist()
     h.close()
+
+
+@pytest.mark.parametrize("grid", [(50, 20, 0.3), (50, 20, 0.1), (120, 200, 0.25), (255, 255, 0.5)])
+def test_odd_grid_shapes(gvamd, grid):
+    """non-square grids, nx % 4 != 0 (generic kernels) and nx % 64 != 0 (partial tiles)."""
+    gx, gy, res = grid
+    h = gvamd.GridVisionHIP(gx, gy, res)
+    og = ol.OGrid(gx, gy, res)
+    assert (h.nx, h.ny) == (og.nx, og.ny)
+    tfs = synth.transforms(True)
+    tfs["base_lidar"] = np.array([0.0, 0.0, 0.0, 1.0, gx / 3.0 + 1.7, -gy * 0.21, 1.8])
+    h.set_transforms(tfs["cam_lidar"], tfs["base_cam"], tfs["base_lidar"])
+    st = synth.Stream(99, gx)
+    n = 40_000
+    lx, ly = og.g.len_x, og.g.len_y
+    x = st.uniform(n, -0.8 * lx, 0.8 * lx)
+    y = st.uniform(n, -0.8 * ly, 0.8 * ly)
+    z = st.uniform(n, -1.0, 1.0)
+    poses = np.zeros(20, dtype=synth.LSHAPE_DTYPE)
+    poses["px"] = st.uniform(20, og.g.pos_x - lx / 2, og.g.pos_x + lx / 2)
+    poses["py"] = st.uniform(20, -ly / 2, ly / 2)
+    poses["length"] = st.uniform(20, 0.5, 5.0)
+    poses["width"] = st.uniform(20, 0.5, 2.5)
+    h.upload_xyz(x, y, z)
+    flags = gvamd.FRAME_BIN | gvamd.FRAME_RAYMARCH | gvamd.FRAME_KEEP_CELL_IDX | gvamd.FRAME_KEEP_COUNTS
+    for frame in range(2):
+        h.process_frame(flags, poses=poses)
+        hits, cell, miss, _, _ = oracle_frame(og, tfs, x, y, z, None, poses)
+        assert np.array_equal(h.cell_idx(), cell)
+        assert np.array_equal(h.hits(), hits)
+        assert np.array_equal(h.miss(), miss.astype(np.int32))
+        nlo, _, _ = check_grid(h, og)
+        assert nlo == 0
+    h.close()
+
+
+def test_config3_full_size_properties(gvamd):
+    """BASELINE configs[2] at full size (1M points, 2000x2000): size-independent
+    properties instead of the oracle: count conservation, hits <-> cell_idx
+    consistency, a hit cell is never counted free, every free cell lies on the
+    Bresenham line of at least... (checked on a sample against the oracle)."""
+    config = 3
+    h, tfs = make_handle(gvamd, config, perturbed=True)
+    g = synth.CONFIGS[config]["grid"]
+    x, y, z, _ = synth.cloud_uniform(config)
+    bboxes, poses = synth.detections(config), synth.lshape_poses(config)
+    h.upload_xyz(x, y, z)
+    flags = (gvamd.FRAME_BIN | gvamd.FRAME_RAYMARCH | gvamd.FRAME_BBOX_TEST | gvamd.FRAME_KEEP_CELL_IDX
+             | gvamd.FRAME_KEEP_COUNTS)
+    h.process_frame(flags, bboxes=bboxes, poses=poses)
+    cell, hits, miss, ids = h.cell_idx(), h.hits(), h.miss(), h.bbox_id()
+    inmap = cell >= 0
+    assert hits.sum() == inmap.sum()
+    assert np.array_equal(np.bincount(cell[inmap], minlength=h.G).astype(np.int32), hits)
+    assert set(np.unique(miss)) <= {0, 1}
+    assert ids.min() >= -1 and ids.max() < len(bboxes)
+    # the oracle on the same full-size inputs (a few seconds with dedupe)
+    og = ol.OGrid(g.grid_x, g.grid_y, g.resolution)
+    ohits, ocell, omiss, oids, _ = oracle_frame(og, tfs, x, y, z, bboxes, poses)
+    assert np.array_equal(cell, ocell)
+    assert np.array_equal(hits, ohits)
+    assert np.array_equal(miss, omiss.astype(np.int32))
+    assert np.array_equal(ids, oids)
+    nlo, _, _ = check_grid(h, og)
+    assert nlo == 0
+    h.close()
+
+
+def test_simple_ray_impl_matches(gvamd, monkeypatch):
+    """GV_RAY_IMPL=simple (literal per-ray march kernels) and the sector/gather
+    kernels produce the same miss grid."""
+    config = 2
+    x, y, z, _ = synth.cloud_lidar_like(config, 80_000)
+    outs = []
+    for impl in ("simple", "sectors"):
+        monkeypatch.setenv("GV_RAY_IMPL", impl)
+        h, tfs = make_handle(gvamd, config, perturbed=True)
+        h.upload_xyz(x, y, z)
+        h.process_frame(gvamd.FRAME_BIN | gvamd.FRAME_RAYMARCH | gvamd.FRAME_KEEP_COUNTS)
+        outs.append((h.hits(), h.miss(), h.log_odds()))
+        h.close()
+    for a, b in zip(*outs):
+        assert np.array_equal(a, b)
+
+
+def test_sector_chunk_overflow_path(gvamd, monkeypatch):
+    """few, fat sectors (GV_LOG2S=5) with a dense cloud: more ends per wedge than one
+    LDS chunk holds, so the chunked scan/flush path of the sector kernel runs."""
+    monkeypatch.setenv("GV_LOG2S", "5")
+    monkeypatch.setenv("GV_CAP", "2048")
+    config = 2
+    h, tfs = make_handle(gvamd, config, perturbed=True)
+    g = synth.CONFIGS[config]["grid"]
+    og = ol.OGrid(g.grid_x, g.grid_y, g.resolution)
+    x, y, z, _ = synth.cloud_uniform(config, 700_000)
+    h.upload_xyz(x, y, z)
+    h.process_frame(gvamd.FRAME_BIN | gvamd.FRAME_RAYMARCH | gvamd.FRAME_KEEP_COUNTS)
+    hits, cell, miss, _, _ = oracle_frame(og, tfs, x, y, z)
+    assert np.array_equal(h.hits(), hits)
+    assert np.array_equal(h.miss(), miss.astype(np.int32))
+    n_rays, n_visits = h.ray_stats()
+    assert n_rays > 32 * 8 * 2048 // 2   # some wedges must have overflowed one chunk
+    h.close()
+
+
+def test_bbox_test_many_fractional_boxes(gvamd):
+    """150 overlapping boxes (3 mask words) with fractional fp64 bounds, some exactly on
+    float values of projected pixels: the float-threshold form must keep the fp64 truth table."""
+    h, tfs = make_handle(gvamd, 2, perturbed=True)
+    x, y, z, _ = synth.cloud_lidar_like(2, 120_000)
+    m_cam = ol.tf_to_matrix4f(tfs["cam_lidar"])
+    cx, cy, cz = ol.transform_cloud(m_cam, x, y, z)
+    K = ol.set_intrinsic(synth.FX, synth.FY, synth.CX, synth.CY)
+    u, v, _ = ol.project_points(K, cx, cy, cz)
+    st = synth.Stream(77, 3)
+    nb = 150
+    b = np.zeros(nb, dtype=synth.BBOX_DTYPE)
+    x0 = st.uniform(nb, -20, 600).astype(np.float64) + 1e-7
+    y0 = st.uniform(nb, -20, 440).astype(np.float64) - 1e-9
+    b["x_min"], b["y_min"] = x0, y0
+    b["x_max"] = x0 + st.uniform(nb, 1, 120).astype(np.float64)
+    b["y_max"] = y0 + st.uniform(nb, 1, 120).astype(np.float64)
+    # bounds sitting exactly on projected pixel coordinates (inclusive edges must match)
+    pick = st.integers(40, 0, len(u))
+    b["x_min"][:20] = u[pick[:20]].astype(np.float64)
+    b["x_max"][20:40] = u[pick[20:40]].astype(np.float64)
+    b["x_max"][:20] = b["x_min"][:20] + 50
+    b["x_min"][20:40] = b["x_max"][20:40] - 50
+    b[140]["x_min"] = np.nan          # never matches
+    b[141]["x_max"] = b[141]["x_min"] - 1   # empty
+    b["confidence"] = np.sort(st.uniform(nb, 0.5, 1.0))[::-1]
+    b["label"] = st.integers(nb, 0, 10)
+    h.upload_xyz(x, y, z)
+    ids, counts = h.extract_cloud_per_bbox(b)
+    exp = ol.extract_cloud_per_bbox(K, cx, cy, cz, b, synth.IMG_W, synth.IMG_H)
+    assert np.array_equal(ids, exp)
+    assert (exp >= 64).sum() > 0 and (exp >= 128).sum() > 0, "fixture must reach the 2nd and 3rd mask word"
+    h.close()
