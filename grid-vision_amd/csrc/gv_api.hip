@@ -46,8 +46,9 @@ struct gv_context {
   bool tile_path = false;                   // nx % 4 == 0 and the grid fits the packed (a,b) fields
   bool force_simple = false;                // GV_RAY_IMPL=simple
   int32_t last_log2s = 0, last_cap = 0;
+  unsigned long long *d_dbg = nullptr;      // GV_SECTOR_DBG=1: phase stamps of the sector kernel
   size_t stat_slots = 1;                    // ray_stats slots written by the last frame
-  int32_t env_log2s = 0, env_cap = 0, env_ablate = 0;   // GV_LOG2S / GV_CAP / GV_ABLATE (experiments)
+  int32_t env_log2s = 0, env_cap = 0, env_ablate = 0, env_log2m = 0;   // GV_LOG2S / GV_CAP / GV_ABLATE (experiments)
 
   // resident cloud
   float *cx = nullptr, *cy = nullptr, *cz = nullptr;
@@ -310,24 +311,24 @@ int enqueue_frame(gv_context *h, bool stage_events)
       sa.org = h->org;
       // sectors per octant: wedge width <= 32 cells (imax <= 30*S) and ~<= cap ends per sector
       const int imax = std::max(std::max(h->org.cx, h->g.nx - 1 - h->org.cx), std::max(h->org.cy, h->g.ny - 1 - h->org.cy));
-      int log2s = 8;
+      // Measured on config 3 (tools/sweep_sectors.sh): 128 sectors per octant with 4096-end
+      // LDS chunks beats 256 x 2048 (62 vs 79 us): the kernel is bound by per-workgroup
+      // latency chains, so fewer, fatter wedges win as long as a wedge fits one chunk.
+      int log2s = 7;
       while ((30 << log2s) < imax) ++log2s;
       const double dens = std::min((double)h->n, (double)h->g.G) / (double)h->g.G;
-      double est = 0.0;
-      for (;;) {
-        est = 1.5 * dens * (double)imax * (double)imax / (double)(2 << log2s);
-        if (est <= 4096.0 || log2s >= 12) break;
-        ++log2s;
-      }
-      // prefer more sectors over bigger LDS chunks: cap 2048 keeps ~5 workgroups per CU
-      while (est > 1800.0 && log2s < 12) {
+      double est = 1.5 * dens * (double)imax * (double)imax / (double)(2 << log2s);
+      while (est > 3600.0 && log2s < 12) {
         ++log2s;
         est *= 0.5;
       }
       if (h->env_log2s > 0) log2s = h->env_log2s;
       sa.log2s = log2s;
-      sa.cap = h->env_cap > 0 ? h->env_cap : ((est <= 1800.0 || h->env_log2s > 0) ? 2048 : 4096);
+      sa.cap = h->env_cap > 0 ? std::max(2048, h->env_cap) : ((est <= 1700.0 && h->env_log2s <= 0) ? 2048 : 4096);
       sa.ablate = h->env_ablate;
+      sa.dbg = h->d_dbg;
+      sa.log2m = h->env_log2m > 0 ? h->env_log2m : 9;
+      while (sa.log2m < 9 && ((1 << sa.log2m) << sa.log2s) <= imax) ++sa.log2m;   // one boundary per bucket
       sa.marks_words = (std::max(h->g.nx, h->g.ny) + 2) & ~1;
       sa.hitN = h->hitN; sa.clipN = h->clipN; sa.hitT = h->hitT; sa.clipT = h->clipT;
       sa.nxw = h->nxw; sa.nyw = h->nyw; sa.nx_pad = h->nx_pad; sa.ny_pad = h->ny_pad;
@@ -524,6 +525,13 @@ int gv_create(gv_handle *out, uint8_t grid_x, uint8_t grid_y, double resolution,
     if (const char *e = std::getenv("GV_LOG2S")) h->env_log2s = std::atoi(e);
     if (const char *e = std::getenv("GV_CAP")) h->env_cap = std::atoi(e);
     if (const char *e = std::getenv("GV_ABLATE")) h->env_ablate = std::atoi(e);
+    if (const char *e = std::getenv("GV_SECTOR_DBG")) {
+      if (std::atoi(e) > 0) {
+        GV_C(hipMalloc(reinterpret_cast<void **>(&h->d_dbg), kMaxStatSlots * 16 * sizeof(unsigned long long)));
+        GV_C(hipMemsetAsync(h->d_dbg, 0, kMaxStatSlots * 16 * sizeof(unsigned long long), h->stream));
+      }
+    }
+    if (const char *e = std::getenv("GV_LOG2M")) h->env_log2m = std::min(9, std::max(4, std::atoi(e)));
   }
   for (auto &e : h->ev) GV_C(hipEventCreate(&e));
   GV_C(hipMemsetAsync(h->ray_count, 0, 4 * sizeof(uint32_t), h->stream));
@@ -544,7 +552,7 @@ int gv_destroy(gv_handle h)
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   void *bufs[] = {h->log_odds, h->occupancy, h->occ_i8, h->hits, h->miss, h->clip_end, h->ray_list, h->ray_count,
-                  h->ray_stats, h->scratch_i32, h->missT, h->hitN, h->clipN, h->hitT, h->clipT, h->cx, h->cy, h->cz, h->tx, h->ty, h->tz, h->raw, h->cell_idx,
+                  h->ray_stats, h->scratch_i32, h->d_dbg, h->missT, h->hitN, h->clipN, h->hitT, h->clipT, h->cx, h->cy, h->cz, h->tx, h->ty, h->tz, h->raw, h->cell_idx,
                   h->bbox_id, h->d_bboxes, h->d_poses, h->d_rects, h->d_orient, h->d_conf, h->d_dims, h->d_vout,
                   h->d_pts, h->d_bbox_f, h->d_tile_mask};
   for (void *p : bufs)
@@ -1024,6 +1032,13 @@ int gv_get_ray_stats(gv_handle h, uint64_t *n_rays, uint64_t *n_visits)
   if (n_visits) *n_visits = visits;
   return GV_OK;
   GV_CATCH
+}
+
+// diagnostic only (tools/sector_phases.py): copies the phase stamps of the last sector launch
+int gv_debug_sector_stamps(gv_handle h, unsigned long long *out, size_t n_wg)
+{
+  if (!h || !out || !h->d_dbg) return GV_ERR_STATE;
+  return copy_out(h, out, h->d_dbg, n_wg * 16 * sizeof(unsigned long long));
 }
 
 void *gv_stream(gv_handle h) { return h ? (void *)h->stream : nullptr; }

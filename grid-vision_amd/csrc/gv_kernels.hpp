@@ -88,16 +88,18 @@ struct SectorArgs {
   GridParams g;
   RayOrigin org;
   int32_t log2s;          // sectors per octant = 1 << log2s
-  int32_t cap;            // ends per LDS chunk (power of two, >= 2048)
+  int32_t cap;            // ends per LDS chunk (>= 2048)
+  int32_t log2m;          // slope buckets per sector = 1 << log2m (<= 9)
   int32_t marks_words;    // >= max(nx, ny) + 1
   const uint32_t *hitN, *clipN, *hitT, *clipT;
   int32_t nxw, nyw, nx_pad, ny_pad;
   uint8_t *missN;         // G bytes, [y][x]
   uint8_t *missT;         // G bytes, [x][y]
   unsigned long long *stats;
-  int32_t ablate;         // timing experiments only: 1 skip sort, 2 skip gather, 4 skip flush
+  int32_t ablate;         // timing experiments only: 2 skip gather, 4 skip flush, 8/16/32 early exits
+  unsigned long long *dbg; // diagnostic phase stamps, 16 per workgroup (null in production)
 };
-size_t sector_lds_bytes(int cap, int marks_words);
+size_t sector_lds_bytes(int cap, int marks_words, int log2m);
 void launch_ray_sectors(const SectorArgs &a, hipStream_t s);
 
 struct FinalizeTileArgs {

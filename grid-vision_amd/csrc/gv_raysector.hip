@@ -10,10 +10,12 @@
 // cell depends on the ray only through its slope b/a.  So cell (i,j) is free
 //        iff  some end has slope in [(2j-1)/2i, (2j+1)/2i)  and  reach > i
 // (reach = a for a hit end, a+1 for a clipped end whose own cell counts).
-// That is a range-max query over the ends sorted by slope.  Each workgroup owns
+// That is a range-max query over the ends ordered by slope.  Each workgroup owns
 // one angular sector of one octant: it collects its ends from end bitmaps,
-// sorts them by slope in LDS, builds a block-decomposed range-max structure,
-// and answers every cell of its wedge with two binary searches.  Everything is
+// counting-sorts them into M slope buckets in LDS (exact integer bucket index),
+// builds a sparse range-max table over the bucket maxima, and answers every cell
+// of its wedge from the table plus exact cross-multiplication tests on the (at
+// most two) buckets its slope interval only partly covers.  Everything is
 // integer arithmetic: bit-exact against the oracle's literal march.
 #include "gv_kernels.hpp"
 
@@ -109,10 +111,47 @@ __device__ __forceinline__ unsigned pack_ab(int a, int b, int incl) { return ((u
 __device__ __forceinline__ int ab_a(unsigned p) { return (int)(p >> 14) & 0x1FFF; }
 __device__ __forceinline__ int ab_b(unsigned p) { return (int)(p >> 1) & 0x1FFF; }
 
-__global__ void __launch_bounds__(256) k_ray_sectors(SectorArgs A)
+constexpr int kSecThreads = 512;   // 8 wavefronts per sector workgroup
+#ifndef GV_SECTOR_WPE
+#define GV_SECTOR_WPE 4             // min waves per SIMD the register allocator must allow
+#endif
+
+// LDS layout of one sector workgroup (bytes), shared by the kernel and the launcher
+struct SectorLds {
+  size_t abv, marks, cnt, bstart, bmax32, un, lvl, pfx, sfx, raw, bkt, total;
+};
+__host__ __device__ inline SectorLds sector_lds_layout(int cap, int marks_words, int log2m)
 {
+  const size_t M = (size_t)1 << log2m;
+  SectorLds L;
+  size_t o = 0;
+  L.abv = o;    o += (size_t)cap * 4;
+  L.marks = o;  o += (size_t)marks_words * 4;
+  L.cnt = o;    o += M * 4;
+  L.bstart = o; o += (M + 2) * 4;
+  L.bmax32 = o; o += M * 4;
+  // union: {staging list: raw ends + their bucket ids} is dead once the ends are placed,
+  // which is before {range-max tables} are written
+  L.un = o;
+  L.lvl = o;
+  L.pfx = L.lvl + 7 * M * 2;        // in-block (64 buckets) sparse levels 0..6
+  L.sfx = L.pfx + M * 2;
+  const size_t tables = 9 * M * 2;
+  L.raw = o;
+  L.bkt = L.raw + (size_t)cap * 4;
+  const size_t staging = (size_t)cap * 6;
+  o += (tables > staging ? tables : staging);
+  L.total = (o + 15) & ~(size_t)15;
+  return L;
+}
+
+template <int CH>
+__global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(SectorArgs A)
+{
+  constexpr int NT = kSecThreads;
   extern __shared__ __align__(16) unsigned char smem[];
   const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
   const int S = 1 << A.log2s;
   const int o = blockIdx.x >> A.log2s;
   const int s = blockIdx.x & (S - 1);
@@ -121,24 +160,36 @@ __global__ void __launch_bounds__(256) k_ray_sectors(SectorArgs A)
     if (threadIdx.x == 0 && A.stats) { A.stats[2 * blockIdx.x] = 0; A.stats[2 * blockIdx.x + 1] = 0; }
     return;
   }
-  const int cap = A.cap, nblk = cap >> 4;
-  int nlev = 0;
-  while ((1 << nlev) < nblk) ++nlev;
-  ++nlev;   // levels 0..log2(nblk)
+  const int cap = A.cap;
+  const int LM = A.log2m, M = 1 << LM, NB = (M + 63) >> 6;
 
-  // LDS carve-up (10 bytes per end + marks): packed ends, then reach / prefix / suffix maxima
-  unsigned *abv = reinterpret_cast<unsigned *>(smem);                                   // cap
-  unsigned *marks = abv + cap;                                                          // marks_words
-  unsigned short *reach = reinterpret_cast<unsigned short *>(marks + A.marks_words);    // cap
-  unsigned short *pm = reach + cap;                                                     // cap
-  unsigned short *sm = pm + cap;                                                        // cap
-  unsigned short *bmx = sm + cap;                                                       // nlev * nblk
-  __shared__ unsigned s_count, s_batch;
-  __shared__ unsigned long long s_rays, s_visits;
+  const SectorLds L = sector_lds_layout(cap, A.marks_words, LM);
+  unsigned *abv = reinterpret_cast<unsigned *>(smem + L.abv);          // packed ends grouped by slope bucket
+  unsigned *marks = reinterpret_cast<unsigned *>(smem + L.marks);      // one word of cell bits per wedge column
+  unsigned *cnt = reinterpret_cast<unsigned *>(smem + L.cnt);          // bucket counts, then placement cursors
+  unsigned *bstart = reinterpret_cast<unsigned *>(smem + L.bstart);    // bucket starts (M+1)
+  unsigned *bmax32 = reinterpret_cast<unsigned *>(smem + L.bmax32);    // bucket max reach
+  unsigned short *lvl = reinterpret_cast<unsigned short *>(smem + L.lvl);   // lvl[l*M+m] = max of buckets m..m+2^l-1 inside m's 64-block
+  unsigned short *pfx = reinterpret_cast<unsigned short *>(smem + L.pfx);   // max from the block start to m
+  unsigned short *sfx = reinterpret_cast<unsigned short *>(smem + L.sfx);   // max from m to the block end
+  unsigned *raw = reinterpret_cast<unsigned *>(smem + L.raw);               // staging: packed ends, scan order
+  unsigned short *bkt = reinterpret_cast<unsigned short *>(smem + L.bkt);   // staging: their slope buckets
+  __shared__ unsigned s_wsum[NT / 64], s_blkmax[8], s_lvlmin[16], s_nlong;
+  __shared__ unsigned long long s_wvis[NT / 64];
 
-  for (int i = tid; i <= oc.imax; i += 256) marks[i] = 0;
-  if (tid == 0) { s_count = 0; s_rays = 0; s_visits = 0; }
+  // diagnostic build only (GV_SECTOR_DBG=1): thread 0 stamps the shader clock at phase
+  // boundaries into a debug buffer nothing else reads; A.dbg is null in production
+  int stamp_n = 0;
+  auto stamp = [&]() {
+    if (A.dbg && tid == 0 && stamp_n < 16) A.dbg[(size_t)blockIdx.x * 16 + stamp_n] = __builtin_amdgcn_s_memtime();
+    ++stamp_n;
+  };
+  stamp();
+  for (int i = tid; i <= oc.imax; i += NT) marks[i] = 0;
+  if (tid < NT / 64) s_wvis[tid] = 0;
   __syncthreads();
+  stamp();   // 1: init done
+  if (A.ablate & 8) return;    // timing experiment: launch + init only
 
   const unsigned *bmH = oc.xmaj ? A.hitT : A.hitN;
   const unsigned *bmC = oc.xmaj ? A.clipT : A.clipN;
@@ -147,252 +198,438 @@ __global__ void __launch_bounds__(256) k_ray_sectors(SectorArgs A)
   const int oc_major = oc.xmaj ? A.org.cx : A.org.cy;
   const int oc_minor = oc.xmaj ? A.org.cy : A.org.cx;
 
-  // process the collected chunk [0, n): sort by slope, build range-max, gather
-  auto process_chunk = [&](int n) {
-    int npad = 64;
-    while (npad < n) npad <<= 1;
-    constexpr unsigned kSent = 0xFFFFFFFFu;   // sorts after every real end
-    for (int k = n + tid; k < npad; k += 256) abv[k] = kSent;
+  // exact floor(N / Q) for 0 <= N < 2^24, 0 < Q: float estimate + one integer correction
+  auto idiv = [](int N, int Q) -> int {
+    int q = (int)((float)N * __builtin_amdgcn_rcpf((float)Q));
+    const int r = N - q * Q;
+    if (r < 0) --q;
+    else if (r >= Q) ++q;
+    return q;
+  };
+  // wavefront sum / min by butterfly shuffles (no same-address LDS atomics: those serialise)
+  auto wave_sum = [](unsigned v) -> unsigned {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+  };
+  auto wave_min = [](unsigned v) -> unsigned {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = min(v, (unsigned)__shfl_xor(v, off));
+    return v;
+  };
+  // slope bucket of an end: floor((b*S - a*s) * M / a); slope 1 (last sector) -> M-1
+  auto bucket_of_end = [&](int a, int b) -> int {
+    const int rel = b * S - a * s;
+    return (rel >= a) ? (M - 1) : idiv(rel << LM, a);
+  };
+  // bucket holding the boundary slope P/Q: -1 below the sector, M at/above its end
+  auto bucket_of_boundary = [&](int P, int Q) -> int {
+    const int relb = P * S - s * Q;
+    return (relb <= 0) ? -1 : (relb >= Q) ? M : idiv(relb << LM, Q);
+  };
+  // max reach over whole buckets [l, r] (l <= r)
+  auto rmq = [&](int l, int r) -> unsigned {
+    const int bl = l >> 6, br = r >> 6;
+    if (bl == br) {
+      const int lev = 31 - __clz(r - l + 1);
+      return max((unsigned)lvl[lev * M + l], (unsigned)lvl[lev * M + r - (1 << lev) + 1]);
+    }
+    unsigned mx = max((unsigned)sfx[l], (unsigned)pfx[r]);
+    for (int bk = bl + 1; bk < br; ++bk) mx = max(mx, s_blkmax[bk]);
+    return mx;
+  };
+
+  // ---- scan: CH columns per thread (a = 1 + tid + NT*c), bitmap loads issued back to back
+  unsigned ends[CH], vcs[CH];
+  int blos[CH], bhis[CH];
+  {
+    unsigned h0[CH], h1[CH], c0[CH], c1[CH];
+    int shs[CH], ws[CH];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      const int a = 1 + tid + NT * c;
+      const bool in = a <= oc.imax;
+      const int ac = in ? a : 1;
+      const int bmaxa = oc.xmaj ? ac : ac - 1;
+      int blo = (ac * s + S - 1) >> A.log2s;
+      int bhi = ((ac * (s + 1) + S - 1) >> A.log2s) - 1;
+      if (s == S - 1) bhi = bmaxa;
+      blo = max(blo, oc.bmin);
+      bhi = min(min(bhi, bmaxa), oc.jmaxo);
+      const bool ok = in && blo <= bhi;
+      const int w = ok ? bhi - blo + 1 : 0;   // <= 32 (host guarantees imax <= 30*S)
+      const int major_abs = oc_major + oc.smaj * ac;
+      const int m_lo = ok ? ((oc.smin > 0) ? oc_minor + blo : oc_minor - bhi) : 0;
+      const int w0 = m_lo >> 5;
+      const size_t base = (size_t)w0 * major_pad + major_abs;
+      const size_t base1 = (w0 + 1 < roww) ? base + major_pad : base;
+      h0[c] = bmH[base]; c0[c] = bmC[base];
+      h1[c] = bmH[base1]; c1[c] = bmC[base1];
+      shs[c] = m_lo & 31;
+      ws[c] = w;
+      blos[c] = blo;
+      bhis[c] = bhi;
+    }
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      const unsigned long long h64 = ((unsigned long long)h1[c] << 32) | h0[c];
+      const unsigned long long c64 = ((unsigned long long)c1[c] << 32) | c0[c];
+      const unsigned wm = (ws[c] >= 32) ? 0xFFFFFFFFu : ((1u << ws[c]) - 1u);
+      const unsigned vh = (unsigned)(h64 >> shs[c]) & wm;
+      vcs[c] = (unsigned)(c64 >> shs[c]) & wm;
+      ends[c] = vh | vcs[c];   // bit t <-> b = blo + t (positive minor side) or bhi - t
+    }
+  }
+  // total number of ends: one wavefront reduction + one LDS slot per wavefront
+  {
+    unsigned mine = 0;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) mine += (unsigned)__popc(ends[c]);
+    const unsigned r = wave_sum(mine);
+    if (lane == 0) s_wsum[wave] = r;
+  }
+  __syncthreads();
+  int total = 0;
+#pragma unroll
+  for (int wv = 0; wv < NT / 64; ++wv) total += (int)s_wsum[wv];
+  __syncthreads();   // s_wsum is reused by the groups below
+  stamp();   // 2: scan done
+  if (A.ablate & 16) return;   // timing experiment: + scan
+  if (total == 0) {
+    if (tid == 0 && A.stats) { A.stats[2 * blockIdx.x] = 0; A.stats[2 * blockIdx.x + 1] = 0; }
+    return;
+  }
+
+  // One group = the ends of the selected (row c, wavefront) sets; at most cap of them.
+  // rowmask: rows taking part; wsel: -1 = every wavefront, else only that one.
+  // highest level of aligned bucket groups a column of this wedge can ask for
+  const int tqmax = (2 * oc.imax + S - 1) >> A.log2s;
+  const int lv_max = (tqmax <= 1) ? 0 : 32 - __clz(tqmax - 1);
+  auto process_group = [&](unsigned rowmask, int wsel) {
+    const bool mine_w = (wsel < 0) || (wave == wsel);
+    for (int m = tid; m < M; m += NT) { cnt[m] = 0; bmax32[m] = 0; }
+    if (tid < 16) s_lvlmin[tid] = 0xFFFFFFFFu;
     __syncthreads();
-    // bitonic sort by slope b/a, ascending; exact order by cross-multiplication
-    if (!(A.ablate & 1)) {
-      // thread t owns compare-exchange pairs t, t+256, ...; a wavefront's 64 consecutive
-      // pairs span 128 consecutive elements, so strides j <= 64 never cross wavefronts:
-      // those steps need only wave-level ordering of the LDS traffic, no block barrier.
-      for (int k = 2; k <= npad; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-          for (int t = tid; t < (npad >> 1); t += 256) {
-            const int lo = ((t & ~(j - 1)) << 1) | (t & (j - 1));
-            const int hi = lo | j;
-            const bool up = ((lo & k) == 0);
-            const unsigned x = abv[lo], y = abv[hi];
-            bool sw;
-            if (x == kSent || y == kSent) {
-              // sentinel sorts last
-              sw = up ? (x == kSent && y != kSent) : (y == kSent && x != kSent);
-            } else {
-              const unsigned l = (unsigned)ab_b(x) * (unsigned)ab_a(y), r = (unsigned)ab_b(y) * (unsigned)ab_a(x);
-              sw = up ? (l > r) : (l < r);
-            }
-            if (sw) { abv[lo] = y; abv[hi] = x; }
-          }
-          if (j > 64) __syncthreads();
-          else {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-          }
-        }
-        __syncthreads();
+    // append this group's ends to the dense staging list: slots by wavefront prefix sums
+    unsigned mycnt = 0;
+#pragma unroll
+    for (int c = 0; c < CH; ++c)
+      if (((rowmask >> c) & 1u) && mine_w) mycnt += (unsigned)__popc(ends[c]);
+    unsigned incl = mycnt;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const unsigned v = __shfl_up(incl, off);
+      if (lane >= off) incl += v;
+    }
+    if (lane == 63) s_wsum[wave] = incl;
+    __syncthreads();
+    unsigned slot = incl - mycnt;
+    unsigned n = 0;
+#pragma unroll
+    for (int wv = 0; wv < NT / 64; ++wv) {
+      if (wv < wave) slot += s_wsum[wv];
+      n += s_wsum[wv];
+    }
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      if (!((rowmask >> c) & 1u) || !mine_w) continue;
+      const int a = 1 + tid + NT * c;
+      unsigned e = ends[c];
+      while (e) {
+        const int t = __ffs(e) - 1;
+        e &= e - 1;
+        const int b = (oc.smin > 0) ? blos[c] + t : bhis[c] - t;
+        raw[slot] = pack_ab(a, b, (int)((vcs[c] >> t) & 1u));
+        bkt[slot] = (unsigned short)bucket_of_end(a, b);
+        ++slot;
       }
     }
-    // payloads + per-block (16) prefix / suffix maxima + sparse table over block maxima
-    unsigned long long vis = 0;
-    for (int b = tid; b < nblk; b += 256) {
-      unsigned short run = 0;
-      unsigned short r16[16];
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int k = b * 16 + e;
-        unsigned short r = 0;
-        if (k < n) {
-          const unsigned p = abv[k];
-          r = (unsigned short)(ab_a(p) + (int)(p & 1u));
-          vis += r;
-        }
-        r16[e] = r;
-        run = r > run ? r : run;
-        if (k < cap) { reach[k] = r; pm[k] = run; }
-      }
-      bmx[b] = run;
-      run = 0;
-#pragma unroll
-      for (int e = 15; e >= 0; --e) {
-        run = r16[e] > run ? r16[e] : run;
-        sm[b * 16 + e] = run;
-      }
-    }
-    if (vis) atomicAdd(&s_visits, vis);
     __syncthreads();
-    for (int l = 1; l < nlev; ++l) {
-      const int half = 1 << (l - 1);
-      for (int b = tid; b < nblk; b += 256) {
-        const unsigned short x = bmx[(l - 1) * nblk + b];
-        const unsigned short y = (b + half < nblk) ? bmx[(l - 1) * nblk + b + half] : (unsigned short)0;
-        bmx[l * nblk + b] = x > y ? x : y;
+    stamp();   // 3: staged
+    // bucket counts over the dense list
+    for (unsigned k = tid; k < n; k += NT) atomicAdd(&cnt[bkt[k]], 1u);
+    __syncthreads();
+    // exclusive prefix over the M bucket counts (thread m owns bucket m; M <= NT)
+    {
+      const unsigned bc = (tid < M) ? cnt[tid] : 0u;
+      unsigned in2 = bc;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const unsigned v = __shfl_up(in2, off);
+        if (lane >= off) in2 += v;
       }
+      if (lane == 63) s_wsum[wave] = in2;
       __syncthreads();
+      unsigned base = 0;
+      for (int wv = 0; wv < wave; ++wv) base += s_wsum[wv];
+      if (tid < M) {
+        bstart[tid] = base + in2 - bc;
+        cnt[tid] = base + in2 - bc;   // placement cursor
+      }
+      if (tid == M - 1) bstart[M] = base + in2;
+    }
+    __syncthreads();
+    stamp();   // 4: prefix
+    // place the packed ends into their buckets; bucket max reach; visit statistics
+    {
+      unsigned long long vis = 0;
+      for (unsigned k = tid; k < n; k += NT) {
+        const unsigned p = raw[k];
+        const unsigned m = bkt[k];
+        const unsigned rch = (unsigned)(ab_a(p) + (int)(p & 1u));
+        abv[atomicAdd(&cnt[m], 1u)] = p;
+        atomicMax(&bmax32[m], rch);
+        vis += rch;
+      }
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) vis += __shfl_xor(vis, off);
+      if (lane == 0 && vis) s_wvis[wave] += vis;   // one owner per slot
+    }
+    __syncthreads();
+    stamp();   // 5: placed
+    // range-max structure: wavefront `wave` owns the 64-bucket block `wave` (shuffles only)
+    if (wave < NB) {
+      const int m = wave * 64 + lane;
+      const unsigned v0 = (m < M) ? bmax32[m] : 0u;
+      unsigned v = v0;
+      if (m < M) lvl[m] = (unsigned short)v;
+      // level minima: s_lvlmin[Lv] = min over the 2^Lv aligned groups of M>>Lv buckets of the
+      // group's max reach (0 if a group is empty).  Groups of <= 64 buckets live inside one
+      // block: reduce them here; coarser levels are read off s_blkmax at query time.
+      // only levels Lv <= lv_max are ever queried (2^Lv >= 2i/S, i <= imax)
+      if (LM <= lv_max) {
+        const unsigned mn = wave_min((m < M) ? v : 0xFFFFFFFFu);
+        if (lane == 0) atomicMin(&s_lvlmin[LM], mn);
+      }
+#pragma unroll
+      for (int l = 1; l <= 6; ++l) {
+        const int h = 1 << (l - 1);
+        const unsigned up = __shfl_down(v, h);
+        if (lane + h < 64) v = max(v, up);
+        if (m < M) lvl[l * M + m] = (unsigned short)v;
+        if (l <= LM && LM - l <= lv_max) {
+          const unsigned mn = wave_min(((lane & ((1 << l) - 1)) == 0 && m < M) ? v : 0xFFFFFFFFu);
+          if (lane == 0) atomicMin(&s_lvlmin[LM - l], mn);
+        }
+      }
+      unsigned p = v0, q = v0;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const unsigned pu = __shfl_up(p, off), qd = __shfl_down(q, off);
+        if (lane >= off) p = max(p, pu);
+        if (lane + off < 64) q = max(q, qd);
+      }
+      if (m < M) { pfx[m] = (unsigned short)p; sfx[m] = (unsigned short)q; }
+      if (lane == 63) s_blkmax[wave] = p;
+    }
+    __syncthreads();
+    stamp();   // 6: range-max built
+    // T = last column up to which every interior cell is known free from the level minima
+    // (the test is monotone in i).  Columns beyond T are crossed only by the few rays with
+    // reach > T+1: when that is cheap, march exactly those rays over exactly those columns
+    // instead of evaluating every cell there.
+    int T = 0;
+    {
+      bool open = true;
+      for (int Lv = 0; Lv <= lv_max && Lv <= LM && open; ++Lv) {
+        // columns whose cell width asks for level Lv: ceil(2i/S) in (2^(Lv-1), 2^Lv]
+        const int hiL = min(oc.imax, (Lv == 0) ? (S >> 1) : (int)(((long long)S << Lv) >> 1));
+        unsigned lm;
+        if (LM - Lv <= 6) lm = s_lvlmin[Lv];
+        else {
+          const int gb = 1 << (LM - Lv - 6);
+          lm = 0xFFFFFFFFu;
+          for (int g0 = 0; g0 < NB; g0 += gb) {
+            unsigned gm = 0;
+            for (int bk = g0; bk < g0 + gb; ++bk) gm = max(gm, s_blkmax[bk]);
+            lm = min(lm, gm);
+          }
+        }
+        if (lm > (unsigned)hiL) T = hiL;
+        else { T = max(T, min(hiL, (int)lm - 1)); open = false; }
+      }
+      if (A.ablate & 64) T = 0;
+    }
+    // long rays (reach > T+1) -> compact list in the (now free) cursor array `cnt`
+    bool march_tail = false;
+    if (T < oc.imax && !(A.ablate & 256)) {
+      if (tid == 0) s_nlong = 0;
+      unsigned st = 0;
+      __syncthreads();
+      for (unsigned k0 = 0; k0 < n; k0 += NT) {
+        const unsigned k = k0 + tid;
+        unsigned p = 0;
+        bool lng = false;
+        if (k < n) {
+          p = abv[k];
+          const int rch = ab_a(p) + (int)(p & 1u);
+          lng = rch > T + 1;
+          if (lng) st += (unsigned)(rch - (T + 1));
+        }
+        const unsigned long long bm = __ballot(lng);
+        if (bm) {
+          unsigned base = 0;
+          if (lane == 0) base = atomicAdd(&s_nlong, (unsigned)__popcll(bm));
+          base = __shfl(base, 0);
+          const unsigned pos = base + (unsigned)__popcll(bm & ((1ull << lane) - 1ull));
+          if (lng && pos < (unsigned)M) cnt[pos] = p;
+        }
+      }
+      const unsigned r = wave_sum(st);
+      if (lane == 0) s_wsum[wave] = r;
+      __syncthreads();
+      unsigned tail_steps = 0;
+#pragma unroll
+      for (int wv = 0; wv < NT / 64; ++wv) tail_steps += s_wsum[wv];
+      const unsigned nlong = s_nlong;
+      march_tail = (nlong <= (unsigned)M) && (tail_steps <= 64u * NT);
+      if (march_tail) {
+        // one ray per wavefront, lanes over consecutive columns: distinct LDS words
+        for (unsigned r0 = wave; r0 < nlong; r0 += NT / 64) {
+          const unsigned p = cnt[r0];
+          const int a = ab_a(p), b = ab_b(p);
+          const int rch = a + (int)(p & 1u);
+          const int half = a >> 1;
+          for (int i = T + 1 + lane; i < rch; i += 64) {
+            // LineIterator stepping in closed form: j = (a/2 + i*b) / a
+            const int num = half + i * b;
+            int q = (int)((float)num * __builtin_amdgcn_rcpf((float)a));
+            const int rem = num - q * a;
+            if (rem < 0) --q;
+            else if (rem >= a) ++q;
+            const int bit = q - ((2 * i * s + S) >> (A.log2s + 1));
+            atomicOr(&marks[i], 1u << bit);
+          }
+        }
+      }
     }
     // gather: one lane per column of the wedge
-    for (int i = tid; i <= ((A.ablate & 2) ? -1 : oc.imax); i += 256) {
+    const int gather_hi = march_tail ? T : oc.imax;
+    for (int i = tid; i <= ((A.ablate & 2) ? -1 : gather_hi); i += NT) {
       if (i == 0) {
         marks[0] |= 1u;   // every ray (reach >= 1) starts in the origin cell
         continue;
       }
       const int jlo = (2 * i * s + S) >> (A.log2s + 1);
       const int jhi = (2 * i * (s + 1) + S) >> (A.log2s + 1);
-      const unsigned Q = 2u * (unsigned)i;
-      unsigned mask = 0;
-      int prev = 0;
-      for (int j = jlo; j <= jhi; ++j) {
-        int nxt = n;
-        if (j < jhi) {
-          // first k with b_k/a_k >= (2j+1)/(2i):  b_k*Q >= P*a_k
-          const unsigned P = 2u * (unsigned)j + 1u;
-          int lo = prev, hi = n;
-          while (lo < hi) {
-            const int mid = (lo + hi) >> 1;
-            const unsigned p = abv[mid];
-            if ((unsigned)ab_b(p) * Q >= P * (unsigned)ab_a(p)) hi = mid;
-            else lo = mid + 1;
+      const int w = jhi - jlo + 1;
+      const int Q = 2 * i;
+      // a cell interval (width 1/i in slope) fully contains an aligned group of level Lv
+      // buckets when 2^Lv >= 2i/S; if every such group holds a ray longer than i, every
+      // cell that lies inside the sector's slope range (k = 1..w-2) is traversed.
+      const int tq = (Q + S - 1) >> A.log2s;
+      const int Lv = (tq <= 1) ? 0 : 32 - __clz(tq - 1);
+      bool interior_free = false;
+      if (w > 2 && Lv <= LM) {
+        unsigned lm;
+        if (LM - Lv <= 6) lm = s_lvlmin[Lv];
+        else {
+          // groups of 2^(LM-Lv-6) whole blocks
+          const int gb = 1 << (LM - Lv - 6);
+          lm = 0xFFFFFFFFu;
+          for (int g0 = 0; g0 < NB; g0 += gb) {
+            unsigned gm = 0;
+            for (int bk = g0; bk < g0 + gb; ++bk) gm = max(gm, s_blkmax[bk]);
+            lm = min(lm, gm);
           }
-          nxt = lo;
         }
-        if (nxt > prev) {
-          // max reach over [prev, nxt)
-          const int bl = prev >> 4, bh = (nxt - 1) >> 4;
-          unsigned m;
-          if (bl == bh) {
-            m = 0;
-            for (int k = prev; k < nxt; ++k) m = max(m, (unsigned)reach[k]);
-          } else {
-            m = max((unsigned)sm[prev], (unsigned)pm[nxt - 1]);
-            const int len = bh - bl - 1;
-            if (len > 0 && m <= (unsigned)i) {
-              const int l = 31 - __clz(len);
-              m = max(m, (unsigned)bmx[l * nblk + bl + 1]);
-              m = max(m, (unsigned)bmx[l * nblk + bh - (1 << l)]);
+        interior_free = lm > (unsigned)i;
+      }
+      if (A.ablate & 64) interior_free = false;           // timing experiment: always the full loop
+      if ((A.ablate & 128) && !interior_free) continue;   // timing experiment: skip the full loop
+      unsigned mask = 0;
+      if (interior_free) {
+        mask = ((w >= 32) ? 0xFFFFFFFFu : ((1u << w) - 1u)) & ~1u & ~(1u << (w - 1));
+        // edge cell 0: slopes below the first interior boundary
+        {
+          const int Phi = 2 * jlo + 1;
+          const int hi = bucket_of_boundary(Phi, Q);
+          unsigned mx = (hi >= 1) ? rmq(0, min(hi, M) - 1) : 0u;
+          if (mx <= (unsigned)i && hi >= 0 && hi < M) {
+            for (unsigned e = bstart[hi]; e < bstart[hi + 1]; ++e) {
+              const unsigned p = abv[e];
+              const int a = ab_a(p);
+              if (ab_b(p) * Q < Phi * a) mx = max(mx, (unsigned)(a + (int)(p & 1u)));
             }
           }
-          if (m > (unsigned)i) mask |= 1u << (j - jlo);
+          if (mx > (unsigned)i) mask |= 1u;
         }
-        prev = nxt;
-        if (prev >= n) break;
+        // edge cell w-1: slopes at or above the last interior boundary
+        {
+          const int Plo = 2 * jhi - 1;
+          const int lo = bucket_of_boundary(Plo, Q);
+          unsigned mx = (lo + 1 <= M - 1) ? rmq(max(lo + 1, 0), M - 1) : 0u;
+          if (mx <= (unsigned)i && lo >= 0 && lo < M) {
+            for (unsigned e = bstart[lo]; e < bstart[lo + 1]; ++e) {
+              const unsigned p = abv[e];
+              const int a = ab_a(p);
+              if (ab_b(p) * Q >= Plo * a) mx = max(mx, (unsigned)(a + (int)(p & 1u)));
+            }
+          }
+          if (mx > (unsigned)i) mask |= 1u << (w - 1);
+        }
+      } else {
+        int lo = -1;             // bucket holding the cell's lower boundary (-1: below the sector)
+        unsigned above = 0;      // max reach of the ends of bucket `lo` at or above that boundary
+        for (int k = 0; k < w; ++k) {
+          const int Phi = 2 * (jlo + k) + 1;
+          const int hi = (k < w - 1) ? bucket_of_boundary(Phi, Q) : M;
+          // whole buckets strictly between the two boundary buckets
+          unsigned mx = above;
+          const int l = lo + 1, r = min(hi - 1, M - 1);
+          if (l <= r) mx = max(mx, rmq(l, r));
+          // the upper boundary's bucket, read once: ends below the boundary belong to this
+          // cell, the others to the next one (S*M > imax: two boundaries never share a bucket)
+          above = 0;
+          if (hi >= 0 && hi < M) {
+            unsigned below = 0;
+            for (unsigned e = bstart[hi]; e < bstart[hi + 1]; ++e) {
+              const unsigned p = abv[e];
+              const int a = ab_a(p);
+              const unsigned rch = (unsigned)(a + (int)(p & 1u));
+              if (ab_b(p) * Q < Phi * a) below = max(below, rch);
+              else above = max(above, rch);
+            }
+            mx = max(mx, below);
+          }
+          if (mx > (unsigned)i) mask |= 1u << k;
+          lo = hi;
+          if (hi >= M) break;
+        }
       }
       if (mask) marks[i] |= mask;
     }
     __syncthreads();
+    stamp();   // 8: gather done
   };
 
-  // ---- scan the wedge column by column, collecting ends
-  // ends of column a as a bit mask over b = blo..bhi (bit t <-> b = blo+t, or bhi-t on the
-  // negative minor side); vc marks the clipped (inclusive) ones
-  auto scan_col = [&](int a, unsigned &ends, unsigned &vc, int &blo, int &bhi) {
-    ends = 0;
-    vc = 0;
-    const int bmaxa = oc.xmaj ? a : a - 1;
-    blo = (a * s + S - 1) >> A.log2s;
-    bhi = ((a * (s + 1) + S - 1) >> A.log2s) - 1;
-    if (s == S - 1) bhi = bmaxa;
-    blo = max(blo, oc.bmin);
-    bhi = min(min(bhi, bmaxa), oc.jmaxo);
-    if (blo > bhi) return;
-    const int w = bhi - blo + 1;   // <= 32 (host guarantees imax <= 30*S)
-    const int major_abs = oc_major + oc.smaj * a;
-    const int m_lo = (oc.smin > 0) ? oc_minor + blo : oc_minor - bhi;
-    const int w0 = m_lo >> 5, sh = m_lo & 31;
-    const size_t base = (size_t)w0 * major_pad + major_abs;
-    unsigned long long h64 = bmH[base], c64 = bmC[base];
-    if (sh + w > 32 && w0 + 1 < roww) {
-      h64 |= (unsigned long long)bmH[base + major_pad] << 32;
-      c64 |= (unsigned long long)bmC[base + major_pad] << 32;
-    }
-    const unsigned wm = (w >= 32) ? 0xFFFFFFFFu : ((1u << w) - 1u);
-    const unsigned vh = (unsigned)(h64 >> sh) & wm;
-    vc = (unsigned)(c64 >> sh) & wm;
-    ends = vh | vc;
-  };
-  auto append_col = [&](int a, unsigned ends, unsigned vc, int blo, int bhi, int slot) {
-    while (ends) {
-      const int t = __ffs(ends) - 1;
-      ends &= ends - 1;
-      const int b = (oc.smin > 0) ? blo + t : bhi - t;
-      abv[slot++] = pack_ab(a, b, (int)((vc >> t) & 1u));
-    }
-  };
-
-  // pass A: count this thread's ends over all its columns (independent loads, no barriers)
-  int mine_total = 0;
-  for (int a = 1 + tid; a <= oc.imax; a += 256) {
-    unsigned ends, vc;
-    int blo, bhi;
-    scan_col(a, ends, vc, blo, bhi);
-    mine_total += __popc(ends);
-  }
-  if (tid == 0) s_batch = 0;
-  __syncthreads();
-  if (mine_total) atomicAdd(&s_batch, (unsigned)mine_total);
-  __syncthreads();
-  const int total = (int)s_batch;
-  __syncthreads();
-  if (total == 0) {
-    // nothing ends in this wedge
-  } else if (total <= cap) {
-    // common case: one chunk, one slot allocation per thread
-    int slot = mine_total ? (int)atomicAdd(&s_count, (unsigned)mine_total) : 0;
-    for (int a = 1 + tid; a <= oc.imax && mine_total; a += 256) {
-      unsigned ends, vc;
-      int blo, bhi;
-      scan_col(a, ends, vc, blo, bhi);
-      const int c = __popc(ends);
-      append_col(a, ends, vc, blo, bhi, slot);
-      slot += c;
-    }
-    __syncthreads();
-    process_chunk(total);
-    if (tid == 0) { s_rays += (unsigned long long)total; s_count = 0; }
-    __syncthreads();
+  if (A.ablate & 32) return;   // timing experiment
+  if (total <= cap) {
+    process_group((1u << CH) - 1u, -1);
   } else {
-    // rare: more ends than one LDS chunk holds -> batches of 256 columns, flushing chunks
-    for (int a0 = 1; a0 <= oc.imax; a0 += 256) {
-      const int a = a0 + tid;
-      unsigned ends = 0, vc = 0;
-      int blo = 0, bhi = -1;
-      if (a <= oc.imax) scan_col(a, ends, vc, blo, bhi);
-      const int cnt = __popc(ends);
-      if (tid == 0) s_batch = 0;
+    // more ends than one LDS group holds: one group per row of columns, and per
+    // wavefront (64 columns x <= 32 ends <= 2048 <= cap) where a row alone is too big
+    for (int c = 0; c < CH; ++c) {
+      unsigned mine = 0;
+#pragma unroll
+      for (int cc = 0; cc < CH; ++cc)
+        if (cc == c) mine = (unsigned)__popc(ends[cc]);
+      const unsigned r = wave_sum(mine);
       __syncthreads();
-      if (cnt) atomicAdd(&s_batch, (unsigned)cnt);
+      if (lane == 0) s_wsum[wave] = r;
       __syncthreads();
-      const int batch = (int)s_batch;
-      __syncthreads();   // everyone has read s_batch before it is reset again
-      if (batch == 0) continue;
-      // sub-batches of 64 columns bound one append to 64*32 = 2048 <= cap
-      const int nsub = (batch > cap) ? 4 : 1;
-      for (int sb = 0; sb < nsub; ++sb) {
-        const bool mine = (nsub == 1) || ((tid >> 6) == sb);
-        if (nsub > 1) {
-          if (tid == 0) s_batch = 0;
-          __syncthreads();
-          if (mine && cnt) atomicAdd(&s_batch, (unsigned)cnt);
-          __syncthreads();
-        }
-        const int need = (nsub > 1) ? (int)s_batch : batch;
-        if ((int)s_count + need > cap) {
-          const int n = (int)s_count;
-          __syncthreads();
-          process_chunk(n);
-          if (tid == 0) { s_rays += (unsigned long long)n; s_count = 0; }
-          __syncthreads();
-        }
-        if (mine && cnt) {
-          const int slot = (int)atomicAdd(&s_count, (unsigned)cnt);
-          append_col(a, ends, vc, blo, bhi, slot);
-        }
-        __syncthreads();
-      }
-    }
-    const int n = (int)s_count;
-    __syncthreads();
-    if (n > 0) {
-      process_chunk(n);
-      if (tid == 0) s_rays += (unsigned long long)n;
+      int rt = 0;
+      for (int wv = 0; wv < NT / 64; ++wv) rt += (int)s_wsum[wv];
       __syncthreads();
+      if (rt == 0) continue;
+      if (rt <= cap) process_group(1u << c, -1);
+      else
+        for (int wv = 0; wv < NT / 64; ++wv) process_group(1u << c, wv);
     }
   }
 
   // ---- flush the wedge's marks as bytes: N grid for x-major, T grid for y-major
-  for (int i = tid; i <= ((A.ablate & 4) ? -1 : oc.imax); i += 256) {
+  for (int i = tid; i <= ((A.ablate & 4) ? -1 : oc.imax); i += NT) {
     unsigned w = marks[i];
     if (!w) continue;
     const int jlo = (2 * i * s + S) >> (A.log2s + 1);
@@ -407,12 +644,16 @@ __global__ void __launch_bounds__(256) k_ray_sectors(SectorArgs A)
       else A.missT[(size_t)minor_abs * A.g.ny + major_abs] = 1;
     }
   }
+  __syncthreads();
+  stamp();   // 9: flush done
   if (tid == 0) {
     // per-workgroup slots, summed by the host on demand: a shared counter would
     // serialise 2 x 8*S atomics on one address (~12 ns each)
     if (A.stats) {
-      A.stats[2 * blockIdx.x] = s_rays;
-      A.stats[2 * blockIdx.x + 1] = s_visits;
+      unsigned long long vsum = 0;
+      for (int wv = 0; wv < NT / 64; ++wv) vsum += s_wvis[wv];
+      A.stats[2 * blockIdx.x] = (unsigned long long)total;
+      A.stats[2 * blockIdx.x + 1] = vsum;
     }
     // a clipped ray that ends in the origin cell itself (a == 0, inclusive)
     if (blockIdx.x == 0) {
@@ -422,20 +663,23 @@ __global__ void __launch_bounds__(256) k_ray_sectors(SectorArgs A)
   }
 }
 
-size_t sector_lds_bytes(int cap, int marks_words)
+size_t sector_lds_bytes(int cap, int marks_words, int log2m)
 {
-  const int nblk = cap >> 4;
-  int nlev = 0;
-  while ((1 << nlev) < nblk) ++nlev;
-  ++nlev;
-  return (size_t)cap * 4 + (size_t)marks_words * 4 + (size_t)cap * 2 * 3 + (size_t)nlev * nblk * 2;
+  return sector_lds_layout(cap, marks_words, log2m).total;
 }
 
 void launch_ray_sectors(const SectorArgs &a, hipStream_t s)
 {
   if (!a.org.valid) return;
-  const size_t lds = sector_lds_bytes(a.cap, a.marks_words);
-  hipLaunchKernelGGL(k_ray_sectors, dim3(8u << a.log2s), dim3(256), lds, s, a);
+  const size_t lds = sector_lds_bytes(a.cap, a.marks_words, a.log2m);
+  const int imax = std::max(std::max(a.org.cx, a.g.nx - 1 - a.org.cx), std::max(a.org.cy, a.g.ny - 1 - a.org.cy));
+  // every wedge column lives in a register slot of one thread: CH * 512 >= imax
+  if (imax <= 4 * kSecThreads)
+    hipLaunchKernelGGL(k_ray_sectors<4>, dim3(8u << a.log2s), dim3(kSecThreads), lds, s, a);
+  else if (imax <= 8 * kSecThreads)
+    hipLaunchKernelGGL(k_ray_sectors<8>, dim3(8u << a.log2s), dim3(kSecThreads), lds, s, a);
+  else
+    hipLaunchKernelGGL(k_ray_sectors<16>, dim3(8u << a.log2s), dim3(kSecThreads), lds, s, a);
 }
 
 // ------------------------------------------------------ tile grid pass -----

@@ -34,7 +34,8 @@ def needs_build() -> bool:
 def build(force: bool = False) -> str:
     if force or needs_build():
         srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
-        cmd = [hipcc(), *FLAGS, "-o", LIB, *srcs, *extra_link()]
+        extra = os.environ.get("GV_HIPCC_EXTRA", "").split()
+        cmd = [hipcc(), *FLAGS, *extra, "-o", LIB, *srcs, *extra_link()]
         subprocess.check_call(cmd, cwd=CSRC)
     return LIB
 
