@@ -318,7 +318,7 @@ int enqueue_frame(gv_context *h, bool stage_events)
       while ((30 << log2s) < imax) ++log2s;
       const double dens = std::min((double)h->n, (double)h->g.G) / (double)h->g.G;
       double est = 1.5 * dens * (double)imax * (double)imax / (double)(2 << log2s);
-      while (est > 3600.0 && log2s < 12) {
+      while (est > 5000.0 && log2s < 12) {
         ++log2s;
         est *= 0.5;
       }
