@@ -67,6 +67,11 @@ struct gv_context {
   float *d_orient = nullptr, *d_conf = nullptr, *d_dims = nullptr;
   VisionOut *d_vout = nullptr;
   double *d_pts = nullptr;
+  // kNN depth / PCA pose scratch
+  Cand2 *knn_partial = nullptr; size_t knn_partial_cap = 0;
+  float *d_depths = nullptr, *d_knn_d2 = nullptr; size_t knn_out_cap = 0;
+  int32_t *d_idx = nullptr, *d_segof = nullptr, *d_segstart = nullptr; size_t seg_cap = 0, segstart_cap = 0;
+  float *gx = nullptr, *gy = nullptr, *gz = nullptr; uint8_t *d_keep = nullptr; size_t gcap = 0;
   float4 *d_bbox_f = nullptr;                // float thresholds of the bbox test
   unsigned long long *d_tile_mask = nullptr; // candidate masks per 16x16-pixel tile
   size_t tile_mask_cap = 0;
@@ -554,7 +559,8 @@ int gv_destroy(gv_handle h)
   void *bufs[] = {h->log_odds, h->occupancy, h->occ_i8, h->hits, h->miss, h->clip_end, h->ray_list, h->ray_count,
                   h->ray_stats, h->scratch_i32, h->d_dbg, h->missT, h->hitN, h->clipN, h->hitT, h->clipT, h->cx, h->cy, h->cz, h->tx, h->ty, h->tz, h->raw, h->cell_idx,
                   h->bbox_id, h->d_bboxes, h->d_poses, h->d_rects, h->d_orient, h->d_conf, h->d_dims, h->d_vout,
-                  h->d_pts, h->d_bbox_f, h->d_tile_mask};
+                  h->d_pts, h->d_bbox_f, h->d_tile_mask, h->knn_partial, h->d_depths, h->d_knn_d2, h->d_idx, h->d_segof,
+                  h->d_segstart, h->gx, h->gy, h->gz, h->d_keep};
   for (void *p : bufs)
     if (p) (void)hipFree(p);
   for (auto &e : h->ev)
@@ -1088,14 +1094,156 @@ static int not_built(gv_context *h, const char *what)
   return GV_ERR_STATE;
 }
 
-int gv_compute_depth_for_bboxes(gv_handle h, const gv_bbox *, int32_t, int32_t, float *, float *)
+static int ensure_tbuf(gv_context *h, size_t n)
 {
-  return not_built(h, "gv_compute_depth_for_bboxes");
+  if (n <= h->tcap) return GV_OK;
+  for (float **p : {&h->tx, &h->ty, &h->tz}) {
+    if (*p) GV_HIP(hipFree(*p));
+    *p = nullptr;
+  }
+  h->tcap = 0;
+  GV_HIP(hipMalloc(reinterpret_cast<void **>(&h->tx), n * sizeof(float)));
+  GV_HIP(hipMalloc(reinterpret_cast<void **>(&h->ty), n * sizeof(float)));
+  GV_HIP(hipMalloc(reinterpret_cast<void **>(&h->tz), n * sizeof(float)));
+  h->tcap = n;
+  return GV_OK;
 }
 
-int gv_compute_bbox_pose(gv_handle h, const gv_bbox *, int32_t, gv_lshape_pose *, uint8_t *)
+int gv_compute_depth_for_bboxes(gv_handle h, const gv_bbox *bboxes, int32_t nb, int32_t k, float *depths,
+                                float *knn_d2)
 {
-  return not_built(h, "gv_compute_bbox_pose");
+  if (!h || nb < 0 || (nb && (!bboxes || !depths)) || k < 1 || k > 32) return GV_ERR_BAD_ARG;
+  if (!h->has_cl) return GV_ERR_TF;
+  GV_TRY
+  if (nb == 0) return GV_OK;
+  int rc = use_device(h);
+  if (rc) return rc;
+  if ((rc = upload_bboxes(h, bboxes, nb))) return rc;
+  if ((rc = ensure_tbuf(h, std::max<size_t>(h->n, 1)))) return rc;
+  const int nchunks = 64;
+  if ((rc = grow(h, h->knn_partial, h->knn_partial_cap, (size_t)nb * nchunks * k))) return rc;
+  if ((size_t)nb * k > h->knn_out_cap) {
+    if (h->d_depths) GV_HIP(hipFree(h->d_depths));
+    if (h->d_knn_d2) GV_HIP(hipFree(h->d_knn_d2));
+    h->d_depths = h->d_knn_d2 = nullptr;
+    h->knn_out_cap = 0;
+    GV_HIP(hipMalloc(reinterpret_cast<void **>(&h->d_depths), (size_t)nb * 32 * sizeof(float)));
+    GV_HIP(hipMalloc(reinterpret_cast<void **>(&h->d_knn_d2), (size_t)nb * 32 * sizeof(float)));
+    h->knn_out_cap = (size_t)nb * 32;
+  }
+  // buildKDTree projection (cloud_detections.cpp:8-33) then the exact k nearest (:43-87)
+  launch_project_uvd(h->cx, h->cy, h->cz, (uint32_t)h->n, h->m_cam, h->camk, h->tx, h->ty, h->tz, h->stream);
+  launch_knn(h->tx, h->ty, h->tz, (uint32_t)h->n, h->d_bboxes, nb, k, nchunks, h->knn_partial, h->d_depths,
+             h->d_knn_d2, h->stream);
+  GV_HIP(hipGetLastError());
+  GV_HIP(hipMemcpyAsync(depths, h->d_depths, (size_t)nb * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+  if (knn_d2)
+    GV_HIP(hipMemcpyAsync(knn_d2, h->d_knn_d2, (size_t)nb * k * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+  GV_HIP(hipStreamSynchronize(h->stream));
+  return GV_OK;
+  GV_CATCH
+}
+
+int gv_compute_bbox_pose(gv_handle h, const gv_bbox *bboxes, int32_t nb, gv_lshape_pose *poses_out, uint8_t *valid)
+{
+  if (!h || nb < 0 || (nb && (!bboxes || !poses_out || !valid))) return GV_ERR_BAD_ARG;
+  if (!h->has_cl) return GV_ERR_TF;
+  GV_TRY
+  if (nb == 0) return GV_OK;
+  int rc = use_device(h);
+  if (rc) return rc;
+  const size_t n = h->n;
+  for (int32_t b = 0; b < nb; ++b) { valid[b] = 0; poses_out[b] = gv_lshape_pose{}; }
+  if (n == 0) return GV_OK;
+  if ((rc = upload_bboxes(h, bboxes, nb))) return rc;
+  if ((rc = ensure_tbuf(h, n))) return rc;
+  // extractCloudPerBBox (cloud_detections.cpp:250-298): first-match bbox id per point,
+  // and the camera-frame cloud the per-bbox clouds are cut from
+  {
+    PointsArgs a{};
+    a.x = h->cx; a.y = h->cy; a.z = h->cz;
+    a.n = (uint32_t)n;
+    a.g = h->g;
+    a.m_cam = h->m_cam;
+    a.cam = h->camk;
+    a.bboxes = h->d_bboxes;
+    a.nb = nb;
+    a.bbox_f = h->d_bbox_f;
+    a.tile_mask = h->d_tile_mask;
+    a.tiles_x = h->tiles_x; a.tiles_y = h->tiles_y; a.mask_words = h->mask_words;
+    a.bbox_id = h->bbox_id;
+    a.do_bbox = true;
+    launch_points(a, h->stream);
+    launch_transform_cloud(h->cx, h->cy, h->cz, (uint32_t)n, h->m_cam, h->tx, h->ty, h->tz, h->stream);
+    GV_HIP(hipGetLastError());
+  }
+  std::vector<int32_t> ids(n);
+  GV_HIP(hipMemcpyAsync(ids.data(), h->bbox_id, n * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+  GV_HIP(hipStreamSynchronize(h->stream));
+  h->have_bbox_id = true;
+  // per-bbox point lists in cloud order (the reference appends in cloud order, :286)
+  std::vector<int32_t> seg_start((size_t)nb + 1, 0);
+  for (size_t i = 0; i < n; ++i)
+    if (ids[i] >= 0) seg_start[(size_t)ids[i] + 1]++;
+  for (int32_t b = 0; b < nb; ++b) seg_start[b + 1] += seg_start[b];
+  const int32_t m = seg_start[nb];
+  if (m == 0) return GV_OK;
+  std::vector<int32_t> idx((size_t)m), seg_of((size_t)m), cur(seg_start.begin(), seg_start.end() - 1);
+  for (size_t i = 0; i < n; ++i)
+    if (ids[i] >= 0) {
+      const int32_t p = cur[ids[i]]++;
+      idx[p] = (int32_t)i;
+      seg_of[p] = ids[i];
+    }
+  if ((size_t)m > h->gcap) {
+    for (float **p : {&h->gx, &h->gy, &h->gz})
+      if (*p) { GV_HIP(hipFree(*p)); *p = nullptr; }
+    if (h->d_keep) { GV_HIP(hipFree(h->d_keep)); h->d_keep = nullptr; }
+    h->gcap = 0;
+    const size_t want = (size_t)m + (size_t)m / 4 + 1024;
+    GV_HIP(hipMalloc(reinterpret_cast<void **>(&h->gx), want * sizeof(float)));
+    GV_HIP(hipMalloc(reinterpret_cast<void **>(&h->gy), want * sizeof(float)));
+    GV_HIP(hipMalloc(reinterpret_cast<void **>(&h->gz), want * sizeof(float)));
+    GV_HIP(hipMalloc(reinterpret_cast<void **>(&h->d_keep), want));
+    h->gcap = want;
+  }
+  if ((size_t)m > h->seg_cap) {
+    if (h->d_idx) { GV_HIP(hipFree(h->d_idx)); h->d_idx = nullptr; }
+    if (h->d_segof) { GV_HIP(hipFree(h->d_segof)); h->d_segof = nullptr; }
+    h->seg_cap = 0;
+    const size_t want = (size_t)m + (size_t)m / 4 + 1024;
+    GV_HIP(hipMalloc(reinterpret_cast<void **>(&h->d_idx), want * sizeof(int32_t)));
+    GV_HIP(hipMalloc(reinterpret_cast<void **>(&h->d_segof), want * sizeof(int32_t)));
+    h->seg_cap = want;
+  }
+  if ((rc = grow(h, h->d_segstart, h->segstart_cap, (size_t)nb + 1))) return rc;
+  GV_HIP(hipMemcpyAsync(h->d_idx, idx.data(), (size_t)m * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+  GV_HIP(hipMemcpyAsync(h->d_segof, seg_of.data(), (size_t)m * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+  GV_HIP(hipMemcpyAsync(h->d_segstart, seg_start.data(), ((size_t)nb + 1) * sizeof(int32_t), hipMemcpyHostToDevice,
+                        h->stream));
+  launch_gather_xyz(h->tx, h->ty, h->tz, h->d_idx, m, h->gx, h->gy, h->gz, h->stream);
+  // RadiusOutlierRemoval(0.4, 10)  (cloud_detections.cpp:150-154)
+  const double radius = 0.4;
+  launch_radius_count(h->gx, h->gy, h->gz, h->d_segof, h->d_segstart, m, host::floor_to_float(radius * radius), 10,
+                      h->d_keep, h->stream);
+  GV_HIP(hipGetLastError());
+  std::vector<float> px((size_t)m), py((size_t)m), pz((size_t)m);
+  std::vector<uint8_t> keep((size_t)m);
+  GV_HIP(hipMemcpyAsync(px.data(), h->gx, (size_t)m * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+  GV_HIP(hipMemcpyAsync(py.data(), h->gy, (size_t)m * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+  GV_HIP(hipMemcpyAsync(pz.data(), h->gz, (size_t)m * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+  GV_HIP(hipMemcpyAsync(keep.data(), h->d_keep, (size_t)m, hipMemcpyDeviceToHost, h->stream));
+  GV_HIP(hipStreamSynchronize(h->stream));
+  // centroid + PCA rectangle per bbox on the filtered points, reference order (:156-247)
+  std::vector<float> fx, fy, fz;
+  for (int32_t b = 0; b < nb; ++b) {
+    fx.clear(); fy.clear(); fz.clear();
+    for (int32_t p = seg_start[b]; p < seg_start[b + 1]; ++p)
+      if (keep[p]) { fx.push_back(px[p]); fy.push_back(py[p]); fz.push_back(pz[p]); }
+    valid[b] = host::pca_bbox(fx.data(), fy.data(), fz.data(), fx.size(), poses_out[b]) ? 1 : 0;
+  }
+  return GV_OK;
+  GV_CATCH
 }
 
 int gv_comm_unique_id(uint8_t *) { return GV_ERR_STATE; }

@@ -212,6 +212,62 @@ inline float floor_to_float(double v)
   return f;
 }
 
+// bboxPoseEstimation :156-181 + computePCABoundingBox :187-247 for one (already filtered)
+// bbox cloud, in the reference's order: pcl::compute3DCentroid (fp32 running sum / n),
+// cv::PCA(DATA_AS_ROW, CV_32F) on rows (z, x): fp32 mean, fp64 covariance of the
+// fp32-centred samples scaled by 1/n and stored fp32, eigenvectors of the symmetric 2x2,
+// projections min/max.  The eigenvector sign is arbitrary upstream; major.x >= 0 here.
+inline bool pca_bbox(const float *x, const float *y, const float *z, size_t n, gv_lshape_pose &out)
+{
+  out = gv_lshape_pose{};
+  if (n == 0) return false;   // :174-175
+  float cy = 0.0f;
+  for (size_t i = 0; i < n; ++i) cy += y[i];
+  cy /= (float)n;
+  float m0 = 0.0f, m1 = 0.0f;
+  for (size_t i = 0; i < n; ++i) { m0 += z[i]; m1 += x[i]; }
+  m0 = m0 * (float)(1.0 / (double)n);
+  m1 = m1 * (float)(1.0 / (double)n);
+  double c00 = 0, c01 = 0, c11 = 0;
+  for (size_t i = 0; i < n; ++i) {
+    const float a = z[i] - m0, b = x[i] - m1;
+    c00 += (double)a * a; c01 += (double)a * b; c11 += (double)b * b;
+  }
+  const double sc = 1.0 / (double)n;
+  const double a = (double)(float)(c00 * sc), b = (double)(float)(c01 * sc), d = (double)(float)(c11 * sc);
+  double mjx, mjy;
+  if (b == 0.0) {
+    if (a >= d) { mjx = 1; mjy = 0; } else { mjx = 0; mjy = 1; }
+  } else {
+    const double tr = a + d, df = a - d;
+    const double root = std::sqrt(df * df + 4.0 * b * b);
+    const double l1 = 0.5 * (tr + root);
+    mjx = b; mjy = l1 - a;
+    if (std::fabs(l1 - d) > std::fabs(mjy)) { mjx = l1 - d; mjy = b; }
+    const double nn = std::sqrt(mjx * mjx + mjy * mjy);
+    mjx /= nn; mjy /= nn;
+  }
+  if (mjx < 0 || (mjx == 0 && mjy < 0)) { mjx = -mjx; mjy = -mjy; }
+  const float Mx = (float)mjx, My = (float)mjy, Nx = (float)(-mjy), Ny = (float)mjx;
+  float minL = 3.402823466e+38f, maxL = -3.402823466e+38f, minW = 3.402823466e+38f, maxW = -3.402823466e+38f;
+  for (size_t i = 0; i < n; ++i) {   // :203-216
+    const float dx = z[i] - m0, dy = x[i] - m1;
+    const float pl = dx * Mx + dy * My, pw = dx * Nx + dy * Ny;
+    minL = std::min(minL, pl); maxL = std::max(maxL, pl);
+    minW = std::min(minW, pw); maxW = std::max(maxW, pw);
+  }
+  const float angle = std::atan2(My, Mx) * 180.0f / (float)3.14159265358979323846;   // :227 (degrees)
+  out.px = m1;    // :230 center.y
+  out.py = cy;    // :231 then :181
+  out.pz = m0;    // :232 center.x
+  const Quat q = quat_from_rpy(0, -angle, 0);   // :236 (degrees passed as radians, as the reference does)
+  out.qx = q.x; out.qy = q.y; out.qz = q.z; out.qw = q.w;
+  out.length = maxL - minL;   // :218,:243
+  out.width = maxW - minW;    // :219,:244
+  out.height = 0.0;           // never set on this path in the reference
+  return true;
+}
+
 // host getIndex (same arithmetic as the device one) for geometry-only queries
 inline bool get_index(const GridParams &g, double x, double y, int &ix, int &iy)
 {

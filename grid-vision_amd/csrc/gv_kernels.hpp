@@ -118,4 +118,19 @@ struct FinalizeTileArgs {
 void launch_finalize_tiles(const FinalizeTileArgs &a, hipStream_t s);
 void launch_miss_to_i32(const uint8_t *mN, const uint8_t *mT, int nx, int ny, int32_t *out, hipStream_t s);
 
+// ---- kNN depth + radius outlier counts (gv_knn_pca.hip) ----
+struct Cand2 {
+  float d2;
+  uint32_t idx;
+};
+void launch_project_uvd(const float *x, const float *y, const float *z, uint32_t n, const Mat34f &m,
+                        const CamK &cam, float *pu, float *pv, float *pd, hipStream_t s);
+void launch_knn(const float *pu, const float *pv, const float *pd, uint32_t n, const gv_bbox *bboxes, int nb, int k,
+                int nchunks, Cand2 *partial, float *depths, float *knn_d2, hipStream_t s);
+void launch_radius_count(const float *x, const float *y, const float *z, const int32_t *seg_of,
+                         const int32_t *seg_start, int32_t n, float r2f, int32_t min_pts, uint8_t *keep,
+                         hipStream_t s);
+void launch_gather_xyz(const float *x, const float *y, const float *z, const int32_t *idx, int32_t n, float *ox,
+                       float *oy, float *oz, hipStream_t s);
+
 }  // namespace gv

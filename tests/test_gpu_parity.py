@@ -495,3 +495,108 @@ def test_bbox_test_many_fractional_boxes(gvamd):
     assert np.array_equal(ids, exp)
     assert (exp >= 64).sum() > 0 and (exp >= 128).sum() > 0, "fixture must reach the 2nd and 3rd mask word"
     h.close()
+
+
+def _cluster_scene(tfs, n_clusters=24, pts_per=400, seed=11):
+    """clusters of points in front of the camera + a sparse background, and one integer
+    pixel bbox around each cluster (what a detector would hand over)."""
+    st = synth.Stream(seed, 21)
+    cxs = st.uniform(n_clusters, 6.0, 45.0).astype(np.float64)
+    cys = (st.uniform(n_clusters, -0.7, 0.7).astype(np.float64)) * cxs
+    czs = st.uniform(n_clusters, -1.0, 0.5).astype(np.float64)
+    xs, ys, zs = [], [], []
+    for k in range(n_clusters):
+        xs.append(cxs[k] + st.uniform(pts_per, -0.7, 0.7))
+        ys.append(cys[k] + st.uniform(pts_per, -0.5, 0.5))
+        zs.append(czs[k] + st.uniform(pts_per, -0.4, 0.4))
+    nbg = 30_000
+    xs.append(st.uniform(nbg, -20, 60)); ys.append(st.uniform(nbg, -40, 40)); zs.append(st.uniform(nbg, -2, 3))
+    x = np.concatenate(xs).astype(np.float32); y = np.concatenate(ys).astype(np.float32); z = np.concatenate(zs).astype(np.float32)
+    m_cam = ol.tf_to_matrix4f(tfs["cam_lidar"])
+    cx, cy, cz = ol.transform_cloud(m_cam, x, y, z)
+    K = ol.set_intrinsic(synth.FX, synth.FY, synth.CX, synth.CY)
+    boxes = []
+    for k in range(n_clusters):
+        sl = slice(k * pts_per, (k + 1) * pts_per)
+        zc = cz[sl]
+        ok = zc > 0.1
+        if ok.sum() < 10:
+            continue
+        u = synth.FX * cx[sl][ok] / zc[ok] + synth.CX
+        v = synth.FY * cy[sl][ok] / zc[ok] + synth.CY
+        x0, x1 = int(max(0, np.floor(u.min()) - 2)), int(min(639, np.ceil(u.max()) + 2))
+        y0, y1 = int(max(0, np.floor(v.min()) - 2)), int(min(479, np.ceil(v.max()) + 2))
+        if x1 > x0 and y1 > y0:
+            boxes.append((x0, y0, x1, y1))
+    b = np.zeros(len(boxes), dtype=synth.BBOX_DTYPE)
+    for i, (x0, y0, x1, y1) in enumerate(boxes):
+        b[i] = (x0, y0, x1, y1, 0.99 - 0.01 * i, [9, 2, 0, 1, 5][i % 5])
+    return x, y, z, (cx, cy, cz), K, b
+
+
+@pytest.mark.parametrize("k", [1, 4, 10, 32])
+def test_compute_depth_for_bboxes_knn(gvamd, k):
+    """buildKDTree + computeDepthForBoundingBoxes: exact k nearest in (u, v, depth),
+    distances bit-equal, ties by lower index, upper-median depth equal."""
+    h, tfs = make_handle(gvamd, 2, perturbed=True)
+    x, y, z, (cx, cy, cz), K, b = _cluster_scene(tfs)
+    h.upload_xyz(x, y, z)
+    depths, d2 = h.compute_depth_for_bboxes(b, k)
+    u, v, d = ol.project_points(K, cx, cy, cz)
+    edepths, ed2 = ol.depth_for_bboxes(u, v, d, b, k)
+    assert len(b) >= 15
+    assert np.array_equal(d2, ed2)
+    assert np.array_equal(depths, edepths)
+    assert (depths > 0).all()
+    h.close()
+
+
+def test_compute_depth_empty_and_behind(gvamd):
+    h, tfs = make_handle(gvamd, 1)
+    b = synth.detections(3, 5)
+    # every point behind the camera -> depth stays -1 (cloud_detections.cpp:49)
+    x = np.full(100, -5.0, np.float32)
+    h.upload_xyz(x, np.zeros(100, np.float32), np.zeros(100, np.float32))
+    depths, d2 = h.compute_depth_for_bboxes(b, 4)
+    assert (depths == -1.0).all() and np.isinf(d2).all()
+    # fewer points than k: the reference's kNN returns what exists
+    h.upload_xyz(np.array([10.0, 12.0], np.float32), np.zeros(2, np.float32), np.zeros(2, np.float32))
+    depths, d2 = h.compute_depth_for_bboxes(b, 4)
+    m_cam = ol.tf_to_matrix4f(tfs["cam_lidar"])
+    cx, cy, cz = ol.transform_cloud(m_cam, [10.0, 12.0], [0, 0], [0, 0])
+    u, v, d = ol.project_points(ol.set_intrinsic(synth.FX, synth.FY, synth.CX, synth.CY), cx, cy, cz)
+    ed, ed2 = ol.depth_for_bboxes(u, v, d, b, 4)
+    assert np.array_equal(depths, ed) and np.array_equal(d2, ed2)
+    h.close()
+
+
+def test_compute_bbox_pose_pca_path(gvamd):
+    """use_vision_orientation=false path: extractCloudPerBBox + RadiusOutlierRemoval(0.4, 10)
+    + centroid + PCA rectangle per bbox.  The RANSAC ground removal is not part of this call
+    (DESIGN.md).  Host-side PCA arithmetic is the reference's, so results equal the oracle's;
+    tolerance 1e-6 documents that nothing here is approximate."""
+    h, tfs = make_handle(gvamd, 2, perturbed=True)
+    x, y, z, (cx, cy, cz), K, b = _cluster_scene(tfs, n_clusters=20, pts_per=500, seed=5)
+    h.upload_xyz(x, y, z)
+    poses, valid = h.compute_bbox_pose(b)
+    ids = ol.extract_cloud_per_bbox(K, cx, cy, cz, b, synth.IMG_W, synth.IMG_H)
+    n_valid = 0
+    for i in range(len(b)):
+        sel = ids == i
+        keep = ol.radius_outlier(cx[sel], cy[sel], cz[sel], 0.4, 10).astype(bool)
+        ok, e = ol.pca_bbox(cx[sel][keep], cy[sel][keep], cz[sel][keep])
+        assert bool(valid[i]) == ok
+        if ok:
+            n_valid += 1
+            for f in ("px", "py", "pz", "length", "width", "qx", "qy", "qz", "qw"):
+                assert poses[i][f] == pytest.approx(e[f], rel=1e-6, abs=1e-6), (i, f)
+    assert n_valid >= 10
+    # and through the grid: transformLShapeObjects + updateMap(poses)
+    g = synth.CONFIGS[2]["grid"]
+    og = ol.OGrid(g.grid_x, g.grid_y, g.resolution)
+    base = h.transform_lshape_objects(poses[valid.astype(bool)])
+    h.update_map_poses(base)
+    og.update_map_poses(base)
+    nlo, _, _ = check_grid(h, og)
+    assert nlo == 0
+    h.close()
