@@ -2,6 +2,7 @@
 // One gv_context = one device + one stream + one resident grid.  No exception
 // leaves this file; every entry point returns a gv_status.
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
 
 #include <cstdio>
 #include <cstdlib>
@@ -82,6 +83,10 @@ struct gv_context {
 
   bool counts_dirty = false;   // hits/miss/clip_end hold a kept frame
   bool have_counts = false, have_cell_idx = false, have_bbox_id = false;
+
+  // multi-GPU (one large frame sharded by points)
+  ncclComm_t comm = nullptr;
+  int32_t rank = 0, world = 1;
 
   hipEvent_t ev[kNumStages + 1]{};
   std::string err;
@@ -224,6 +229,7 @@ int enqueue_plain_update(gv_context *h, int32_t n_rects)
     t.missT = h->missT;
     t.counts = false;
     t.zero = false;
+    t.use_missT = false;
     t.y_begin = 0;
     t.y_end = h->g.ny;
     launch_finalize_tiles(t, h->stream);
@@ -248,13 +254,16 @@ int enqueue_plain_update(gv_context *h, int32_t n_rects)
   return GV_OK;
 }
 
-int enqueue_frame(gv_context *h, bool stage_events)
+int sharded_tail(gv_context *h, int32_t n_rects);
+
+int enqueue_frame(gv_context *h, bool stage_events, bool sharded = false)
 {
   const uint32_t fl = h->frame_flags;
   const bool do_bin = fl & GV_FRAME_BIN, do_ray = fl & GV_FRAME_RAYMARCH, do_bbox = fl & GV_FRAME_BBOX_TEST;
   const bool keep_cell = fl & GV_FRAME_KEEP_CELL_IDX, keep_counts = fl & GV_FRAME_KEEP_COUNTS;
   const bool vision = fl & GV_FRAME_VISION_ORIENT;
   if (do_ray && !do_bin) return GV_ERR_BAD_ARG;
+  if (sharded && (!do_bin || !h->tile_path || h->force_simple || !h->comm)) return GV_ERR_STATE;
   if (do_bin && !h->has_bl) return GV_ERR_TF;
   if (do_bbox && !h->has_cl) return GV_ERR_TF;
   if (vision && !h->has_bc) return GV_ERR_TF;
@@ -306,7 +315,7 @@ int enqueue_frame(gv_context *h, bool stage_events)
       b.hits = h->hits; b.clip_end = h->clip_end;
       b.hitN = h->hitN; b.clipN = h->clipN; b.hitT = h->hitT; b.clipT = h->clipT;
       b.nxw = h->nxw; b.nyw = h->nyw; b.nx_pad = h->nx_pad; b.ny_pad = h->ny_pad;
-      b.zero_hits = !keep_counts;
+      b.zero_hits = !keep_counts && !sharded;   // the sharded path reduces the counts first
       launch_build_bitmaps(b, h->stream);
     }
     if (stage_events) GV_HIP(hipEventRecord(h->ev[kStageRayCompact + 1], h->stream));
@@ -346,6 +355,7 @@ int enqueue_frame(gv_context *h, bool stage_events)
       launch_ray_sectors(sa, h->stream);
     }
     if (stage_events) GV_HIP(hipEventRecord(h->ev[kStageRayMarch + 1], h->stream));
+    if (sharded) return sharded_tail(h, n_rects);
     FinalizeTileArgs t{};
     t.g = h->g;
     t.log_odds = h->log_odds;
@@ -360,6 +370,7 @@ int enqueue_frame(gv_context *h, bool stage_events)
     t.missT = h->missT;
     t.counts = do_bin;
     t.zero = do_bin && !keep_counts;
+    t.use_missT = true;
     t.y_begin = 0;
     t.y_end = h->g.ny;
     launch_finalize_tiles(t, h->stream);
@@ -403,6 +414,81 @@ int enqueue_frame(gv_context *h, bool stage_events)
   h->have_counts = do_bin && keep_counts;
   h->have_cell_idx = do_bin && keep_cell;
   h->have_bbox_id = do_bbox;
+  return GV_OK;
+}
+
+#define GV_NCCL(call)                                                                          \
+  do {                                                                                         \
+    ncclResult_t r_ = (call);                                                                  \
+    if (r_ != ncclSuccess) {                                                                   \
+      char buf_[256];                                                                          \
+      std::snprintf(buf_, sizeof(buf_), "%s:%d %s -> %s", __FILE__, __LINE__, #call, ncclGetErrorString(r_)); \
+      h->err = buf_;                                                                           \
+      return GV_ERR_RCCL;                                                                      \
+    }                                                                                          \
+  } while (0)
+
+inline void band_rows(const gv_context *h, int r, int32_t &y0, int32_t &y1)
+{
+  y0 = (int32_t)((int64_t)h->g.ny * r / h->world);
+  y1 = (int32_t)((int64_t)h->g.ny * (r + 1) / h->world);
+}
+
+// [EXTENSION] SURVEY 8(e)-2: the one exchange step of the sharded frame.  Every rank has
+// binned + ray-marched ITS slice of the points into private full-size count grids; integer
+// sum / byte max make the result independent of the reduce order, hence bit-identical to
+// one GPU.  Rank r then finalises row band r and the packed int8 bands are exchanged.
+int sharded_tail(gv_context *h, int32_t n_rects)
+{
+  const int nx = h->g.nx, ny = h->g.ny;
+  const size_t G = (size_t)h->g.G;
+  launch_merge_miss(h->miss, h->missT, nx, ny, h->stream);   // miss = N | T^T, missT cleared
+  GV_HIP(hipGetLastError());
+  int32_t y0, y1;
+  band_rows(h, h->rank, y0, y1);
+  if (ny % h->world == 0) {
+    const size_t cnt = G / (size_t)h->world;
+    GV_NCCL(ncclReduceScatter(h->hits, h->hits + (size_t)h->rank * cnt, cnt, ncclInt32, ncclSum, h->comm, h->stream));
+    GV_NCCL(ncclReduceScatter(h->miss, h->miss + (size_t)h->rank * cnt, cnt, ncclUint8, ncclMax, h->comm, h->stream));
+  } else {   // bands are not equal sized: reduce everything everywhere
+    GV_NCCL(ncclAllReduce(h->hits, h->hits, G, ncclInt32, ncclSum, h->comm, h->stream));
+    GV_NCCL(ncclAllReduce(h->miss, h->miss, G, ncclUint8, ncclMax, h->comm, h->stream));
+  }
+  launch_band_hit_bitmap(h->hits, nx, h->ny_pad, y0, y1, h->hitN, h->stream);
+  FinalizeTileArgs t{};
+  t.g = h->g;
+  t.log_odds = h->log_odds;
+  t.occupancy = h->occupancy;
+  t.occ_i8 = h->occ_i8;
+  t.rects = h->d_rects;
+  t.n_rects = n_rects;
+  t.hitN = h->hitN;
+  t.nxw = h->nxw;
+  t.ny_pad = h->ny_pad;
+  t.missN = h->miss;
+  t.missT = h->missT;
+  t.counts = true;
+  t.zero = false;
+  t.use_missT = false;
+  t.y_begin = y0;
+  t.y_end = y1;
+  launch_finalize_tiles(t, h->stream);
+  GV_HIP(hipGetLastError());
+  GV_HIP(hipMemsetAsync(h->hits, 0, G * sizeof(int32_t), h->stream));
+  GV_HIP(hipMemsetAsync(h->miss, 0, G, h->stream));
+  // packed bands to everyone: band r sits at data[G - e_r, G - b_r) (toOccupancyGrid order)
+  GV_NCCL(ncclGroupStart());
+  for (int r = 0; r < h->world; ++r) {
+    int32_t r0, r1;
+    band_rows(h, r, r0, r1);
+    const size_t b = (size_t)r0 * nx, e = (size_t)r1 * nx;
+    if (e > b) GV_NCCL(ncclBroadcast(h->occ_i8 + (G - e), h->occ_i8 + (G - e), e - b, ncclInt8, r, h->comm, h->stream));
+  }
+  GV_NCCL(ncclGroupEnd());
+  h->counts_dirty = false;
+  h->have_counts = false;
+  h->have_cell_idx = false;
+  h->have_bbox_id = (h->frame_flags & GV_FRAME_BBOX_TEST) != 0;
   return GV_OK;
 }
 
@@ -556,6 +642,7 @@ int gv_destroy(gv_handle h)
   if (!h) return GV_ERR_BAD_ARG;
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
+  if (h->comm) { ncclCommDestroy(h->comm); h->comm = nullptr; }
   void *bufs[] = {h->log_odds, h->occupancy, h->occ_i8, h->hits, h->miss, h->clip_end, h->ray_list, h->ray_count,
                   h->ray_stats, h->scratch_i32, h->d_dbg, h->missT, h->hitN, h->clipN, h->hitT, h->clipT, h->cx, h->cy, h->cz, h->tx, h->ty, h->tz, h->raw, h->cell_idx,
                   h->bbox_id, h->d_bboxes, h->d_poses, h->d_rects, h->d_orient, h->d_conf, h->d_dims, h->d_vout,
@@ -1087,13 +1174,6 @@ int gv_time_frame_stages(gv_handle h, int32_t frames, float *stage_ms)
   GV_CATCH
 }
 
-// ---- entry points implemented in later milestones of this build ----
-static int not_built(gv_context *h, const char *what)
-{
-  if (h) h->err = std::string(what) + ": not implemented in this build";
-  return GV_ERR_STATE;
-}
-
 static int ensure_tbuf(gv_context *h, size_t n)
 {
   if (n <= h->tcap) return GV_OK;
@@ -1246,10 +1326,67 @@ int gv_compute_bbox_pose(gv_handle h, const gv_bbox *bboxes, int32_t nb, gv_lsha
   GV_CATCH
 }
 
-int gv_comm_unique_id(uint8_t *) { return GV_ERR_STATE; }
-int gv_comm_init(gv_handle h, const uint8_t *, int32_t, int32_t) { return not_built(h, "gv_comm_init"); }
-int gv_comm_destroy(gv_handle h) { return not_built(h, "gv_comm_destroy"); }
-int gv_process_frame_sharded(gv_handle h, const gv_frame_desc *) { return not_built(h, "gv_process_frame_sharded"); }
-int gv_comm_band(gv_handle h, int64_t *, int64_t *) { return not_built(h, "gv_comm_band"); }
+int gv_comm_unique_id(uint8_t id_out[128])
+{
+  if (!id_out) return GV_ERR_BAD_ARG;
+  static_assert(sizeof(ncclUniqueId) == 128, "RCCL unique id size");
+  ncclUniqueId id;
+  if (ncclGetUniqueId(&id) != ncclSuccess) return GV_ERR_RCCL;
+  std::memcpy(id_out, &id, sizeof(id));
+  return GV_OK;
+}
+
+int gv_comm_init(gv_handle h, const uint8_t id[128], int32_t rank, int32_t world)
+{
+  if (!h || !id || world < 1 || rank < 0 || rank >= world) return GV_ERR_BAD_ARG;
+  if (h->comm) return GV_ERR_STATE;
+  GV_TRY
+  int rc = use_device(h);
+  if (rc) return rc;
+  ncclUniqueId uid;
+  std::memcpy(&uid, id, sizeof(uid));
+  GV_NCCL(ncclCommInitRank(&h->comm, world, uid, rank));
+  h->rank = rank;
+  h->world = world;
+  return GV_OK;
+  GV_CATCH
+}
+
+int gv_comm_destroy(gv_handle h)
+{
+  if (!h) return GV_ERR_BAD_ARG;
+  if (!h->comm) return GV_OK;
+  (void)hipSetDevice(h->device);
+  (void)hipStreamSynchronize(h->stream);
+  ncclCommDestroy(h->comm);
+  h->comm = nullptr;
+  h->rank = 0;
+  h->world = 1;
+  return GV_OK;
+}
+
+int gv_process_frame_sharded(gv_handle h, const gv_frame_desc *desc)
+{
+  if (!h || !desc) return GV_ERR_BAD_ARG;
+  if (!h->comm) return GV_ERR_STATE;
+  int rc = gv_frame_set_detections(h, desc);
+  if (rc) return rc;
+  GV_TRY
+  if ((rc = use_device(h))) return rc;
+  if ((rc = enqueue_frame(h, false, true))) return rc;
+  GV_HIP(hipStreamSynchronize(h->stream));
+  return GV_OK;
+  GV_CATCH
+}
+
+int gv_comm_band(gv_handle h, int64_t *begin, int64_t *end)
+{
+  if (!h) return GV_ERR_BAD_ARG;
+  int32_t y0, y1;
+  band_rows(h, h->rank, y0, y1);
+  if (begin) *begin = (int64_t)y0 * h->g.nx;
+  if (end) *end = (int64_t)y1 * h->g.nx;
+  return GV_OK;
+}
 
 }  // extern "C"

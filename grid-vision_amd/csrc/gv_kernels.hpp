@@ -113,9 +113,12 @@ struct FinalizeTileArgs {
   uint8_t *missN, *missT;
   bool counts;            // apply the hit/miss rule
   bool zero;              // clear the miss grids while reading them
+  bool use_missT;         // false: missT was already folded into missN (multi-GPU path)
   int32_t y_begin, y_end; // rows to finalise ([0, ny) on one GPU)
 };
 void launch_finalize_tiles(const FinalizeTileArgs &a, hipStream_t s);
+void launch_merge_miss(uint8_t *mN, uint8_t *mT, int nx, int ny, hipStream_t s);
+void launch_band_hit_bitmap(const int32_t *hits, int nx, int ny_pad, int y0, int y1, uint32_t *hitN, hipStream_t s);
 void launch_miss_to_i32(const uint8_t *mN, const uint8_t *mT, int nx, int ny, int32_t *out, hipStream_t s);
 
 // ---- kNN depth + radius outlier counts (gv_knn_pca.hip) ----

@@ -736,7 +736,7 @@ __global__ void __launch_bounds__(256) k_finalize_tiles(FinalizeTileArgs a)
       if (k < 64) s_rects[k] = R;
     }
   }
-  if (COUNTS) {
+  if (COUNTS && a.use_missT) {
     // missT rows are x; each holds 64 contiguous y bytes of this tile
     for (int t = tid; t < 64 * 16; t += 256) {
       const int xr = t >> 4, wq = t & 15;
@@ -802,10 +802,12 @@ __global__ void __launch_bounds__(256) k_finalize_tiles(FinalizeTileArgs a)
       }
     }
     const int xr = xq * 4;
-    const bool m0 = COUNTS && ((mN & 0xffu) | tileT[xr + 0][yl]);
-    const bool m1 = COUNTS && (((mN >> 8) & 0xffu) | tileT[xr + 1][yl]);
-    const bool m2 = COUNTS && (((mN >> 16) & 0xffu) | tileT[xr + 2][yl]);
-    const bool m3 = COUNTS && ((mN >> 24) | tileT[xr + 3][yl]);
+    unsigned t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+    if (COUNTS && a.use_missT) { t0 = tileT[xr + 0][yl]; t1 = tileT[xr + 1][yl]; t2 = tileT[xr + 2][yl]; t3 = tileT[xr + 3][yl]; }
+    const bool m0 = COUNTS && ((mN & 0xffu) | t0);
+    const bool m1 = COUNTS && (((mN >> 8) & 0xffu) | t1);
+    const bool m2 = COUNTS && (((mN >> 16) & 0xffu) | t2);
+    const bool m3 = COUNTS && ((mN >> 24) | t3);
     l4.x = cell_update_t(l4.x, k0, COUNTS, hb & 1u, m0);
     l4.y = cell_update_t(l4.y, k1, COUNTS, hb & 2u, m1);
     l4.z = cell_update_t(l4.z, k2, COUNTS, hb & 4u, m2);
@@ -826,6 +828,57 @@ void launch_finalize_tiles(const FinalizeTileArgs &a, hipStream_t s)
   const dim3 grid((a.g.nx + 63) / 64, (rows + 63) / 64);
   if (a.counts) hipLaunchKernelGGL(k_finalize_tiles<true>, grid, dim3(256), 0, s, a);
   else hipLaunchKernelGGL(k_finalize_tiles<false>, grid, dim3(256), 0, s, a);
+}
+
+// [multi-GPU] fold the transposed miss grid into the row-major one (missN |= missT^T) and
+// clear missT, so that one byte grid can be reduced across ranks.  64x64 tiles.
+__global__ void __launch_bounds__(256) k_merge_miss(unsigned char *__restrict__ mN, unsigned char *__restrict__ mT,
+                                                    int nx, int ny)
+{
+  __shared__ unsigned char tile[64][68];
+  const int x0 = blockIdx.x * 64, y0 = blockIdx.y * 64, tid = threadIdx.x;
+  for (int t = tid; t < 64 * 64; t += 256) {
+    const int xr = t >> 6, yl = t & 63;
+    const int x = x0 + xr, y = y0 + yl;
+    unsigned char v = 0;
+    if (x < nx && y < ny) {
+      const size_t off = (size_t)x * ny + y;
+      v = mT[off];
+      if (v) mT[off] = 0;
+    }
+    tile[xr][yl] = v;
+  }
+  __syncthreads();
+  for (int t = tid; t < 64 * 64; t += 256) {
+    const int yl = t >> 6, xr = t & 63;
+    const int x = x0 + xr, y = y0 + yl;
+    if (x < nx && y < ny && tile[xr][yl]) mN[(size_t)y * nx + x] = 1;
+  }
+}
+
+void launch_merge_miss(uint8_t *mN, uint8_t *mT, int nx, int ny, hipStream_t s)
+{
+  hipLaunchKernelGGL(k_merge_miss, dim3((nx + 63) / 64, (ny + 63) / 64), dim3(256), 0, s, mN, mT, nx, ny);
+}
+
+// [multi-GPU] hit bitmap (N orientation only) of rows [y0, y1) from the reduced hit counts
+__global__ void __launch_bounds__(256) k_band_hit_bitmap(const int32_t *__restrict__ hits, int nx, int ny_pad, int y0,
+                                                         int y1, unsigned *__restrict__ hitN)
+{
+  const int lane = threadIdx.x & 63;
+  const int y = y0 + blockIdx.y * 4 + (threadIdx.x >> 6);
+  const int x = blockIdx.x * 64 + lane;
+  if (y >= y1) return;
+  const int h = (x < nx) ? hits[(size_t)y * nx + x] : 0;
+  const unsigned long long m = __ballot(h > 0);
+  if (lane < 2) hitN[(size_t)(2 * blockIdx.x + lane) * ny_pad + y] = (unsigned)(m >> (32 * lane));
+}
+
+void launch_band_hit_bitmap(const int32_t *hits, int nx, int ny_pad, int y0, int y1, uint32_t *hitN, hipStream_t s)
+{
+  if (y1 <= y0) return;
+  hipLaunchKernelGGL(k_band_hit_bitmap, dim3((nx + 63) / 64, (y1 - y0 + 3) / 4), dim3(256), 0, s, hits, nx, ny_pad, y0,
+                     y1, hitN);
 }
 
 // miss read-back: N | T^T as int32 0/1

@@ -338,6 +338,31 @@ class GridVisionHIP:
         self._ck(self._lib.gv_get_ray_stats(self._h, C.byref(a), C.byref(b)), "ray_stats")
         return a.value, b.value
 
+    # ---- multi-GPU (RCCL inside the library)
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        buf = (C.c_uint8 * 128)()
+        rc = load().gv_comm_unique_id(buf)
+        if rc:
+            raise GVError(rc, "gv_comm_unique_id")
+        return bytes(buf)
+
+    def comm_init(self, uid: bytes, rank: int, world: int):
+        buf = (C.c_uint8 * 128).from_buffer_copy(uid)
+        self._ck(self._lib.gv_comm_init(self._h, buf, C.c_int32(rank), C.c_int32(world)), "gv_comm_init")
+
+    def comm_destroy(self):
+        self._ck(self._lib.gv_comm_destroy(self._h), "gv_comm_destroy")
+
+    def comm_band(self):
+        b, e = C.c_int64(), C.c_int64()
+        self._ck(self._lib.gv_comm_band(self._h, C.byref(b), C.byref(e)), "gv_comm_band")
+        return b.value, e.value
+
+    def process_frame_sharded(self, flags, bboxes=None, poses=None, net=None):
+        d = self._desc(flags, bboxes, poses, net)
+        self._ck(self._lib.gv_process_frame_sharded(self._h, C.byref(d)), "process_frame_sharded")
+
     def time_frames(self, frames):
         ms = C.c_float(0)
         self._ck(self._lib.gv_time_frames(self._h, C.c_int32(frames), C.byref(ms)), "time_frames")

@@ -41,10 +41,8 @@ def build(force: bool = False) -> str:
 
 
 def extra_link() -> list:
-    out = []
-    if os.path.exists(os.path.join(CSRC, "gv_comm.hip")):
-        out += ["-L/opt/rocm/lib", "-lrccl"]
-    return out
+    # RCCL for the sharded multi-GPU frame (gv_comm_*)
+    return ["-L/opt/rocm/lib", "-lrccl"]
 
 
 if __name__ == "__main__":

@@ -600,3 +600,29 @@ def test_compute_bbox_pose_pca_path(gvamd):
     nlo, _, _ = check_grid(h, og)
     assert nlo == 0
     h.close()
+
+
+def test_sharded_frame_world1_matches_plain(gvamd):
+    """RCCL path with a 1-rank communicator (all this box has): merge-miss, reduce-scatter,
+    band bitmap, band finalise and band broadcast must reproduce the plain frame exactly.
+    world > 1 is covered algorithmically by tests/test_sharding_gloo.py (CPU, gloo)."""
+    config = 2
+    x, y, z, _ = synth.cloud_uniform(config)
+    poses = synth.lshape_poses(config, 30)
+    bboxes = synth.detections(3, 30)
+    flags = gvamd.FRAME_BIN | gvamd.FRAME_RAYMARCH | gvamd.FRAME_BBOX_TEST
+    ha, tfs = make_handle(gvamd, config, perturbed=True)
+    hb, _ = make_handle(gvamd, config, perturbed=True)
+    hb.comm_init(gvamd.GridVisionHIP.comm_unique_id(), 0, 1)
+    assert hb.comm_band() == (0, hb.G)
+    for h in (ha, hb):
+        h.upload_xyz(x, y, z)
+    for frame in range(3):
+        ha.process_frame(flags, bboxes=bboxes, poses=poses)
+        hb.process_frame_sharded(flags, bboxes=bboxes, poses=poses)
+        assert np.array_equal(ha.log_odds(), hb.log_odds())
+        assert np.array_equal(ha.occupancy(), hb.occupancy())
+        assert np.array_equal(ha.to_occupancy_grid()[0], hb.to_occupancy_grid()[0])
+        assert np.array_equal(ha.bbox_id(), hb.bbox_id())
+    hb.comm_destroy()
+    ha.close(); hb.close()
