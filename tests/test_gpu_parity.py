@@ -626,3 +626,75 @@ def test_sharded_frame_world1_matches_plain(gvamd):
         assert np.array_equal(ha.bbox_id(), hb.bbox_id())
     hb.comm_destroy()
     ha.close(); hb.close()
+
+
+def test_gpu_matches_frozen_fixture(gvamd):
+    """tests/golden/frame_small.npz (made by tests/golden/make_frame_fixture.py): the HIP path
+    against committed expected outputs, independent of the oracle binary on this machine."""
+    gold = np.load(os.path.join(HERE, "golden", "frame_small.npz"))
+    config, N, NDET = 1, 4000, 12
+    h, tfs = make_handle(gvamd, config, perturbed=True)
+    bboxes, poses = synth.detections(3, NDET), synth.lshape_poses(config, NDET)
+    flags = (gvamd.FRAME_BIN | gvamd.FRAME_RAYMARCH | gvamd.FRAME_BBOX_TEST | gvamd.FRAME_KEEP_CELL_IDX
+             | gvamd.FRAME_KEEP_COUNTS)
+    for f in range(3):
+        gen = synth.cloud_lidar_like if f == 1 else synth.cloud_uniform
+        x, y, z, _ = gen(config, N, seed_extra=f)
+        h.upload_xyz(x, y, z)
+        h.process_frame(flags, bboxes=bboxes, poses=poses)
+        hits = h.hits()
+        assert np.array_equal(h.cell_idx(), gold[f"cell_{f}"])
+        assert np.array_equal(np.flatnonzero(hits).astype(np.int32), gold[f"hits_nz_{f}"])
+        assert np.array_equal(hits[hits != 0], gold[f"hits_val_{f}"])
+        assert np.array_equal(np.packbits(h.miss().astype(np.uint8)), gold[f"miss_bits_{f}"])
+        assert np.array_equal(h.bbox_id().astype(np.int8), gold[f"bbox_id_{f}"])
+        assert np.max(np.abs(h.log_odds() - gold[f"log_odds_{f}"])) <= LOG_ODDS_TOL
+        assert np.max(np.abs(h.to_occupancy_grid()[0].astype(int) - gold[f"i8_{f}"].astype(int))) <= 1
+    h.close()
+
+
+def test_cpp_demo(gvamd, tmp_path):
+    """grid-vision_amd/examples/frame_demo.cpp: the reference's timerCallback flow in plain
+    g++ host code over the C ABI (no hipcc, no torch).  Its checksums must equal the same
+    sequence driven through the ctypes binding."""
+    import re
+    import subprocess
+    root = os.path.dirname(HERE)
+    pkg = os.path.join(root, "grid-vision_amd")
+    exe = str(tmp_path / "frame_demo")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", os.path.join(pkg, "examples", "frame_demo.cpp"), "-o", exe,
+                           "-L" + pkg, "-lgridvision_hip", "-Wl,-rpath," + pkg])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    txt = out.stdout
+    sum_i8, sum_hits = (int(v) for v in re.search(r"sum_i8 (-?\d+) sum_hits (\d+)", txt).groups())
+    depth0 = float(re.search(r"depth0 (\S+)", txt).group(1))
+    # the same flow from python
+    n = 50000
+    with np.errstate(over="ignore"):
+        z = synth._mix64(np.uint64(42) + np.arange(1, 3 * n + 1, dtype=np.uint64) * synth.GOLDEN)
+    u = ((z >> np.uint64(40)).astype(np.float32) * np.float32(2.0 ** -24)).reshape(n, 3)
+    x = np.float32(-12.0) + np.float32(56.0) * u[:, 0]
+    y = np.float32(-12.0) + np.float32(24.0) * u[:, 1]
+    zz = np.float32(-2.0) + np.float32(4.0) * u[:, 2]
+    h = gvamd.GridVisionHIP(50, 20, 0.1)
+    h.set_transforms([0.5, -0.5, 0.5, 0.5, 0.0, 0.4, -0.3], [0.5, -0.5, 0.5, -0.5, 0.3, 0.0, 2.2], [0, 0, 0, 1, 0, 0, 1.8])
+    h.upload_xyz(x, y, zz)
+    b = np.array([(100, 150, 220, 300, 0.95, 9), (300, 200, 380, 330, 0.9, 2), (420, 100, 470, 160, 0.8, 5),
+                  (500, 250, 600, 400, 0.7, 0)], dtype=synth.BBOX_DTYPE)
+    st, dy = gvamd.filter_bboxes(b)
+    depths, _ = h.compute_depth_for_bboxes(st, 4)
+    assert abs(depths[0] - depth0) < 1e-5
+    orient = np.tile(np.array([0.8, 0.6, -0.6, 0.8], np.float32), (len(dy), 1))
+    conf = np.tile(np.array([0.3, 0.7], np.float32), (len(dy), 1))
+    dims = np.full((len(dy), 3), 0.1, np.float32)
+    poses = h.transform_lshape_objects(h.vision_post_process(orient, conf, dims, dy))
+    h.update_map_poses(poses)
+    pp, valid = h.compute_bbox_pose(b)
+    h.update_map_poses(h.transform_lshape_objects(pp[valid.astype(bool)]))
+    h.update_map()
+    h.process_frame(gvamd.FRAME_BIN | gvamd.FRAME_RAYMARCH | gvamd.FRAME_BBOX_TEST | gvamd.FRAME_KEEP_COUNTS,
+                    bboxes=b, poses=poses)
+    assert int(h.hits().sum()) == sum_hits
+    assert int(h.to_occupancy_grid()[0].astype(np.int64).sum()) == sum_i8
+    h.close()
