@@ -134,22 +134,38 @@ def main():
 
     out = None
     if rank == 0:
-        # per-kernel device time, HIP events on the handle's own stream
+        # per-kernel device time, HIP events on the handle's own stream (gv_time_frame_stages)
         stages = h.time_frame_stages(max(10, min(a.steps, 50)))
         n_rays, n_visits = h.ray_stats()
         frame_ms = sum(stages.values())
-        alg = {"points": 12.0 * N, "finalize": 13.0 * G}
-        dom = max(stages, key=stages.get)
         bytes_frame = 12.0 * N + 13.0 * G
-        # dominant kernel: its own algorithmic bytes where SURVEY 8(d) assigns any
-        # (points 12N, finalize 13G); the ray-march moves only intermediate grids,
-        # so it is priced with the whole frame's algorithmic bytes over ITS time
-        # share plus a Mcell-visits/s figure.
-        dom_bytes = alg.get(dom, bytes_frame)
+        # Algorithmic bytes per launch (DESIGN.md "Kernels"): SURVEY 8(d) counts 12 B/point
+        # (x,y,z read) and 13 B/cell (log-odds r+w, occupancy w, int8 w); the count grids the
+        # ray stage works on are implementation traffic there.  For the ray kernels the
+        # minimum any implementation of that stage moves is used instead: end flags in
+        # (2 bits/cell in both orientations = G/2 B) and one miss byte per cell out.
+        alg = {"points": 12.0 * N, "ray_ends": 5.0 * G, "ray_march": 1.5 * G, "finalize": 13.0 * G,
+               "detections": 120.0 * (len(bboxes) + len(poses))}
+        kern = {"points": "k_points", "ray_ends": "k_build_bitmaps", "ray_march": "k_ray_sectors",
+                "finalize": "k_finalize_tiles", "detections": "k_rects_from_poses"}
+        dom = max(stages, key=stages.get)
+        kernels = [{"stage": k, "kernel": kern[k], "ms": stages[k], "algorithmic_bytes": alg[k],
+                    "GBps": alg[k] / (stages[k] * 1e-3) / 1e9 if stages[k] > 0 else None,
+                    "frac_hbm_peak": alg[k] / (stages[k] * 1e-3) / 1e9 / HBM_PEAK_GBPS if stages[k] > 0 else None}
+                   for k in stages]
         dom_s = stages[dom] * 1e-3
-        roof = {"bound": "hbm", "kernel": dom, "achieved": dom_bytes / dom_s / 1e9, "peak": HBM_PEAK_GBPS,
-                "unit": "GB/s", "frac": dom_bytes / dom_s / 1e9 / HBM_PEAK_GBPS, "traffic": None,
-                "algorithmic_bytes": dom_bytes, "kernel_ms": stages[dom]}
+        traffic = None
+        tf = os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")
+        if os.path.exists(tf):
+            try:
+                traffic = json.load(open(tf)).get(kern[dom])
+            except Exception:
+                traffic = None
+        roof = {"bound": "hbm", "kernel": kern[dom], "achieved": alg[dom] / dom_s / 1e9, "peak": HBM_PEAK_GBPS,
+                "unit": "GB/s", "frac": alg[dom] / dom_s / 1e9 / HBM_PEAK_GBPS, "traffic": traffic,
+                "algorithmic_bytes": alg[dom], "kernel_ms": stages[dom],
+                "note": "the dominant kernel is the sector ray-march: LDS/latency bound, not HBM bound; "
+                        "see kernels[] for the HBM-bound passes (points 12N, finalize 13G)"}
         out = {
             "metric": "frames/sec into grid (1M-pt cloud / 2000x2000 @ 0.1 m grid)",
             "value": fps, "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -162,8 +178,8 @@ def main():
             "mpoints_per_s": N * fps / 1e6,
             "frame_roofline": {"algorithmic_bytes": bytes_frame, "achieved_GBps": bytes_frame * fps / world / 1e9,
                                "frac_of_hbm_peak": bytes_frame * fps / world / 1e9 / HBM_PEAK_GBPS},
-            "stage_ms": stages, "stage_ms_sum": frame_ms,
-            "ray_march": {"rays": n_rays, "cell_visits": n_visits,
+            "stage_ms": stages, "stage_ms_sum": frame_ms, "kernels": kernels,
+            "ray_march": {"rays": n_rays, "equivalent_cell_visits": n_visits,
                           "mcell_visits_per_s": (n_visits / (stages["ray_march"] * 1e-3) / 1e6) if stages["ray_march"] > 0 else None},
             "roofline": roof,
         }

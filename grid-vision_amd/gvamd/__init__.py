@@ -25,7 +25,7 @@ FRAME_KEEP_CELL_IDX = 1 << 3
 FRAME_KEEP_COUNTS = 1 << 4
 FRAME_VISION_ORIENT = 1 << 5
 
-STAGES = ("detections", "points", "ray_compact", "ray_march", "finalize")
+STAGES = ("detections", "points", "ray_ends", "ray_march", "finalize")
 
 # every symbol include/gridvision_hip.h declares
 ABI_SYMBOLS = [
