@@ -19,6 +19,15 @@ using namespace gv;
 struct gv_context {
   int device = 0;
   hipStream_t stream = nullptr;
+  // frame pipelining: points/bitmaps of frame f+1 (stream) overlap sectors/grid pass of frame f (stream2)
+  hipStream_t stream2 = nullptr;
+  hipEvent_t ev_build[2]{}, ev_fin[2]{};
+  uint32_t *hitN2 = nullptr, *clipN2 = nullptr, *hitT2 = nullptr, *clipT2 = nullptr;   // second bitmap set
+  Rect *d_rects2 = nullptr;
+  uint64_t frame_no = 0;
+  int since_drain = 0;       // pipelined frames enqueued since both streams were last idle
+  bool pipe_busy = false;
+  bool no_pipeline = false;  // GV_PIPELINE=0
   GridParams g{};
   gv_cam_params cam{};
   CamK camk{};
@@ -173,6 +182,7 @@ int ensure_det(gv_context *h, int32_t n)
   if ((rc = re(h->d_bboxes, (size_t)want * sizeof(gv_bbox)))) return rc;
   if ((rc = re(h->d_poses, (size_t)want * sizeof(gv_lshape_pose)))) return rc;
   if ((rc = re(h->d_rects, (size_t)want * sizeof(Rect)))) return rc;
+  if ((rc = re(h->d_rects2, (size_t)want * sizeof(Rect)))) return rc;
   if ((rc = re(h->d_orient, (size_t)want * 4 * sizeof(float)))) return rc;
   if ((rc = re(h->d_conf, (size_t)want * 2 * sizeof(float)))) return rc;
   if ((rc = re(h->d_dims, (size_t)want * 3 * sizeof(float)))) return rc;
@@ -183,9 +193,22 @@ int ensure_det(gv_context *h, int32_t n)
   return GV_OK;
 }
 
+int set_device_only(gv_context *h)
+{
+  GV_HIP(hipSetDevice(h->device));
+  return GV_OK;
+}
+
+// Every entry point except the pipelined gv_frame_enqueue starts from two idle streams.
 int use_device(gv_context *h)
 {
   GV_HIP(hipSetDevice(h->device));
+  if (h->pipe_busy) {
+    GV_HIP(hipStreamSynchronize(h->stream));
+    GV_HIP(hipStreamSynchronize(h->stream2));
+    h->pipe_busy = false;
+    h->since_drain = 0;
+  }
   return GV_OK;
 }
 
@@ -256,6 +279,44 @@ int enqueue_plain_update(gv_context *h, int32_t n_rects)
 
 int sharded_tail(gv_context *h, int32_t n_rects);
 
+// sector-kernel launch parameters for the resident cloud and grid (set-0 bitmaps by default)
+int fill_sector_args(gv_context *h, SectorArgs &sa)
+{
+  sa.g = h->g;
+  sa.org = h->org;
+  // sectors per octant: wedge width <= 32 cells (imax <= 30*S) and ~<= cap ends per sector
+  const int imax = std::max(std::max(h->org.cx, h->g.nx - 1 - h->org.cx), std::max(h->org.cy, h->g.ny - 1 - h->org.cy));
+  // Measured on config 3 (tools/sweep_sectors.sh): 128 sectors per octant with 4096-end
+  // LDS chunks beats 256 x 2048 (62 vs 79 us): the kernel is bound by per-workgroup
+  // latency chains, so fewer, fatter wedges win as long as a wedge fits one chunk.
+  int log2s = 7;
+  while ((30 << log2s) < imax) ++log2s;
+  const double dens = std::min((double)h->n, (double)h->g.G) / (double)h->g.G;
+  double est = 1.5 * dens * (double)imax * (double)imax / (double)(2 << log2s);
+  while (est > 5000.0 && log2s < 12) {
+    ++log2s;
+    est *= 0.5;
+  }
+  if (h->env_log2s > 0) log2s = h->env_log2s;
+  sa.log2s = log2s;
+  sa.cap = h->env_cap > 0 ? std::max(2048, h->env_cap) : ((est <= 1700.0 && h->env_log2s <= 0) ? 2048 : 4096);
+  sa.ablate = h->env_ablate;
+  sa.dbg = h->d_dbg;
+  sa.log2m = h->env_log2m > 0 ? h->env_log2m : 9;
+  while (sa.log2m < 9 && ((1 << sa.log2m) << sa.log2s) <= imax) ++sa.log2m;   // one boundary per bucket
+  sa.marks_words = (std::max(h->g.nx, h->g.ny) + 2) & ~1;
+  sa.hitN = h->hitN; sa.clipN = h->clipN; sa.hitT = h->hitT; sa.clipT = h->clipT;
+  sa.nxw = h->nxw; sa.nyw = h->nyw; sa.nx_pad = h->nx_pad; sa.ny_pad = h->ny_pad;
+  sa.missN = h->miss;
+  sa.missT = h->missT;
+  sa.stats = h->ray_stats;
+  h->last_log2s = sa.log2s;
+  h->last_cap = sa.cap;
+  h->stat_slots = (size_t)8 << sa.log2s;
+  return GV_OK;
+}
+
+
 int enqueue_frame(gv_context *h, bool stage_events, bool sharded = false)
 {
   const uint32_t fl = h->frame_flags;
@@ -321,37 +382,7 @@ int enqueue_frame(gv_context *h, bool stage_events, bool sharded = false)
     if (stage_events) GV_HIP(hipEventRecord(h->ev[kStageRayCompact + 1], h->stream));
     if (do_ray && h->org.valid) {
       SectorArgs sa{};
-      sa.g = h->g;
-      sa.org = h->org;
-      // sectors per octant: wedge width <= 32 cells (imax <= 30*S) and ~<= cap ends per sector
-      const int imax = std::max(std::max(h->org.cx, h->g.nx - 1 - h->org.cx), std::max(h->org.cy, h->g.ny - 1 - h->org.cy));
-      // Measured on config 3 (tools/sweep_sectors.sh): 128 sectors per octant with 4096-end
-      // LDS chunks beats 256 x 2048 (62 vs 79 us): the kernel is bound by per-workgroup
-      // latency chains, so fewer, fatter wedges win as long as a wedge fits one chunk.
-      int log2s = 7;
-      while ((30 << log2s) < imax) ++log2s;
-      const double dens = std::min((double)h->n, (double)h->g.G) / (double)h->g.G;
-      double est = 1.5 * dens * (double)imax * (double)imax / (double)(2 << log2s);
-      while (est > 5000.0 && log2s < 12) {
-        ++log2s;
-        est *= 0.5;
-      }
-      if (h->env_log2s > 0) log2s = h->env_log2s;
-      sa.log2s = log2s;
-      sa.cap = h->env_cap > 0 ? std::max(2048, h->env_cap) : ((est <= 1700.0 && h->env_log2s <= 0) ? 2048 : 4096);
-      sa.ablate = h->env_ablate;
-      sa.dbg = h->d_dbg;
-      sa.log2m = h->env_log2m > 0 ? h->env_log2m : 9;
-      while (sa.log2m < 9 && ((1 << sa.log2m) << sa.log2s) <= imax) ++sa.log2m;   // one boundary per bucket
-      sa.marks_words = (std::max(h->g.nx, h->g.ny) + 2) & ~1;
-      sa.hitN = h->hitN; sa.clipN = h->clipN; sa.hitT = h->hitT; sa.clipT = h->clipT;
-      sa.nxw = h->nxw; sa.nyw = h->nyw; sa.nx_pad = h->nx_pad; sa.ny_pad = h->ny_pad;
-      sa.missN = h->miss;
-      sa.missT = h->missT;
-      sa.stats = h->ray_stats;
-      h->last_log2s = sa.log2s;
-      h->last_cap = sa.cap;
-      h->stat_slots = (size_t)8 << sa.log2s;
+      { int rc2 = fill_sector_args(h, sa); if (rc2) return rc2; }
       launch_ray_sectors(sa, h->stream);
     }
     if (stage_events) GV_HIP(hipEventRecord(h->ev[kStageRayMarch + 1], h->stream));
@@ -413,6 +444,105 @@ int enqueue_frame(gv_context *h, bool stage_events, bool sharded = false)
   h->counts_dirty = do_bin && keep_counts;
   h->have_counts = do_bin && keep_counts;
   h->have_cell_idx = do_bin && keep_cell;
+  h->have_bbox_id = do_bbox;
+  return GV_OK;
+}
+
+// Pipelined frame (production path): stream A = rectangles, points pass, end bitmaps of frame f;
+// stream B = sector ray stage + grid pass of frame f.  A may run up to two frames ahead of B:
+// the end bitmaps and rectangles are double buffered (set f & 1), everything else is either
+// private to one stream (hits/clip_end: A; miss grids, grid layers: B) or ordered by events.
+int enqueue_frame_pipelined(gv_context *h)
+{
+  const uint32_t fl = h->frame_flags;
+  const bool do_bin = fl & GV_FRAME_BIN, do_ray = fl & GV_FRAME_RAYMARCH, do_bbox = fl & GV_FRAME_BBOX_TEST;
+  const bool vision = fl & GV_FRAME_VISION_ORIENT;
+  if (do_ray && !do_bin) return GV_ERR_BAD_ARG;
+  if (do_bin && !h->has_bl) return GV_ERR_TF;
+  if (do_bbox && !h->has_cl) return GV_ERR_TF;
+  if (vision && !h->has_bc) return GV_ERR_TF;
+  if (h->counts_dirty) { int rc = clear_counts(h); if (rc) return rc; }
+  const int p = (int)(h->frame_no & 1);
+  hipStream_t sA = h->stream, sB = h->stream2;
+  uint32_t *hitN = p ? h->hitN2 : h->hitN, *clipN = p ? h->clipN2 : h->clipN;
+  uint32_t *hitT = p ? h->hitT2 : h->hitT, *clipT = p ? h->clipT2 : h->clipT;
+  Rect *rects = p ? h->d_rects2 : h->d_rects;
+  if (h->since_drain >= 2) GV_HIP(hipStreamWaitEvent(sA, h->ev_fin[p], 0));   // set p is free again
+
+  int32_t n_rects = 0;
+  if (vision && h->nb > 0) {
+    launch_vision(h->d_orient, h->d_conf, h->d_dims, h->d_bboxes, h->nb, h->cam, h->d_vout, h->d_poses, sA);
+    launch_rects_from_poses(h->d_poses, h->nb, h->g, true, h->x_bc, rects, sA);
+    n_rects = h->nb;
+  } else if (h->n_poses > 0) {
+    launch_rects_from_poses(h->d_poses, h->n_poses, h->g, false, h->x_bc, rects, sA);
+    n_rects = h->n_poses;
+  }
+  if (do_bin || do_bbox) {
+    PointsArgs a{};
+    a.x = h->cx; a.y = h->cy; a.z = h->cz;
+    a.n = (uint32_t)h->n;
+    a.g = h->g;
+    a.m_base = h->m_base;
+    a.m_cam = h->m_cam;
+    a.cam = h->camk;
+    a.org = h->org;
+    a.bboxes = h->d_bboxes;
+    a.nb = h->nb;
+    a.bbox_f = h->d_bbox_f;
+    a.tile_mask = h->d_tile_mask;
+    a.tiles_x = h->tiles_x; a.tiles_y = h->tiles_y; a.mask_words = h->mask_words;
+    a.hits = h->hits;
+    a.clip_end = h->clip_end;
+    a.cell_idx = nullptr;
+    a.bbox_id = h->bbox_id;
+    a.do_bin = do_bin; a.do_ray = do_ray; a.do_bbox = do_bbox;
+    launch_points(a, sA);
+  }
+  if (do_bin) {
+    BitmapArgs b{};
+    b.nx = h->g.nx; b.ny = h->g.ny;
+    b.hits = h->hits; b.clip_end = h->clip_end;
+    b.hitN = hitN; b.clipN = clipN; b.hitT = hitT; b.clipT = clipT;
+    b.nxw = h->nxw; b.nyw = h->nyw; b.nx_pad = h->nx_pad; b.ny_pad = h->ny_pad;
+    b.zero_hits = true;
+    launch_build_bitmaps(b, sA);
+  }
+  GV_HIP(hipEventRecord(h->ev_build[p], sA));
+  GV_HIP(hipStreamWaitEvent(sB, h->ev_build[p], 0));
+  if (do_ray && h->org.valid) {
+    SectorArgs sa{};
+    int rc = fill_sector_args(h, sa);
+    if (rc) return rc;
+    sa.hitN = hitN; sa.clipN = clipN; sa.hitT = hitT; sa.clipT = clipT;
+    launch_ray_sectors(sa, sB);
+  }
+  FinalizeTileArgs t{};
+  t.g = h->g;
+  t.log_odds = h->log_odds;
+  t.occupancy = h->occupancy;
+  t.occ_i8 = h->occ_i8;
+  t.rects = rects;
+  t.n_rects = n_rects;
+  t.hitN = hitN;
+  t.nxw = h->nxw;
+  t.ny_pad = h->ny_pad;
+  t.missN = h->miss;
+  t.missT = h->missT;
+  t.counts = do_bin;
+  t.zero = do_bin;
+  t.use_missT = true;
+  t.y_begin = 0;
+  t.y_end = h->g.ny;
+  launch_finalize_tiles(t, sB);
+  GV_HIP(hipEventRecord(h->ev_fin[p], sB));
+  GV_HIP(hipGetLastError());
+  h->frame_no++;
+  if (h->since_drain < 2) h->since_drain++;
+  h->pipe_busy = true;
+  h->counts_dirty = false;
+  h->have_counts = false;
+  h->have_cell_idx = false;
   h->have_bbox_id = do_bbox;
   return GV_OK;
 }
@@ -581,6 +711,11 @@ int gv_create(gv_handle *out, uint8_t grid_x, uint8_t grid_y, double resolution,
   } while (0)
   GV_C(hipSetDevice(h->device));
   GV_C(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+  GV_C(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
+  for (int i = 0; i < 2; ++i) {
+    GV_C(hipEventCreateWithFlags(&h->ev_build[i], hipEventDisableTiming));
+    GV_C(hipEventCreateWithFlags(&h->ev_fin[i], hipEventDisableTiming));
+  }
   const size_t G = (size_t)g.G;
   GV_C(hipMalloc(reinterpret_cast<void **>(&h->log_odds), G * sizeof(float)));
   GV_C(hipMalloc(reinterpret_cast<void **>(&h->occupancy), G * sizeof(float)));
@@ -607,12 +742,21 @@ int gv_create(gv_handle *out, uint8_t grid_x, uint8_t grid_y, double resolution,
     GV_C(hipMemsetAsync(h->clipN, 0, nN * sizeof(uint32_t), h->stream));
     GV_C(hipMemsetAsync(h->hitT, 0, nT * sizeof(uint32_t), h->stream));
     GV_C(hipMemsetAsync(h->clipT, 0, nT * sizeof(uint32_t), h->stream));
+    GV_C(hipMalloc(reinterpret_cast<void **>(&h->hitN2), nN * sizeof(uint32_t)));
+    GV_C(hipMalloc(reinterpret_cast<void **>(&h->clipN2), nN * sizeof(uint32_t)));
+    GV_C(hipMalloc(reinterpret_cast<void **>(&h->hitT2), nT * sizeof(uint32_t)));
+    GV_C(hipMalloc(reinterpret_cast<void **>(&h->clipT2), nT * sizeof(uint32_t)));
+    GV_C(hipMemsetAsync(h->hitN2, 0, nN * sizeof(uint32_t), h->stream));
+    GV_C(hipMemsetAsync(h->clipN2, 0, nN * sizeof(uint32_t), h->stream));
+    GV_C(hipMemsetAsync(h->hitT2, 0, nT * sizeof(uint32_t), h->stream));
+    GV_C(hipMemsetAsync(h->clipT2, 0, nT * sizeof(uint32_t), h->stream));
   }
   // packed (a,b) fields hold 13 bits each; vector stores need nx % 4 == 0
   h->tile_path = (g.nx % 4 == 0) && g.nx <= 8000 && g.ny <= 8000;
   {
     const char *impl = std::getenv("GV_RAY_IMPL");
     h->force_simple = impl && std::strcmp(impl, "simple") == 0;
+    if (const char *e = std::getenv("GV_PIPELINE")) h->no_pipeline = std::atoi(e) == 0;
     if (const char *e = std::getenv("GV_LOG2S")) h->env_log2s = std::atoi(e);
     if (const char *e = std::getenv("GV_CAP")) h->env_cap = std::atoi(e);
     if (const char *e = std::getenv("GV_ABLATE")) h->env_ablate = std::atoi(e);
@@ -642,9 +786,10 @@ int gv_destroy(gv_handle h)
   if (!h) return GV_ERR_BAD_ARG;
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
+  if (h->stream2) (void)hipStreamSynchronize(h->stream2);
   if (h->comm) { ncclCommDestroy(h->comm); h->comm = nullptr; }
   void *bufs[] = {h->log_odds, h->occupancy, h->occ_i8, h->hits, h->miss, h->clip_end, h->ray_list, h->ray_count,
-                  h->ray_stats, h->scratch_i32, h->d_dbg, h->missT, h->hitN, h->clipN, h->hitT, h->clipT, h->cx, h->cy, h->cz, h->tx, h->ty, h->tz, h->raw, h->cell_idx,
+                  h->ray_stats, h->scratch_i32, h->d_dbg, h->hitN2, h->clipN2, h->hitT2, h->clipT2, h->d_rects2, h->missT, h->hitN, h->clipN, h->hitT, h->clipT, h->cx, h->cy, h->cz, h->tx, h->ty, h->tz, h->raw, h->cell_idx,
                   h->bbox_id, h->d_bboxes, h->d_poses, h->d_rects, h->d_orient, h->d_conf, h->d_dims, h->d_vout,
                   h->d_pts, h->d_bbox_f, h->d_tile_mask, h->knn_partial, h->d_depths, h->d_knn_d2, h->d_idx, h->d_segof,
                   h->d_segstart, h->gx, h->gy, h->gz, h->d_keep};
@@ -652,6 +797,11 @@ int gv_destroy(gv_handle h)
     if (p) (void)hipFree(p);
   for (auto &e : h->ev)
     if (e) (void)hipEventDestroy(e);
+  for (int i = 0; i < 2; ++i) {
+    if (h->ev_build[i]) (void)hipEventDestroy(h->ev_build[i]);
+    if (h->ev_fin[i]) (void)hipEventDestroy(h->ev_fin[i]);
+  }
+  if (h->stream2) (void)hipStreamDestroy(h->stream2);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
   return GV_OK;
@@ -1054,6 +1204,13 @@ int gv_frame_enqueue(gv_handle h)
 {
   if (!h) return GV_ERR_BAD_ARG;
   GV_TRY
+  const uint32_t keep = GV_FRAME_KEEP_CELL_IDX | GV_FRAME_KEEP_COUNTS;
+  const bool pipelined = h->tile_path && !h->force_simple && !h->no_pipeline && !(h->frame_flags & keep);
+  if (pipelined) {
+    int rc = set_device_only(h);
+    if (rc) return rc;
+    return enqueue_frame_pipelined(h);
+  }
   int rc = use_device(h);
   if (rc) return rc;
   return enqueue_frame(h, false);
@@ -1145,7 +1302,11 @@ int gv_time_frames(gv_handle h, int32_t frames, float *ms_total)
   hipEvent_t e0 = h->ev[0], e1 = h->ev[kNumStages];
   GV_HIP(hipEventRecord(e0, h->stream));
   for (int32_t i = 0; i < frames; ++i)
-    if ((rc = enqueue_frame(h, false))) return rc;
+    if ((rc = gv_frame_enqueue(h))) return rc;
+  if (h->pipe_busy) {   // join stream B into stream A before the closing event
+    GV_HIP(hipEventRecord(h->ev[1], h->stream2));
+    GV_HIP(hipStreamWaitEvent(h->stream, h->ev[1], 0));
+  }
   GV_HIP(hipEventRecord(e1, h->stream));
   GV_HIP(hipEventSynchronize(e1));
   GV_HIP(hipEventElapsedTime(ms_total, e0, e1));
