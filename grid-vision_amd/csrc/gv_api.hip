@@ -304,7 +304,7 @@ int fill_sector_args(gv_context *h, SectorArgs &sa)
   sa.dbg = h->d_dbg;
   sa.log2m = h->env_log2m > 0 ? h->env_log2m : 9;
   while (sa.log2m < 9 && ((1 << sa.log2m) << sa.log2s) <= imax) ++sa.log2m;   // one boundary per bucket
-  sa.marks_words = (std::max(h->g.nx, h->g.ny) + 2) & ~1;
+  sa.marks_words = (imax + 3) & ~1;   // one word per wedge column, 0..imax
   sa.hitN = h->hitN; sa.clipN = h->clipN; sa.hitT = h->hitT; sa.clipT = h->clipT;
   sa.nxw = h->nxw; sa.nyw = h->nyw; sa.nx_pad = h->nx_pad; sa.ny_pad = h->ny_pad;
   sa.missN = h->miss;

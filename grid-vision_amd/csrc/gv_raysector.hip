@@ -174,7 +174,8 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
   unsigned short *sfx = reinterpret_cast<unsigned short *>(smem + L.sfx);   // max from m to the block end
   unsigned *raw = reinterpret_cast<unsigned *>(smem + L.raw);               // staging: packed ends, scan order
   unsigned short *bkt = reinterpret_cast<unsigned short *>(smem + L.bkt);   // staging: their slope buckets
-  __shared__ unsigned s_wsum[NT / 64], s_blkmax[8], s_lvlmin[16], s_nlong;
+  __shared__ unsigned s_wsum[NT / 64], s_blkmax[8], s_blkpfx[9], s_blksfx[9], s_lvlmin[16], s_nlong;
+  __shared__ int s_T;
   __shared__ unsigned long long s_wvis[NT / 64];
 
   // diagnostic build only (GV_SECTOR_DBG=1): thread 0 stamps the shader clock at phase
@@ -428,8 +429,8 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
     // (the test is monotone in i).  Columns beyond T are crossed only by the few rays with
     // reach > T+1: when that is cheap, march exactly those rays over exactly those columns
     // instead of evaluating every cell there.
-    int T = 0;
-    {
+    if (tid == 0) {
+      int Tt = 0;
       bool open = true;
       for (int Lv = 0; Lv <= lv_max && Lv <= LM && open; ++Lv) {
         // columns whose cell width asks for level Lv: ceil(2i/S) in (2^(Lv-1), 2^Lv]
@@ -445,11 +446,19 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
             lm = min(lm, gm);
           }
         }
-        if (lm > (unsigned)hiL) T = hiL;
-        else { T = max(T, min(hiL, (int)lm - 1)); open = false; }
+        if (lm > (unsigned)hiL) Tt = hiL;
+        else { Tt = max(Tt, min(hiL, (int)lm - 1)); open = false; }
       }
-      if (A.ablate & 64) T = 0;
+      if (A.ablate & 64) Tt = 0;
+      s_T = Tt;
+      // exclusive prefix / suffix maxima over the 64-bucket blocks (edge-cell queries)
+      unsigned run = 0;
+      for (int bk = 0; bk < NB; ++bk) { s_blkpfx[bk] = run; run = max(run, s_blkmax[bk]); }
+      run = 0;
+      for (int bk = NB - 1; bk >= 0; --bk) { s_blksfx[bk] = run; run = max(run, s_blkmax[bk]); }
     }
+    __syncthreads();
+    const int T = s_T;
     // long rays (reach > T+1) -> compact list in the (now free) cursor array `cnt`
     bool march_tail = false;
     if (T < oc.imax && !(A.ablate & 256)) {
@@ -517,24 +526,8 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
       // a cell interval (width 1/i in slope) fully contains an aligned group of level Lv
       // buckets when 2^Lv >= 2i/S; if every such group holds a ray longer than i, every
       // cell that lies inside the sector's slope range (k = 1..w-2) is traversed.
-      const int tq = (Q + S - 1) >> A.log2s;
-      const int Lv = (tq <= 1) ? 0 : 32 - __clz(tq - 1);
-      bool interior_free = false;
-      if (w > 2 && Lv <= LM) {
-        unsigned lm;
-        if (LM - Lv <= 6) lm = s_lvlmin[Lv];
-        else {
-          // groups of 2^(LM-Lv-6) whole blocks
-          const int gb = 1 << (LM - Lv - 6);
-          lm = 0xFFFFFFFFu;
-          for (int g0 = 0; g0 < NB; g0 += gb) {
-            unsigned gm = 0;
-            for (int bk = g0; bk < g0 + gb; ++bk) gm = max(gm, s_blkmax[bk]);
-            lm = min(lm, gm);
-          }
-        }
-        interior_free = lm > (unsigned)i;
-      }
+      // columns up to T have every interior cell free (monotone test, computed once above)
+      bool interior_free = (w > 2) && (i <= T);
       if (A.ablate & 64) interior_free = false;           // timing experiment: always the full loop
       if ((A.ablate & 128) && !interior_free) continue;   // timing experiment: skip the full loop
       unsigned mask = 0;
@@ -544,7 +537,12 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
         {
           const int Phi = 2 * jlo + 1;
           const int hi = bucket_of_boundary(Phi, Q);
-          unsigned mx = (hi >= 1) ? rmq(0, min(hi, M) - 1) : 0u;
+          // max reach over buckets [0, hi-1]: in-block prefix + whole blocks before it
+          unsigned mx = 0u;
+          if (hi >= 1) {
+            const int r = min(hi, M) - 1;
+            mx = max((unsigned)pfx[r], s_blkpfx[r >> 6]);
+          }
           if (mx <= (unsigned)i && hi >= 0 && hi < M) {
             for (unsigned e = bstart[hi]; e < bstart[hi + 1]; ++e) {
               const unsigned p = abv[e];
@@ -558,7 +556,12 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
         {
           const int Plo = 2 * jhi - 1;
           const int lo = bucket_of_boundary(Plo, Q);
-          unsigned mx = (lo + 1 <= M - 1) ? rmq(max(lo + 1, 0), M - 1) : 0u;
+          // max reach over buckets [lo+1, M-1]: in-block suffix + whole blocks after it
+          unsigned mx = 0u;
+          if (lo + 1 <= M - 1) {
+            const int l = max(lo + 1, 0);
+            mx = max((unsigned)sfx[l], s_blksfx[l >> 6]);
+          }
           if (mx <= (unsigned)i && lo >= 0 && lo < M) {
             for (unsigned e = bstart[lo]; e < bstart[lo + 1]; ++e) {
               const unsigned p = abv[e];
