@@ -84,10 +84,18 @@ def main():
     n_gpus = max(a.gpus, 1)
     import torch
     dist = None
+    ndev = torch.cuda.device_count()
+    on_gpu_collectives = ndev >= world
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if on_gpu_collectives:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))   # nccl == RCCL
+        else:
+            # rehearsal on a box with fewer GPUs than ranks: ranks share devices, gloo for the barrier
+            local_rank = local_rank % max(ndev, 1)
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend="gloo")
     else:
         torch.cuda.set_device(0)
         local_rank = 0
@@ -126,7 +134,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if on_gpu_collectives else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     frames = a.steps * world
@@ -174,7 +182,8 @@ def main():
             "config": {"workload": f"BASELINE configs[{config - 1}]: {N}-point {a.cloud} cloud per GPU, "
                                    f"{g.nx}x{g.ny} @ {g.resolution} m grid, {len(bboxes)} bboxes + {len(poses)} poses, "
                                    "bin + ray-march + bbox test + grid pass",
-                       "points": N, "cells": G, "parallelism": f"frame-per-gpu x{world}"},
+                       "points": N, "cells": G, "parallelism": f"frame-per-gpu x{world}",
+                       "devices_visible": ndev},
             "mpoints_per_s": N * fps / 1e6,
             "frame_roofline": {"algorithmic_bytes": bytes_frame, "achieved_GBps": bytes_frame * fps / world / 1e9,
                                "frac_of_hbm_peak": bytes_frame * fps / world / 1e9 / HBM_PEAK_GBPS},

@@ -688,7 +688,11 @@ void launch_ray_sectors(const SectorArgs &a, hipStream_t s)
 // ------------------------------------------------------ tile grid pass -----
 __device__ __forceinline__ float sigmoid_ref_t(float l)
 {
+#ifdef GV_EXPF_EXPERIMENT
+  const float e = expf(-l);
+#else
   const float e = (float)exp((double)(-l));
+#endif
   return 1.0f / (1.0f + e);
 }
 
@@ -769,7 +773,7 @@ __global__ void __launch_bounds__(256) k_finalize_tiles(FinalizeTileArgs a)
   const bool overflow = s_nr > 64;
   const int xq = tid & 15;        // which float4 of the row
   const int x = x0 + xq * 4;
-#pragma unroll 2
+#pragma unroll
   for (int pass = 0; pass < 4; ++pass) {
     const int yl = pass * 16 + (tid >> 4);
     const int y = y0 + yl;
