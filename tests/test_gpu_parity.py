@@ -698,3 +698,31 @@ def test_cpp_demo(gvamd, tmp_path):
     assert int(h.hits().sum()) == sum_hits
     assert int(h.to_occupancy_grid()[0].astype(np.int64).sum()) == sum_i8
     h.close()
+
+
+@pytest.mark.timeout(600)
+def test_config5_full_size(gvamd):
+    """BASELINE configs[4] at full size on one GPU: 10M points, 4000x4000 @ 0.05 m
+    (wedges longer than 2048 columns -> the 8-columns-per-thread sector kernel)."""
+    config = 5
+    h, tfs = make_handle(gvamd, config, perturbed=True)
+    g = synth.CONFIGS[config]["grid"]
+    assert (h.nx, h.ny) == (4000, 4000)
+    x, y, z, _ = synth.cloud_lidar_like(config, 5_000_000)
+    x2, y2, z2, _ = synth.cloud_uniform(config, 5_000_000)
+    x, y, z = np.concatenate([x, x2]), np.concatenate([y, y2]), np.concatenate([z, z2])
+    h.upload_xyz(x, y, z)
+    h.process_frame(gvamd.FRAME_BIN | gvamd.FRAME_RAYMARCH | gvamd.FRAME_KEEP_CELL_IDX | gvamd.FRAME_KEEP_COUNTS)
+    og = ol.OGrid(g.grid_x, g.grid_y, g.resolution)
+    hits, cell, miss, _, _ = oracle_frame(og, tfs, x, y, z)
+    assert np.array_equal(h.cell_idx(), cell)
+    assert np.array_equal(h.hits(), hits)
+    assert np.array_equal(h.miss(), miss.astype(np.int32))
+    nlo, _, _ = check_grid(h, og)
+    assert nlo == 0
+    # the production (pipelined, counts not kept) path on the same input gives the same grid
+    h2, _ = make_handle(gvamd, config, perturbed=True)
+    h2.upload_xyz(x, y, z)
+    h2.process_frame(gvamd.FRAME_BIN | gvamd.FRAME_RAYMARCH)
+    assert np.array_equal(h2.log_odds(), h.log_odds())
+    h.close(); h2.close()
