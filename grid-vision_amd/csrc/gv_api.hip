@@ -82,6 +82,9 @@ struct gv_context {
   float *d_depths = nullptr, *d_knn_d2 = nullptr; size_t knn_out_cap = 0;
   int32_t *d_idx = nullptr, *d_segof = nullptr, *d_segstart = nullptr; size_t seg_cap = 0, segstart_cap = 0;
   float *gx = nullptr, *gy = nullptr, *gz = nullptr; uint8_t *d_keep = nullptr; size_t gcap = 0;
+  float4 *d_planes = nullptr; unsigned *d_plane_counts = nullptr; size_t planes_cap = 0;
+  uint8_t *d_ground = nullptr; size_t ground_cap = 0;
+  std::vector<uint8_t> ground_mask;   // last gv_segment_ground_plane result (host copy)
   float4 *d_bbox_f = nullptr;                // float thresholds of the bbox test
   unsigned long long *d_tile_mask = nullptr; // candidate masks per 16x16-pixel tile
   size_t tile_mask_cap = 0;
@@ -792,7 +795,7 @@ int gv_destroy(gv_handle h)
                   h->ray_stats, h->scratch_i32, h->d_dbg, h->hitN2, h->clipN2, h->hitT2, h->clipT2, h->d_rects2, h->missT, h->hitN, h->clipN, h->hitT, h->clipT, h->cx, h->cy, h->cz, h->tx, h->ty, h->tz, h->raw, h->cell_idx,
                   h->bbox_id, h->d_bboxes, h->d_poses, h->d_rects, h->d_orient, h->d_conf, h->d_dims, h->d_vout,
                   h->d_pts, h->d_bbox_f, h->d_tile_mask, h->knn_partial, h->d_depths, h->d_knn_d2, h->d_idx, h->d_segof,
-                  h->d_segstart, h->gx, h->gy, h->gz, h->d_keep};
+                  h->d_segstart, h->gx, h->gy, h->gz, h->d_keep, h->d_planes, h->d_plane_counts, h->d_ground};
   for (void *p : bufs)
     if (p) (void)hipFree(p);
   for (auto &e : h->ev)
@@ -1385,7 +1388,8 @@ int gv_compute_depth_for_bboxes(gv_handle h, const gv_bbox *bboxes, int32_t nb, 
   GV_CATCH
 }
 
-int gv_compute_bbox_pose(gv_handle h, const gv_bbox *bboxes, int32_t nb, gv_lshape_pose *poses_out, uint8_t *valid)
+static int compute_bbox_pose_impl(gv_handle h, const gv_bbox *bboxes, int32_t nb, gv_lshape_pose *poses_out,
+                                  uint8_t *valid, const uint8_t *skip)
 {
   if (!h || nb < 0 || (nb && (!bboxes || !poses_out || !valid))) return GV_ERR_BAD_ARG;
   if (!h->has_cl) return GV_ERR_TF;
@@ -1424,6 +1428,9 @@ int gv_compute_bbox_pose(gv_handle h, const gv_bbox *bboxes, int32_t nb, gv_lsha
   h->have_bbox_id = true;
   // per-bbox point lists in cloud order (the reference appends in cloud order, :286)
   std::vector<int32_t> seg_start((size_t)nb + 1, 0);
+  if (skip)   // ground points were removed before extractCloudPerBBox (cloud_detections.cpp:306-314)
+    for (size_t i = 0; i < n; ++i)
+      if (skip[i]) ids[i] = -1;
   for (size_t i = 0; i < n; ++i)
     if (ids[i] >= 0) seg_start[(size_t)ids[i] + 1]++;
   for (int32_t b = 0; b < nb; ++b) seg_start[b + 1] += seg_start[b];
@@ -1485,6 +1492,107 @@ int gv_compute_bbox_pose(gv_handle h, const gv_bbox *bboxes, int32_t nb, gv_lsha
   }
   return GV_OK;
   GV_CATCH
+}
+
+int gv_compute_bbox_pose(gv_handle h, const gv_bbox *bboxes, int32_t nb, gv_lshape_pose *poses_out, uint8_t *valid)
+{
+  return compute_bbox_pose_impl(h, bboxes, nb, poses_out, valid, nullptr);
+}
+
+int gv_segment_ground_plane(gv_handle h, double threshold, int32_t iterations, uint64_t seed, uint8_t *is_ground,
+                            float coeff[4], int64_t *n_inliers)
+{
+  if (!h || !(threshold > 0.0) || iterations < 1 || iterations > 4096) return GV_ERR_BAD_ARG;
+  if (!h->has_cl) return GV_ERR_TF;
+  GV_TRY
+  int rc = use_device(h);
+  if (rc) return rc;
+  const size_t n = h->n;
+  h->ground_mask.assign(n, 0);
+  if (coeff) coeff[0] = coeff[1] = coeff[2] = coeff[3] = 0.0f;
+  if (n_inliers) *n_inliers = 0;
+  if (n < 3) return GV_OK;
+  if ((rc = ensure_tbuf(h, n))) return rc;
+  // camera-frame cloud (the reference segments transformed_cloud, grid_vision_node.cpp:215-216)
+  launch_transform_cloud(h->cx, h->cy, h->cz, (uint32_t)n, h->m_cam, h->tx, h->ty, h->tz, h->stream);
+  GV_HIP(hipGetLastError());
+  std::vector<float> px(n), py(n), pz(n);
+  GV_HIP(hipMemcpyAsync(px.data(), h->tx, n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+  GV_HIP(hipMemcpyAsync(py.data(), h->ty, n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+  GV_HIP(hipMemcpyAsync(pz.data(), h->tz, n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+  GV_HIP(hipStreamSynchronize(h->stream));
+  // hypotheses: three counter-based draws each (specified by outcome, not PCL's RNG)
+  std::vector<float4> planes;
+  std::vector<int32_t> hyp_of;
+  for (int32_t t = 0; t < iterations; ++t) {
+    size_t id[3];
+    for (int k = 0; k < 3; ++k) id[k] = (size_t)(host::splitmix64(seed + 3ull * (uint64_t)t + (uint64_t)k) % (uint64_t)n);
+    const float p0[3] = {px[id[0]], py[id[0]], pz[id[0]]}, p1[3] = {px[id[1]], py[id[1]], pz[id[1]]},
+                p2[3] = {px[id[2]], py[id[2]], pz[id[2]]};
+    float c[4];
+    if (!host::plane_from_sample(p0, p1, p2, c)) continue;
+    planes.push_back(make_float4(c[0], c[1], c[2], c[3]));
+    hyp_of.push_back(t);
+  }
+  if (planes.empty()) return GV_OK;
+  const size_t nh = planes.size();
+  if (nh > h->planes_cap) {
+    if (h->d_planes) { GV_HIP(hipFree(h->d_planes)); h->d_planes = nullptr; }
+    if (h->d_plane_counts) { GV_HIP(hipFree(h->d_plane_counts)); h->d_plane_counts = nullptr; }
+    h->planes_cap = 0;
+    GV_HIP(hipMalloc(reinterpret_cast<void **>(&h->d_planes), nh * sizeof(float4)));
+    GV_HIP(hipMalloc(reinterpret_cast<void **>(&h->d_plane_counts), nh * sizeof(unsigned)));
+    h->planes_cap = nh;
+  }
+  if ((rc = grow(h, h->d_ground, h->ground_cap, n))) return rc;
+  GV_HIP(hipMemcpyAsync(h->d_planes, planes.data(), nh * sizeof(float4), hipMemcpyHostToDevice, h->stream));
+  GV_HIP(hipMemsetAsync(h->d_plane_counts, 0, nh * sizeof(unsigned), h->stream));
+  launch_plane_count(h->tx, h->ty, h->tz, (uint32_t)n, h->d_planes, (int)nh, threshold, h->d_plane_counts, h->stream);
+  GV_HIP(hipGetLastError());
+  std::vector<unsigned> counts(nh);
+  GV_HIP(hipMemcpyAsync(counts.data(), h->d_plane_counts, nh * sizeof(unsigned), hipMemcpyDeviceToHost, h->stream));
+  GV_HIP(hipStreamSynchronize(h->stream));
+  size_t best = 0;
+  unsigned bestc = 0;
+  for (size_t k = 0; k < nh; ++k)
+    if (counts[k] > bestc) { bestc = counts[k]; best = k; }   // first wins ties
+  if (bestc == 0) return GV_OK;   // "Could not estimate a planar model" (:122-126)
+  const float c0[4] = {planes[best].x, planes[best].y, planes[best].z, planes[best].w};
+  float refined[4];
+  host::refine_plane(px.data(), py.data(), pz.data(), n, c0, threshold, refined);   // optimizeCoefficients
+  launch_plane_mask(h->tx, h->ty, h->tz, (uint32_t)n, make_float4(refined[0], refined[1], refined[2], refined[3]),
+                    threshold, h->d_ground, h->stream);
+  GV_HIP(hipGetLastError());
+  GV_HIP(hipMemcpyAsync(h->ground_mask.data(), h->d_ground, n, hipMemcpyDeviceToHost, h->stream));
+  GV_HIP(hipStreamSynchronize(h->stream));
+  int64_t m = 0;
+  for (size_t i = 0; i < n; ++i) m += h->ground_mask[i];
+  if (is_ground) std::memcpy(is_ground, h->ground_mask.data(), n);
+  if (coeff) std::memcpy(coeff, refined, sizeof(refined));
+  if (n_inliers) *n_inliers = m;
+  return GV_OK;
+  GV_CATCH
+}
+
+int gv_compute_bbox_pose_ground_removed(gv_handle h, const gv_bbox *bboxes, int32_t nb, gv_lshape_pose *poses_out,
+                                        uint8_t *valid, int32_t *n_poses_or_fail)
+{
+  if (!h) return GV_ERR_BAD_ARG;
+  // computeBBoxPose (cloud_detections.cpp:300-321): segmentGroundPlane -> extractCloudPerBBox -> PCA
+  int64_t m = 0;
+  int rc = gv_segment_ground_plane(h, 0.04, 50, 12345ull, nullptr, nullptr, &m);
+  if (rc) return rc;
+  if (n_poses_or_fail) *n_poses_or_fail = 0;
+  if (m == 0 || (size_t)m == h->n) {   // empty segmented cloud -> the reference returns {} (:307-309)
+    for (int32_t b = 0; b < nb; ++b) valid[b] = 0;
+    if (n_poses_or_fail) *n_poses_or_fail = -1;
+    return GV_OK;
+  }
+  rc = compute_bbox_pose_impl(h, bboxes, nb, poses_out, valid, h->ground_mask.data());
+  if (rc) return rc;
+  if (n_poses_or_fail)
+    for (int32_t b = 0; b < nb; ++b) *n_poses_or_fail += valid[b];
+  return GV_OK;
 }
 
 int gv_comm_unique_id(uint8_t id_out[128])

@@ -133,6 +133,10 @@ void launch_knn(const float *pu, const float *pv, const float *pd, uint32_t n, c
 void launch_radius_count(const float *x, const float *y, const float *z, const int32_t *seg_of,
                          const int32_t *seg_start, int32_t n, float r2f, int32_t min_pts, uint8_t *keep,
                          hipStream_t s);
+void launch_plane_count(const float *x, const float *y, const float *z, uint32_t n, const float4 *planes, int nh,
+                        double thr, unsigned *counts, hipStream_t s);
+void launch_plane_mask(const float *x, const float *y, const float *z, uint32_t n, float4 pl, double thr,
+                       uint8_t *mask, hipStream_t s);
 void launch_gather_xyz(const float *x, const float *y, const float *z, const int32_t *idx, int32_t n, float *ox,
                        float *oy, float *oz, hipStream_t s);
 

@@ -56,7 +56,7 @@ int main()
     occ_grid.updateMap(bboxes_pose);
 
     // dynamic branch, PCA path (:210-231)
-    std::vector<LShapePose> pca_pose = cloud_detections::computeBBoxPose(ctx, bboxes);
+    std::vector<LShapePose> pca_pose = cloud_detections::computeBBoxPose(ctx, bboxes, /*remove_ground=*/false);
     vision_orient.transformLShapeObjects(pca_pose);
     occ_grid.updateMap(pca_pose);
     occ_grid.updateMap();

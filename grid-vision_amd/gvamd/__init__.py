@@ -32,7 +32,8 @@ ABI_SYMBOLS = [
     "gv_create", "gv_destroy", "gv_last_error", "gv_abi_version", "gv_grid_geometry", "gv_reset",
     "gv_set_transforms", "gv_cloud_upload_xyz", "gv_cloud_upload_pointcloud2",
     "gv_transform_lidar_to_camera", "gv_extract_cloud_per_bbox", "gv_compute_depth_for_bboxes",
-    "gv_convert_pixels_to_3d", "gv_compute_bbox_pose", "gv_vision_post_process",
+    "gv_convert_pixels_to_3d", "gv_compute_bbox_pose", "gv_segment_ground_plane",
+    "gv_compute_bbox_pose_ground_removed", "gv_vision_post_process",
     "gv_transform_lshape_objects", "gv_extract_bboxes", "gv_filter_bboxes", "gv_get_intrinsics",
     "gv_update_map", "gv_update_map_poses", "gv_update_map_points", "gv_to_occupancy_grid",
     "gv_get_log_odds", "gv_get_occupancy", "gv_set_log_odds", "gv_frame_set_detections",
@@ -227,6 +228,24 @@ class GridVisionHIP:
         self._ck(self._lib.gv_compute_bbox_pose(self._h, _ptr(b), C.c_int32(len(b)), _ptr(poses), _ptr(valid)),
                  "compute_bbox_pose")
         return poses[:len(b)], valid[:len(b)]
+
+    def segment_ground_plane(self, threshold=0.04, iterations=50, seed=12345):
+        mask = np.zeros(max(self.n, 1), np.uint8)
+        coeff = np.zeros(4, np.float32)
+        m = C.c_int64(0)
+        self._ck(self._lib.gv_segment_ground_plane(self._h, C.c_double(threshold), C.c_int32(iterations),
+                                                   C.c_uint64(seed), _ptr(mask), _ptr(coeff), C.byref(m)),
+                 "segment_ground_plane")
+        return m.value, mask[:self.n], coeff
+
+    def compute_bbox_pose_ground_removed(self, bboxes):
+        b = np.ascontiguousarray(bboxes, dtype=BBOX_DTYPE)
+        poses = np.zeros(max(len(b), 1), dtype=LSHAPE_DTYPE)
+        valid = np.zeros(max(len(b), 1), np.uint8)
+        npz = C.c_int32(0)
+        self._ck(self._lib.gv_compute_bbox_pose_ground_removed(self._h, _ptr(b), C.c_int32(len(b)), _ptr(poses),
+                                                               _ptr(valid), C.byref(npz)), "compute_bbox_pose_gr")
+        return poses[:len(b)], valid[:len(b)], npz.value
 
     def vision_post_process(self, orient, conf, dims, bboxes):
         o, c, d = _f32(orient), _f32(conf), _f32(dims)

@@ -174,14 +174,35 @@ inline std::vector<int32_t> extractCloudPerBBox(GridVisionContext &ctx, const st
   return ids;
 }
 
-// computeBBoxPose  cloud_detections.hpp:50-52 (without segmentGroundPlane)
-inline std::vector<LShapePose> computeBBoxPose(GridVisionContext &ctx, const std::vector<BoundingBox> &bboxes)
+// segmentGroundPlane  cloud_detections.hpp:40-41: mask of the ground points of the camera-frame cloud
+// (empty vector where the reference returns an empty cloud: no plane found)
+inline std::vector<uint8_t> segmentGroundPlane(GridVisionContext &ctx, float coeff[4] = nullptr)
+{
+  std::vector<uint8_t> mask(ctx.cloudSize());
+  int64_t m = 0;
+  gv::check(gv_segment_ground_plane(ctx.handle(), 0.04, 50, 12345ull, mask.data(), coeff, &m), ctx.handle(),
+            "gv_segment_ground_plane");
+  if (m == 0) mask.clear();
+  return mask;
+}
+
+// computeBBoxPose  cloud_detections.hpp:50-52.  remove_ground = true is the reference's flow
+// (segmentGroundPlane first, :306-314); false skips the RANSAC step.
+inline std::vector<LShapePose> computeBBoxPose(GridVisionContext &ctx, const std::vector<BoundingBox> &bboxes,
+                                               bool remove_ground = true)
 {
   std::vector<LShapePose> all(bboxes.size()), out;
   std::vector<uint8_t> valid(bboxes.size());
-  if (!bboxes.empty())
-    gv::check(gv_compute_bbox_pose(ctx.handle(), bboxes.data(), (int32_t)bboxes.size(), all.data(), valid.data()),
-              ctx.handle(), "gv_compute_bbox_pose");
+  if (!bboxes.empty()) {
+    if (remove_ground) {
+      int32_t np = 0;
+      gv::check(gv_compute_bbox_pose_ground_removed(ctx.handle(), bboxes.data(), (int32_t)bboxes.size(), all.data(),
+                                                    valid.data(), &np), ctx.handle(), "gv_compute_bbox_pose_ground_removed");
+      if (np < 0) return out;   // empty segmented cloud: the reference returns {} (:307-309)
+    } else
+      gv::check(gv_compute_bbox_pose(ctx.handle(), bboxes.data(), (int32_t)bboxes.size(), all.data(), valid.data()),
+                ctx.handle(), "gv_compute_bbox_pose");
+  }
   for (size_t i = 0; i < all.size(); ++i)
     if (valid[i]) out.push_back(all[i]);   // the reference appends only non-empty clouds (:174-181)
   return out;

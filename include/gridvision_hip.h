@@ -147,6 +147,22 @@ int gv_convert_pixels_to_3d(gv_handle h, const gv_bbox *bboxes, const float *dep
 int gv_compute_bbox_pose(gv_handle h, const gv_bbox *bboxes, int32_t nb,
                          gv_lshape_pose *poses_out, uint8_t *valid);
 
+/* Replaces cloud_detections::segmentGroundPlane (cloud_detections.hpp:40-41,
+ * src/cloud_detections.cpp:105-138: pcl SACSegmentation, plane, RANSAC, threshold 0.04,
+ * optimised coefficients) on the camera-frame view of the resident cloud.  PCL's sample
+ * sequence cannot be reproduced, so this is specified BY OUTCOME:
+ * `iterations` hypotheses from a counter-based RNG (seed), inliers |n.p+d| < threshold
+ * counted on the device, least-squares refinement, inliers re-selected.  is_ground
+ * (optional, n bytes) marks the plane's points; *n_inliers == 0 means "could not
+ * estimate a planar model" (the reference then returns an empty cloud, :122-126). */
+int gv_segment_ground_plane(gv_handle h, double threshold, int32_t iterations, uint64_t seed,
+                            uint8_t *is_ground, float coeff[4], int64_t *n_inliers);
+/* Replaces cloud_detections::computeBBoxPose in full (src/cloud_detections.cpp:300-321):
+ * segmentGroundPlane(0.04, 50 iterations) -> extractCloudPerBBox -> bboxPoseEstimation.
+ * *n_poses = number of valid poses, or -1 where the reference returns {} (empty segmented cloud). */
+int gv_compute_bbox_pose_ground_removed(gv_handle h, const gv_bbox *bboxes, int32_t nb,
+                                        gv_lshape_pose *poses_out, uint8_t *valid, int32_t *n_poses);
+
 /* ---------------------------------------------------- vision_orientation -- */
 /* Replaces VisionOrientation::postProcessOutputs (+ computeAlpha,
  * computeThetaRay, calcLocation; vision_orientation.hpp:90-98,

@@ -170,6 +170,16 @@ void gvo_radius_outlier(const float *x, const float *y, const float *z, size_t n
  * cloud (already filtered).  Returns 0 when the cloud is empty (:174-175). */
 int gvo_pca_bbox(const float *x, const float *y, const float *z, size_t n, gvo_lshape *out);
 
+/* segmentGroundPlane :105-138, specified BY OUTCOME (oracle/ransac.c): counter-based RANSAC
+ * with `iters` hypotheses, fp64 least-squares refinement; inlier[i] = 1 for ground points.
+ * Returns the inlier count (0 = "could not estimate a planar model"). */
+size_t gvo_segment_ground_plane(const float *x, const float *y, const float *z, size_t n, double thr,
+                                int32_t iters, uint64_t seed, uint8_t *inlier, float coeff_out[4]);
+int gvo_plane_from_sample(const float p0[3], const float p1[3], const float p2[3], float coeff[4]);
+void gvo_smallest_eigenvector3(const double cov[6], double v[3]);
+size_t gvo_refine_plane(const float *x, const float *y, const float *z, size_t n, const float coeff[4],
+                        double thr, float refined[4]);
+
 /* ---------------------------------------------------- vision_orientation -- */
 void  gvo_generate_bins(int32_t bins, float *out);                       /* :241-258 */
 float gvo_compute_alpha(const float orient[4], int32_t argmax, const float *bins); /* :260-275 */

@@ -1,0 +1,156 @@
+/*
+ * oracle/ransac.c -- CPU ORACLE (test infrastructure; see gv_oracle.h).
+ * cloud_detections::segmentGroundPlane  src/cloud_detections.cpp:105-138:
+ * pcl::SACSegmentation, SACMODEL_PLANE, SAC_RANSAC, distance threshold 0.04,
+ * optimizeCoefficients = true, inliers removed.
+ *
+ * PARITY UNPINNED and NOT bit-reproducible against PCL: PCL draws its samples from
+ * boost::mt19937 (and stops adaptively); SURVEY 8(f)-2 specifies this step BY OUTCOME.
+ * This file defines the variant the HIP path implements:
+ *   - `iters` hypotheses (PCL default max_iterations_ = 50), sample t draws three point
+ *     indices from the counter-based splitmix64 stream seed + 3t + {0,1,2} (mod n);
+ *   - plane through the 3 points and the collinearity test as PCL's
+ *     SampleConsensusModelPlane::computeModelCoefficients / isSampleGood (fp32);
+ *   - inlier iff |n.p + d| < threshold (fp32 distance vs fp64 threshold), best = most
+ *     inliers, first wins ties;
+ *   - refinement: centroid + covariance of the inliers in fp64, cloud order; normal =
+ *     eigenvector of the smallest eigenvalue (cyclic Jacobi), d = -n.centroid; the final
+ *     inlier set is re-selected with the refined coefficients.
+ */
+#include "gv_oracle.h"
+
+#include <math.h>
+#include <string.h>
+
+static uint64_t sm64(uint64_t z)
+{
+  z += 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+
+/* returns 1 and the fp32 plane (a,b,c,d) when the sample is usable */
+int gvo_plane_from_sample(const float p0[3], const float p1[3], const float p2[3], float coeff[4])
+{
+  for (int k = 0; k < 3; ++k)
+    if (!isfinite(p0[k]) || !isfinite(p1[k]) || !isfinite(p2[k])) return 0;
+  const float a[3] = {p1[0] - p0[0], p1[1] - p0[1], p1[2] - p0[2]};
+  const float b[3] = {p2[0] - p0[0], p2[1] - p0[1], p2[2] - p0[2]};
+  /* isSampleGood: dy1dy2 = p1p0 / p2p0 elementwise; good iff not all three ratios equal */
+  const float r0 = a[0] / b[0], r1 = a[1] / b[1], r2 = a[2] / b[2];
+  if (!((r0 != r1) || (r2 != r1))) return 0;
+  float n[3] = {a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]};
+  const float len = sqrtf((n[0] * n[0] + n[1] * n[1]) + n[2] * n[2]);
+  if (!(len > 0.0f) || !isfinite(len)) return 0;
+  n[0] /= len; n[1] /= len; n[2] /= len;
+  coeff[0] = n[0]; coeff[1] = n[1]; coeff[2] = n[2];
+  coeff[3] = -1.0f * (((n[0] * p0[0]) + n[1] * p0[1]) + n[2] * p0[2]);
+  return 1;
+}
+
+static inline int is_inlier(const float c[4], float x, float y, float z, double thr)
+{
+  const float d = (((c[0] * x) + c[1] * y) + c[2] * z) + c[3];
+  return (double)fabsf(d) < thr;   /* NaN -> 0 */
+}
+
+/* cyclic Jacobi on a symmetric 3x3 (fp64); returns the unit eigenvector of the smallest
+ * eigenvalue, sign fixed so that its largest-magnitude component is positive */
+void gvo_smallest_eigenvector3(const double cov[6], double v[3])
+{
+  double a[3][3] = {{cov[0], cov[1], cov[2]}, {cov[1], cov[3], cov[4]}, {cov[2], cov[4], cov[5]}};
+  double e[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+  for (int sweep = 0; sweep < 32; ++sweep) {
+    const double off = a[0][1] * a[0][1] + a[0][2] * a[0][2] + a[1][2] * a[1][2];
+    if (off < 1e-300) break;
+    for (int p = 0; p < 2; ++p)
+      for (int q = p + 1; q < 3; ++q) {
+        if (a[p][q] == 0.0) continue;
+        const double theta = (a[q][q] - a[p][p]) / (2.0 * a[p][q]);
+        const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+        const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+        for (int k = 0; k < 3; ++k) {
+          const double akp = a[k][p], akq = a[k][q];
+          a[k][p] = c * akp - s * akq;
+          a[k][q] = s * akp + c * akq;
+        }
+        for (int k = 0; k < 3; ++k) {
+          const double apk = a[p][k], aqk = a[q][k];
+          a[p][k] = c * apk - s * aqk;
+          a[q][k] = s * apk + c * aqk;
+        }
+        for (int k = 0; k < 3; ++k) {
+          const double ekp = e[k][p], ekq = e[k][q];
+          e[k][p] = c * ekp - s * ekq;
+          e[k][q] = s * ekp + c * ekq;
+        }
+      }
+  }
+  int m = 0;
+  if (a[1][1] < a[m][m]) m = 1;
+  if (a[2][2] < a[m][m]) m = 2;
+  double n[3] = {e[0][m], e[1][m], e[2][m]};
+  const double len = sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+  int big = 0;
+  if (fabs(n[1]) > fabs(n[big])) big = 1;
+  if (fabs(n[2]) > fabs(n[big])) big = 2;
+  const double sg = (n[big] < 0) ? -1.0 / len : 1.0 / len;
+  v[0] = n[0] * sg; v[1] = n[1] * sg; v[2] = n[2] * sg;
+}
+
+/* refined plane from the inliers of `coeff` (cloud order, fp64); returns inlier count */
+size_t gvo_refine_plane(const float *x, const float *y, const float *z, size_t n, const float coeff[4],
+                        double thr, float refined[4])
+{
+  double sx = 0, sy = 0, sz = 0;
+  size_t m = 0;
+  for (size_t i = 0; i < n; ++i)
+    if (is_inlier(coeff, x[i], y[i], z[i], thr)) { sx += x[i]; sy += y[i]; sz += z[i]; ++m; }
+  memcpy(refined, coeff, 4 * sizeof(float));
+  if (m < 3) return m;
+  const double cx = sx / (double)m, cy = sy / (double)m, cz = sz / (double)m;
+  double cov[6] = {0, 0, 0, 0, 0, 0};
+  for (size_t i = 0; i < n; ++i)
+    if (is_inlier(coeff, x[i], y[i], z[i], thr)) {
+      const double dx = x[i] - cx, dy = y[i] - cy, dz = z[i] - cz;
+      cov[0] += dx * dx; cov[1] += dx * dy; cov[2] += dx * dz;
+      cov[3] += dy * dy; cov[4] += dy * dz; cov[5] += dz * dz;
+    }
+  double nv[3];
+  gvo_smallest_eigenvector3(cov, nv);
+  refined[0] = (float)nv[0]; refined[1] = (float)nv[1]; refined[2] = (float)nv[2];
+  refined[3] = (float)(-((nv[0] * cx + nv[1] * cy) + nv[2] * cz));
+  return m;
+}
+
+size_t gvo_segment_ground_plane(const float *x, const float *y, const float *z, size_t n, double thr,
+                                int32_t iters, uint64_t seed, uint8_t *inlier, float coeff_out[4])
+{
+  memset(inlier, 0, n);
+  memset(coeff_out, 0, 4 * sizeof(float));
+  if (n < 3) return 0;
+  size_t best = 0;
+  float bestc[4] = {0, 0, 0, 0};
+  for (int32_t t = 0; t < iters; ++t) {
+    size_t id[3];
+    for (int k = 0; k < 3; ++k) id[k] = (size_t)(sm64(seed + 3ull * (uint64_t)t + (uint64_t)k) % (uint64_t)n);
+    const float p0[3] = {x[id[0]], y[id[0]], z[id[0]]}, p1[3] = {x[id[1]], y[id[1]], z[id[1]]},
+                p2[3] = {x[id[2]], y[id[2]], z[id[2]]};
+    float c[4];
+    if (!gvo_plane_from_sample(p0, p1, p2, c)) continue;
+    size_t cnt = 0;
+    for (size_t i = 0; i < n; ++i) cnt += (size_t)is_inlier(c, x[i], y[i], z[i], thr);
+    if (cnt > best) { best = cnt; memcpy(bestc, c, sizeof(c)); }
+  }
+  if (best == 0) return 0;   /* :122-126 "Could not estimate a planar model" */
+  float refined[4];
+  gvo_refine_plane(x, y, z, n, bestc, thr, refined);
+  size_t m = 0;
+  for (size_t i = 0; i < n; ++i) {
+    inlier[i] = (uint8_t)is_inlier(refined, x[i], y[i], z[i], thr);
+    m += inlier[i];
+  }
+  memcpy(coeff_out, refined, 4 * sizeof(float));
+  return m;
+}

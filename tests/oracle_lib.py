@@ -59,6 +59,7 @@ def lib():
         _LIB.gvo_compute_alpha.restype = C.c_float
         _LIB.gvo_compute_theta_ray.restype = C.c_float
         _LIB.gvo_project_points.restype = C.c_size_t
+        _LIB.gvo_segment_ground_plane.restype = C.c_size_t
     return _LIB
 
 
@@ -336,3 +337,13 @@ def post_process(cam: Cam, orient, conf, dims, bboxes):
     m = lib().gvo_post_process(C.byref(cam), _p(orient, C.c_float), _p(conf, C.c_float), _p(dims, C.c_float),
                                b.ctypes.data_as(C.c_void_p), C.c_int32(len(b)), out.ctypes.data_as(C.c_void_p))
     return out[:m].copy()
+
+
+def segment_ground_plane(x, y, z, thr=0.04, iters=50, seed=12345):
+    x, y, z = f32(x), f32(y), f32(z)
+    inl = np.zeros(len(x), dtype=np.uint8)
+    coeff = np.zeros(4, dtype=np.float32)
+    m = lib().gvo_segment_ground_plane(_p(x, C.c_float), _p(y, C.c_float), _p(z, C.c_float), C.c_size_t(len(x)),
+                                       C.c_double(thr), C.c_int32(iters), C.c_uint64(seed), _p(inl, C.c_uint8),
+                                       _p(coeff, C.c_float))
+    return int(m), inl, coeff

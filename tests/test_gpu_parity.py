@@ -726,3 +726,92 @@ def test_config5_full_size(gvamd):
     h2.process_frame(gvamd.FRAME_BIN | gvamd.FRAME_RAYMARCH)
     assert np.array_equal(h2.log_odds(), h.log_odds())
     h.close(); h2.close()
+
+
+def _ground_scene(tfs, seed=3):
+    """ground plane (camera y ~ +1.6, slightly tilted, 2 cm noise) + the cluster scene on top"""
+    x, y, z, _, K, b = _cluster_scene(tfs, n_clusters=16, pts_per=400, seed=seed)
+    st = synth.Stream(seed, 33)
+    ng = 60_000
+    gx = st.uniform(ng, 1.0, 60.0)
+    gy = st.uniform(ng, -40.0, 40.0)
+    gz = (np.float32(-1.3) + np.float32(0.01) * gx + st.uniform(ng, -0.02, 0.02)).astype(np.float32)  # lidar z up
+    x = np.concatenate([x, gx]); y = np.concatenate([y, gy]); z = np.concatenate([z, gz])
+    return x, y, z, K, b
+
+
+def test_segment_ground_plane_matches_oracle(gvamd):
+    """A12 by outcome: same counter-based hypotheses, inlier counts on the device, fp64
+    refinement on the host: mask and coefficients equal the oracle's; the recovered plane is
+    the planted one."""
+    h, tfs = make_handle(gvamd, 2, perturbed=True)
+    x, y, z, K, b = _ground_scene(tfs)
+    h.upload_xyz(x, y, z)
+    m, mask, coeff = h.segment_ground_plane()
+    cx, cy, cz = ol.transform_cloud(ol.tf_to_matrix4f(tfs["cam_lidar"]), x, y, z)
+    em, emask, ecoeff = ol.segment_ground_plane(cx, cy, cz)
+    assert m == em > 50_000
+    assert np.array_equal(mask, emask)
+    assert np.array_equal(coeff, ecoeff)
+    # planted ground points are (nearly all) found, cluster points above ground are not
+    ng = 60_000
+    assert mask[-ng:].mean() > 0.9
+    assert mask[:16 * 400].mean() < 0.2
+    # no plane in pure noise of 2 points / failure path
+    h.upload_xyz(x[:2], y[:2], z[:2])
+    m2, _, _ = h.segment_ground_plane()
+    assert m2 == 0
+    h.close()
+
+
+def test_compute_bbox_pose_ground_removed(gvamd):
+    """computeBBoxPose in full: segmentGroundPlane -> extractCloudPerBBox -> radius filter -> PCA"""
+    h, tfs = make_handle(gvamd, 2, perturbed=True)
+    x, y, z, K, b = _ground_scene(tfs, seed=9)
+    h.upload_xyz(x, y, z)
+    poses, valid, npz = h.compute_bbox_pose_ground_removed(b)
+    cx, cy, cz = ol.transform_cloud(ol.tf_to_matrix4f(tfs["cam_lidar"]), x, y, z)
+    em, ground, _ = ol.segment_ground_plane(cx, cy, cz)
+    keep_pts = ground == 0
+    ids = ol.extract_cloud_per_bbox(K, cx[keep_pts], cy[keep_pts], cz[keep_pts], b, synth.IMG_W, synth.IMG_H)
+    sx, sy, sz = cx[keep_pts], cy[keep_pts], cz[keep_pts]
+    nv = 0
+    for i in range(len(b)):
+        sel = ids == i
+        kp = ol.radius_outlier(sx[sel], sy[sel], sz[sel], 0.4, 10).astype(bool)
+        ok, e = ol.pca_bbox(sx[sel][kp], sy[sel][kp], sz[sel][kp])
+        assert bool(valid[i]) == ok
+        if ok:
+            nv += 1
+            for f in ("px", "py", "pz", "length", "width"):
+                assert poses[i][f] == pytest.approx(e[f], rel=1e-6, abs=1e-6), (i, f)
+    assert nv == npz >= 8
+    h.close()
+
+
+def test_pipelined_equals_serial(gvamd, monkeypatch):
+    """two-stream frame pipelining (default) vs GV_PIPELINE=0, including the vision-orientation
+    mode and detections that change between frames."""
+    config = 2
+    outs = []
+    for pipe in ("1", "0"):
+        monkeypatch.setenv("GV_PIPELINE", pipe)
+        h, tfs = make_handle(gvamd, config, perturbed=True)
+        res = []
+        for f in range(6):
+            x, y, z, _ = synth.cloud_uniform(config, 50_000, seed_extra=f % 3)
+            h.upload_xyz(x, y, z)
+            bboxes = synth.detections(3, 20, seed_extra=f)
+            if f % 2 == 0:
+                h.set_detections(gvamd.FRAME_BIN | gvamd.FRAME_RAYMARCH | gvamd.FRAME_BBOX_TEST, bboxes=bboxes,
+                                 poses=synth.lshape_poses(config, 15, seed_extra=f))
+            else:
+                h.set_detections(gvamd.FRAME_BIN | gvamd.FRAME_RAYMARCH | gvamd.FRAME_VISION_ORIENT, bboxes=bboxes,
+                                 net=synth.network_outputs(20, seed=f))
+            for _ in range(3):
+                h.enqueue_frame()      # several frames in flight
+        h.synchronize()
+        outs.append((h.log_odds(), h.occupancy(), h.to_occupancy_grid()[0]))
+        h.close()
+    for a, b in zip(*outs):
+        assert np.array_equal(a, b)
