@@ -713,8 +713,15 @@ int gv_create(gv_handle *out, uint8_t grid_x, uint8_t grid_y, double resolution,
     if ((call) != hipSuccess) return fail(GV_ERR_HIP);       \
   } while (0)
   GV_C(hipSetDevice(h->device));
-  GV_C(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
-  GV_C(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
+  {
+    // GV_PRIO (experiment): 1 = stream A (points/bitmaps) high priority, 2 = stream B high priority
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+    const char *pe = std::getenv("GV_PRIO");
+    const int mode = pe ? std::atoi(pe) : 0;
+    GV_C(hipStreamCreateWithPriority(&h->stream, hipStreamNonBlocking, mode == 1 ? hi : (mode == 2 ? lo : 0)));
+    GV_C(hipStreamCreateWithPriority(&h->stream2, hipStreamNonBlocking, mode == 2 ? hi : (mode == 1 ? lo : 0)));
+  }
   for (int i = 0; i < 2; ++i) {
     GV_C(hipEventCreateWithFlags(&h->ev_build[i], hipEventDisableTiming));
     GV_C(hipEventCreateWithFlags(&h->ev_fin[i], hipEventDisableTiming));
