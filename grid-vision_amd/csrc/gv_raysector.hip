@@ -174,8 +174,8 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
   unsigned short *sfx = reinterpret_cast<unsigned short *>(smem + L.sfx);   // max from m to the block end
   unsigned *raw = reinterpret_cast<unsigned *>(smem + L.raw);               // staging: packed ends, scan order
   unsigned short *bkt = reinterpret_cast<unsigned short *>(smem + L.bkt);   // staging: their slope buckets
-  __shared__ unsigned s_wsum[NT / 64], s_blkmax[8], s_blkpfx[9], s_blksfx[9], s_lvlmin[16], s_nlong;
-  __shared__ int s_T;
+  __shared__ unsigned s_wsum[NT / 64], s_wsum2[NT / 64], s_blkmax[8], s_blkpfx[9], s_blksfx[9], s_lvlmin[16], s_nlong;
+  __shared__ unsigned s_lm[16];
   __shared__ unsigned long long s_wvis[NT / 64];
 
   // diagnostic build only (GV_SECTOR_DBG=1): thread 0 stamps the shader clock at phase
@@ -188,6 +188,9 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
   stamp();
   for (int i = tid; i <= oc.imax; i += NT) marks[i] = 0;
   if (tid < NT / 64) s_wvis[tid] = 0;
+  for (int m = tid; m < M; m += NT) { cnt[m] = 0; bmax32[m] = 0; }
+  if (tid < 16) s_lvlmin[tid] = 0xFFFFFFFFu;
+  if (tid == 0) s_nlong = 0;
   __syncthreads();
   stamp();   // 1: init done
   if (A.ablate & 8) return;    // timing experiment: launch + init only
@@ -281,19 +284,22 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
       ends[c] = vh | vcs[c];   // bit t <-> b = blo + t (positive minor side) or bhi - t
     }
   }
-  // total number of ends: one wavefront reduction + one LDS slot per wavefront
-  {
-    unsigned mine = 0;
+  // ends per thread -> inclusive prefix inside the wavefront, wavefront totals in LDS: gives
+  // the total AND (fast path) every thread's slot range without another barrier
+  unsigned scan_mine = 0;
 #pragma unroll
-    for (int c = 0; c < CH; ++c) mine += (unsigned)__popc(ends[c]);
-    const unsigned r = wave_sum(mine);
-    if (lane == 0) s_wsum[wave] = r;
+  for (int c = 0; c < CH; ++c) scan_mine += (unsigned)__popc(ends[c]);
+  unsigned scan_incl = scan_mine;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const unsigned v = __shfl_up(scan_incl, off);
+    if (lane >= off) scan_incl += v;
   }
+  if (lane == 63) s_wsum[wave] = scan_incl;
   __syncthreads();
   int total = 0;
 #pragma unroll
   for (int wv = 0; wv < NT / 64; ++wv) total += (int)s_wsum[wv];
-  __syncthreads();   // s_wsum is reused by the groups below
   stamp();   // 2: scan done
   if (A.ablate & 16) return;   // timing experiment: + scan
   if (total == 0) {
@@ -306,24 +312,31 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
   // highest level of aligned bucket groups a column of this wedge can ask for
   const int tqmax = (2 * oc.imax + S - 1) >> A.log2s;
   const int lv_max = (tqmax <= 1) ? 0 : 32 - __clz(tqmax - 1);
-  auto process_group = [&](unsigned rowmask, int wsel) {
+  auto process_group = [&](unsigned rowmask, int wsel, bool first) {
     const bool mine_w = (wsel < 0) || (wave == wsel);
-    for (int m = tid; m < M; m += NT) { cnt[m] = 0; bmax32[m] = 0; }
-    if (tid < 16) s_lvlmin[tid] = 0xFFFFFFFFu;
-    __syncthreads();
-    // append this group's ends to the dense staging list: slots by wavefront prefix sums
-    unsigned mycnt = 0;
+    unsigned mycnt, incl;
+    if (first) {   // whole wedge in one group: the scan already produced the prefix and s_wsum
+      mycnt = scan_mine;
+      incl = scan_incl;
+    } else {
+      __syncthreads();   // previous group fully done with the tables
+      for (int m = tid; m < M; m += NT) { cnt[m] = 0; bmax32[m] = 0; }
+      if (tid < 16) s_lvlmin[tid] = 0xFFFFFFFFu;
+      if (tid == 0) s_nlong = 0;
+      mycnt = 0;
 #pragma unroll
-    for (int c = 0; c < CH; ++c)
-      if (((rowmask >> c) & 1u) && mine_w) mycnt += (unsigned)__popc(ends[c]);
-    unsigned incl = mycnt;
+      for (int c = 0; c < CH; ++c)
+        if (((rowmask >> c) & 1u) && mine_w) mycnt += (unsigned)__popc(ends[c]);
+      incl = mycnt;
 #pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      const unsigned v = __shfl_up(incl, off);
-      if (lane >= off) incl += v;
+      for (int off = 1; off < 64; off <<= 1) {
+        const unsigned v = __shfl_up(incl, off);
+        if (lane >= off) incl += v;
+      }
+      if (lane == 63) s_wsum[wave] = incl;
+      __syncthreads();
     }
-    if (lane == 63) s_wsum[wave] = incl;
-    __syncthreads();
+    // slots of the dense staging list from the wavefront prefix sums
     unsigned slot = incl - mycnt;
     unsigned n = 0;
 #pragma unroll
@@ -331,6 +344,7 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
       if (wv < wave) slot += s_wsum[wv];
       n += s_wsum[wv];
     }
+    // append: packed end + its slope bucket; bucket counts on the fly
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
       if (!((rowmask >> c) & 1u) || !mine_w) continue;
@@ -340,16 +354,15 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
         const int t = __ffs(e) - 1;
         e &= e - 1;
         const int b = (oc.smin > 0) ? blos[c] + t : bhis[c] - t;
+        const int bk = bucket_of_end(a, b);
         raw[slot] = pack_ab(a, b, (int)((vcs[c] >> t) & 1u));
-        bkt[slot] = (unsigned short)bucket_of_end(a, b);
+        bkt[slot] = (unsigned short)bk;
+        atomicAdd(&cnt[bk], 1u);
         ++slot;
       }
     }
     __syncthreads();
-    stamp();   // 3: staged
-    // bucket counts over the dense list
-    for (unsigned k = tid; k < n; k += NT) atomicAdd(&cnt[bkt[k]], 1u);
-    __syncthreads();
+    stamp();   // 3: staged + counted
     // exclusive prefix over the M bucket counts (thread m owns bucket m; M <= NT)
     {
       const unsigned bc = (tid < M) ? cnt[tid] : 0u;
@@ -359,10 +372,10 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
         const unsigned v = __shfl_up(in2, off);
         if (lane >= off) in2 += v;
       }
-      if (lane == 63) s_wsum[wave] = in2;
+      if (lane == 63) s_wsum2[wave] = in2;
       __syncthreads();
       unsigned base = 0;
-      for (int wv = 0; wv < wave; ++wv) base += s_wsum[wv];
+      for (int wv = 0; wv < wave; ++wv) base += s_wsum2[wv];
       if (tid < M) {
         bstart[tid] = base + in2 - bc;
         cnt[tid] = base + in2 - bc;   // placement cursor
@@ -429,42 +442,49 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
     // (the test is monotone in i).  Columns beyond T are crossed only by the few rays with
     // reach > T+1: when that is cheap, march exactly those rays over exactly those columns
     // instead of evaluating every cell there.
-    if (tid == 0) {
-      int Tt = 0;
+    // per-level minima in parallel (thread Lv), block prefix/suffix tables (threads 32, 33),
+    // then a short serial combine by thread 0
+    if (tid <= lv_max && tid <= LM) {
+      const int Lv = tid;
+      unsigned lm;
+      if (LM - Lv <= 6) lm = s_lvlmin[Lv];
+      else {
+        const int gb = 1 << (LM - Lv - 6);
+        lm = 0xFFFFFFFFu;
+        for (int g0 = 0; g0 < NB; g0 += gb) {
+          unsigned gm = 0;
+          for (int bk = g0; bk < g0 + gb; ++bk) gm = max(gm, s_blkmax[bk]);
+          lm = min(lm, gm);
+        }
+      }
+      s_lm[Lv] = lm;
+    }
+    if (tid == 32) {   // exclusive prefix maxima over the 64-bucket blocks (edge-cell queries)
+      unsigned run = 0;
+      for (int bk = 0; bk < NB; ++bk) { s_blkpfx[bk] = run; run = max(run, s_blkmax[bk]); }
+    }
+    if (tid == 33) {
+      unsigned run = 0;
+      for (int bk = NB - 1; bk >= 0; --bk) { s_blksfx[bk] = run; run = max(run, s_blkmax[bk]); }
+    }
+    __syncthreads();
+    int T = 0;
+    {
       bool open = true;
       for (int Lv = 0; Lv <= lv_max && Lv <= LM && open; ++Lv) {
         // columns whose cell width asks for level Lv: ceil(2i/S) in (2^(Lv-1), 2^Lv]
         const int hiL = min(oc.imax, (Lv == 0) ? (S >> 1) : (int)(((long long)S << Lv) >> 1));
-        unsigned lm;
-        if (LM - Lv <= 6) lm = s_lvlmin[Lv];
-        else {
-          const int gb = 1 << (LM - Lv - 6);
-          lm = 0xFFFFFFFFu;
-          for (int g0 = 0; g0 < NB; g0 += gb) {
-            unsigned gm = 0;
-            for (int bk = g0; bk < g0 + gb; ++bk) gm = max(gm, s_blkmax[bk]);
-            lm = min(lm, gm);
-          }
-        }
-        if (lm > (unsigned)hiL) Tt = hiL;
-        else { Tt = max(Tt, min(hiL, (int)lm - 1)); open = false; }
+        const unsigned lm = s_lm[Lv];
+        if (lm > (unsigned)hiL) T = hiL;
+        else { T = max(T, min(hiL, (int)lm - 1)); open = false; }
       }
-      if (A.ablate & 64) Tt = 0;
-      s_T = Tt;
-      // exclusive prefix / suffix maxima over the 64-bucket blocks (edge-cell queries)
-      unsigned run = 0;
-      for (int bk = 0; bk < NB; ++bk) { s_blkpfx[bk] = run; run = max(run, s_blkmax[bk]); }
-      run = 0;
-      for (int bk = NB - 1; bk >= 0; --bk) { s_blksfx[bk] = run; run = max(run, s_blkmax[bk]); }
+      if (A.ablate & 64) T = 0;
     }
-    __syncthreads();
-    const int T = s_T;
+    stamp();   // 7: threshold
     // long rays (reach > T+1) -> compact list in the (now free) cursor array `cnt`
     bool march_tail = false;
     if (T < oc.imax && !(A.ablate & 256)) {
-      if (tid == 0) s_nlong = 0;
       unsigned st = 0;
-      __syncthreads();
       for (unsigned k0 = 0; k0 < n; k0 += NT) {
         const unsigned k = k0 + tid;
         unsigned p = 0;
@@ -492,6 +512,7 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
       for (int wv = 0; wv < NT / 64; ++wv) tail_steps += s_wsum[wv];
       const unsigned nlong = s_nlong;
       march_tail = (nlong <= (unsigned)M) && (tail_steps <= 64u * NT);
+      stamp();   // 8: long rays compacted
       if (march_tail) {
         // one ray per wavefront, lanes over consecutive columns: distinct LDS words
         for (unsigned r0 = wave; r0 < nlong; r0 += NT / 64) {
@@ -512,6 +533,8 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
         }
       }
     }
+    if (A.dbg) __syncthreads();
+    stamp();   // 9: tail marched (barrier only in the diagnostic build)
     // gather: one lane per column of the wedge
     const int gather_hi = march_tail ? T : oc.imax;
     for (int i = tid; i <= ((A.ablate & 2) ? -1 : gather_hi); i += NT) {
@@ -603,12 +626,12 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
       if (mask) marks[i] |= mask;
     }
     __syncthreads();
-    stamp();   // 8: gather done
+    stamp();   // 10: gather done
   };
 
   if (A.ablate & 32) return;   // timing experiment
   if (total <= cap) {
-    process_group((1u << CH) - 1u, -1);
+    process_group((1u << CH) - 1u, -1, true);
   } else {
     // more ends than one LDS group holds: one group per row of columns, and per
     // wavefront (64 columns x <= 32 ends <= 2048 <= cap) where a row alone is too big
@@ -625,9 +648,9 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
       for (int wv = 0; wv < NT / 64; ++wv) rt += (int)s_wsum[wv];
       __syncthreads();
       if (rt == 0) continue;
-      if (rt <= cap) process_group(1u << c, -1);
+      if (rt <= cap) process_group(1u << c, -1, false);
       else
-        for (int wv = 0; wv < NT / 64; ++wv) process_group(1u << c, wv);
+        for (int wv = 0; wv < NT / 64; ++wv) process_group(1u << c, wv, false);
     }
   }
 
@@ -648,7 +671,7 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
     }
   }
   __syncthreads();
-  stamp();   // 9: flush done
+  stamp();   // 11: flush done
   if (tid == 0) {
     // per-workgroup slots, summed by the host on demand: a shared counter would
     // serialise 2 x 8*S atomics on one address (~12 ns each)

@@ -24,7 +24,7 @@ nwg = 8 << log2s
 buf = np.zeros((nwg, 16), np.uint64)
 rc = h._lib.gv_debug_sector_stamps(h._h, buf.ctypes.data_as(C.c_void_p), C.c_size_t(nwg))
 assert rc == 0, rc
-names = ["init", "scan", "stage", "cnt+pfx", "place", "rmq", "gather", "flush"]  # stamps 0..8
+names = ["init", "scan", "stage", "cnt+pfx", "place", "rmq", "thresh", "compact", "march", "edge", "flush"]  # stamps 0..11
 t = buf.astype(np.int64)
 NS = len(names)
 full = t[:, NS] > 0
