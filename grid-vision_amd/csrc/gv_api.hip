@@ -44,7 +44,7 @@ struct gv_context {
   int8_t *occ_i8 = nullptr;
   // per-frame count grids
   int32_t *hits = nullptr;
-  uint8_t *miss = nullptr, *clip_end = nullptr;
+  uint8_t *miss = nullptr, *clip_end = nullptr, *hit8 = nullptr;
   uint32_t *ray_list = nullptr;
   uint32_t *ray_count = nullptr;            // [0] = number of list entries
   unsigned long long *ray_stats = nullptr;  // [0] rays, [1] visits
@@ -94,6 +94,8 @@ struct gv_context {
   int32_t nb = 0, n_poses = 0;
 
   bool counts_dirty = false;   // hits/miss/clip_end hold a kept frame
+  bool frame_counts = false;   // the frame in flight used int32 hit counts (else byte flags)
+  bool force_counts = false;   // GV_HIT_COUNTS=1: always count (A/B measurement of the atomics path)
   bool have_counts = false, have_cell_idx = false, have_bbox_id = false;
 
   // multi-GPU (one large frame sharded by points)
@@ -232,6 +234,7 @@ int clear_counts(gv_context *h)
   GV_HIP(hipMemsetAsync(h->hits, 0, G * sizeof(int32_t), h->stream));
   GV_HIP(hipMemsetAsync(h->miss, 0, G, h->stream));
   GV_HIP(hipMemsetAsync(h->clip_end, 0, G, h->stream));
+  GV_HIP(hipMemsetAsync(h->hit8, 0, G, h->stream));
   GV_HIP(hipMemsetAsync(h->missT, 0, G, h->stream));
   h->counts_dirty = false;
   return GV_OK;
@@ -333,6 +336,11 @@ int enqueue_frame(gv_context *h, bool stage_events, bool sharded = false)
   if (vision && !h->has_bc) return GV_ERR_TF;
   if (h->counts_dirty) { int rc = clear_counts(h); if (rc) return rc; }
   if (stage_events) GV_HIP(hipEventRecord(h->ev[0], h->stream));
+  // int32 hit counts only where someone reads them (KEEP_COUNTS getter, generic ray path);
+  // otherwise points mark byte flags (no atomics)
+  const bool sectors = h->tile_path && !h->force_simple;
+  const bool counts = keep_counts || !sectors || h->force_counts;
+  h->frame_counts = counts;
 
   // --- detections -> rectangles
   int32_t n_rects = 0;
@@ -362,21 +370,23 @@ int enqueue_frame(gv_context *h, bool stage_events, bool sharded = false)
     a.tile_mask = h->d_tile_mask;
     a.tiles_x = h->tiles_x; a.tiles_y = h->tiles_y; a.mask_words = h->mask_words;
     a.hits = h->hits;
+    a.hit8 = h->hit8;
     a.clip_end = h->clip_end;
     a.cell_idx = keep_cell ? h->cell_idx : nullptr;
     a.bbox_id = h->bbox_id;
     a.do_bin = do_bin; a.do_ray = do_ray; a.do_bbox = do_bbox;
+    a.counts = counts;
     launch_points(a, h->stream);
   }
   if (stage_events) GV_HIP(hipEventRecord(h->ev[kStagePoints + 1], h->stream));
 
-  const bool sectors = h->tile_path && !h->force_simple;
   if (sectors) {
     // --- end bitmaps (both orientations), sector gather, tile grid pass
     if (do_bin) {
       BitmapArgs b{};
       b.nx = h->g.nx; b.ny = h->g.ny;
       b.hits = h->hits; b.clip_end = h->clip_end;
+      b.hit8 = counts ? nullptr : h->hit8;
       b.hitN = h->hitN; b.clipN = h->clipN; b.hitT = h->hitT; b.clipT = h->clipT;
       b.nxw = h->nxw; b.nyw = h->nyw; b.nx_pad = h->nx_pad; b.ny_pad = h->ny_pad;
       b.zero_hits = !keep_counts && !sharded;   // the sharded path reduces the counts first
@@ -496,16 +506,19 @@ int enqueue_frame_pipelined(gv_context *h)
     a.tile_mask = h->d_tile_mask;
     a.tiles_x = h->tiles_x; a.tiles_y = h->tiles_y; a.mask_words = h->mask_words;
     a.hits = h->hits;
+    a.hit8 = h->hit8;
     a.clip_end = h->clip_end;
     a.cell_idx = nullptr;
     a.bbox_id = h->bbox_id;
     a.do_bin = do_bin; a.do_ray = do_ray; a.do_bbox = do_bbox;
+    a.counts = h->force_counts;
     launch_points(a, sA);
   }
   if (do_bin) {
     BitmapArgs b{};
     b.nx = h->g.nx; b.ny = h->g.ny;
     b.hits = h->hits; b.clip_end = h->clip_end;
+    b.hit8 = h->force_counts ? nullptr : h->hit8;
     b.hitN = hitN; b.clipN = clipN; b.hitT = hitT; b.clipT = clipT;
     b.nxw = h->nxw; b.nyw = h->nyw; b.nx_pad = h->nx_pad; b.ny_pad = h->ny_pad;
     b.zero_hits = true;
@@ -579,15 +592,19 @@ int sharded_tail(gv_context *h, int32_t n_rects)
   GV_HIP(hipGetLastError());
   int32_t y0, y1;
   band_rows(h, h->rank, y0, y1);
+  const bool counts = h->frame_counts;   // int32 sums only when the caller keeps the counts; else byte flags, max
   if (ny % h->world == 0) {
     const size_t cnt = G / (size_t)h->world;
-    GV_NCCL(ncclReduceScatter(h->hits, h->hits + (size_t)h->rank * cnt, cnt, ncclInt32, ncclSum, h->comm, h->stream));
+    if (counts) GV_NCCL(ncclReduceScatter(h->hits, h->hits + (size_t)h->rank * cnt, cnt, ncclInt32, ncclSum, h->comm, h->stream));
+    else GV_NCCL(ncclReduceScatter(h->hit8, h->hit8 + (size_t)h->rank * cnt, cnt, ncclUint8, ncclMax, h->comm, h->stream));
     GV_NCCL(ncclReduceScatter(h->miss, h->miss + (size_t)h->rank * cnt, cnt, ncclUint8, ncclMax, h->comm, h->stream));
   } else {   // bands are not equal sized: reduce everything everywhere
-    GV_NCCL(ncclAllReduce(h->hits, h->hits, G, ncclInt32, ncclSum, h->comm, h->stream));
+    if (counts) GV_NCCL(ncclAllReduce(h->hits, h->hits, G, ncclInt32, ncclSum, h->comm, h->stream));
+    else GV_NCCL(ncclAllReduce(h->hit8, h->hit8, G, ncclUint8, ncclMax, h->comm, h->stream));
     GV_NCCL(ncclAllReduce(h->miss, h->miss, G, ncclUint8, ncclMax, h->comm, h->stream));
   }
-  launch_band_hit_bitmap(h->hits, nx, h->ny_pad, y0, y1, h->hitN, h->stream);
+  if (counts) launch_band_hit_bitmap(h->hits, nx, h->ny_pad, y0, y1, h->hitN, h->stream);
+  else launch_band_hit_bitmap8(h->hit8, nx, h->ny_pad, y0, y1, h->hitN, h->stream);
   FinalizeTileArgs t{};
   t.g = h->g;
   t.log_odds = h->log_odds;
@@ -607,7 +624,8 @@ int sharded_tail(gv_context *h, int32_t n_rects)
   t.y_end = y1;
   launch_finalize_tiles(t, h->stream);
   GV_HIP(hipGetLastError());
-  GV_HIP(hipMemsetAsync(h->hits, 0, G * sizeof(int32_t), h->stream));
+  if (counts) GV_HIP(hipMemsetAsync(h->hits, 0, G * sizeof(int32_t), h->stream));
+  else GV_HIP(hipMemsetAsync(h->hit8, 0, G, h->stream));
   GV_HIP(hipMemsetAsync(h->miss, 0, G, h->stream));
   // packed bands to everyone: band r sits at data[G - e_r, G - b_r) (toOccupancyGrid order)
   GV_NCCL(ncclGroupStart());
@@ -733,6 +751,7 @@ int gv_create(gv_handle *out, uint8_t grid_x, uint8_t grid_y, double resolution,
   GV_C(hipMalloc(reinterpret_cast<void **>(&h->hits), G * sizeof(int32_t)));
   GV_C(hipMalloc(reinterpret_cast<void **>(&h->miss), G + 16));
   GV_C(hipMalloc(reinterpret_cast<void **>(&h->clip_end), G + 16));
+  GV_C(hipMalloc(reinterpret_cast<void **>(&h->hit8), G + 16));
   GV_C(hipMalloc(reinterpret_cast<void **>(&h->ray_list), G * sizeof(uint32_t)));
   GV_C(hipMalloc(reinterpret_cast<void **>(&h->ray_count), 4 * sizeof(uint32_t)));
   GV_C(hipMalloc(reinterpret_cast<void **>(&h->ray_stats), kMaxStatSlots * 2 * sizeof(unsigned long long)));
@@ -767,6 +786,7 @@ int gv_create(gv_handle *out, uint8_t grid_x, uint8_t grid_y, double resolution,
     const char *impl = std::getenv("GV_RAY_IMPL");
     h->force_simple = impl && std::strcmp(impl, "simple") == 0;
     if (const char *e = std::getenv("GV_PIPELINE")) h->no_pipeline = std::atoi(e) == 0;
+    if (const char *e = std::getenv("GV_HIT_COUNTS")) h->force_counts = std::atoi(e) != 0;
     if (const char *e = std::getenv("GV_LOG2S")) h->env_log2s = std::atoi(e);
     if (const char *e = std::getenv("GV_CAP")) h->env_cap = std::atoi(e);
     if (const char *e = std::getenv("GV_ABLATE")) h->env_ablate = std::atoi(e);
@@ -798,7 +818,7 @@ int gv_destroy(gv_handle h)
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   if (h->stream2) (void)hipStreamSynchronize(h->stream2);
   if (h->comm) { ncclCommDestroy(h->comm); h->comm = nullptr; }
-  void *bufs[] = {h->log_odds, h->occupancy, h->occ_i8, h->hits, h->miss, h->clip_end, h->ray_list, h->ray_count,
+  void *bufs[] = {h->log_odds, h->occupancy, h->occ_i8, h->hits, h->miss, h->clip_end, h->hit8, h->ray_list, h->ray_count,
                   h->ray_stats, h->scratch_i32, h->d_dbg, h->hitN2, h->clipN2, h->hitT2, h->clipT2, h->d_rects2, h->missT, h->hitN, h->clipN, h->hitT, h->clipT, h->cx, h->cy, h->cz, h->tx, h->ty, h->tz, h->raw, h->cell_idx,
                   h->bbox_id, h->d_bboxes, h->d_poses, h->d_rects, h->d_orient, h->d_conf, h->d_dims, h->d_vout,
                   h->d_pts, h->d_bbox_f, h->d_tile_mask, h->knn_partial, h->d_depths, h->d_knn_d2, h->d_idx, h->d_segof,

@@ -84,20 +84,25 @@ __device__ __forceinline__ double krow(const double *k, int r, double x, double 
 //   X2  ray end of out-of-map points (clip_end[cell] = 1)
 //   A1+A5 camera<-lidar transform, pinhole projection, first-match bbox id
 //       (src/cloud_detections.cpp:250-298)
-// Hit counting: points of one workgroup that fall into the same cell (the cells next to the
-// sensor collect hundreds of hits per frame) are combined in an LDS direct-mapped cache
-// (cell -> count) and flushed with ONE global atomicAdd per cached cell; a cell that loses
-// its slot to another cell goes straight to the global atomic.  Integer adds: the grid is
-// the same whatever the interleaving.
+// Hit marking (COUNTS == false, the production frame): the X2 update rule only asks
+// "hits > 0", so a point stores the byte 1 into hit8[cell] -- an idempotent plain store,
+// no atomics; every writer stores the same value, the L2s merge byte-masked lines.
+// Hit counting (COUNTS == true, GV_FRAME_KEEP_COUNTS / generic path): points of one
+// workgroup that fall into the same cell (the cells next to the sensor collect hundreds of
+// hits per frame) are combined in an LDS direct-mapped cache (cell -> count) and flushed
+// with ONE global atomicAdd per cached cell; a cell that loses its slot to another cell
+// goes straight to the global atomic.  Integer adds: the grid is the same whatever the
+// interleaving.
 constexpr int kHitSlots = 4096;
 constexpr unsigned kHitEmpty = 0xFFFFFFFFu;
 
-template <bool BIN, bool RAY, bool BBOX, bool KEEPCELL>
-__global__ void __launch_bounds__(1024) k_points(PointsArgs a)
+template <bool BIN, bool RAY, bool BBOX, bool KEEPCELL, bool COUNTS>
+__global__ void __launch_bounds__(COUNTS ? 1024 : 256) k_points(PointsArgs a)
 {
-  __shared__ unsigned s_key[BIN ? kHitSlots : 1];
-  __shared__ unsigned s_cnt[BIN ? kHitSlots : 1];
-  if (BIN) {
+  constexpr bool CACHE = BIN && COUNTS;
+  __shared__ unsigned s_key[CACHE ? kHitSlots : 1];
+  __shared__ unsigned s_cnt[CACHE ? kHitSlots : 1];
+  if (CACHE) {
     for (int k = threadIdx.x; k < kHitSlots; k += blockDim.x) { s_key[k] = kHitEmpty; s_cnt[k] = 0; }
     __syncthreads();
   }
@@ -112,10 +117,14 @@ __global__ void __launch_bounds__(1024) k_points(PointsArgs a)
         int ix, iy;
         if (get_index(a.g, (double)bx, (double)by, ix, iy)) {
           cell = iy * a.g.nx + ix;
-          const unsigned slot = ((unsigned)cell * 2654435761u) >> 20;   // 12 bits
-          const unsigned old = atomicCAS(&s_key[slot], kHitEmpty, (unsigned)cell);
-          if (old == kHitEmpty || old == (unsigned)cell) atomicAdd(&s_cnt[slot], 1u);
-          else atomicAdd(&a.hits[cell], 1);   // no-return global_atomic_add
+          if (COUNTS) {
+            const unsigned slot = ((unsigned)cell * 2654435761u) >> 20;   // 12 bits
+            const unsigned old = atomicCAS(&s_key[slot], kHitEmpty, (unsigned)cell);
+            if (old == kHitEmpty || old == (unsigned)cell) atomicAdd(&s_cnt[slot], 1u);
+            else atomicAdd(&a.hits[cell], 1);   // no-return global_atomic_add
+          } else {
+            a.hit8[cell] = 1;   // idempotent byte store
+          }
         } else if (RAY && a.org.valid) {
           int ex, ey;
           clip_ray_end(a.g, a.org, (double)bx, (double)by, ex, ey);
@@ -158,7 +167,7 @@ __global__ void __launch_bounds__(1024) k_points(PointsArgs a)
       a.bbox_id[i] = id;
     }
   }
-  if (BIN) {
+  if (CACHE) {
     __syncthreads();
     for (int k = threadIdx.x; k < kHitSlots; k += blockDim.x) {
       const unsigned key = s_key[k];
@@ -170,23 +179,27 @@ __global__ void __launch_bounds__(1024) k_points(PointsArgs a)
 void launch_points(const PointsArgs &a, hipStream_t s)
 {
   if (a.n == 0) return;
-  // binning: 8192 points per 1024-thread workgroup (measured best of 2k..16k) so that the LDS hit cache sees the
-  // duplicates of the hot cells; bbox-only: plain streaming configuration
-  const uint32_t threads = a.do_bin ? 1024u : 256u;
+  // counting: 8192 points per 1024-thread workgroup (measured best of 2k..16k) so that the LDS hit cache sees the
+  // duplicates of the hot cells; byte marking / bbox-only: plain streaming configuration
+  const bool cache = a.do_bin && a.counts;
+  const uint32_t threads = cache ? 1024u : 256u;
   static const uint32_t chunk = [] { const char *e = std::getenv("GV_POINTS_CHUNK"); return (uint32_t)(e ? std::max(1024, std::atoi(e)) : 8192); }();
-  const uint32_t blocks = a.do_bin ? (uint32_t)std::min<uint64_t>(((uint64_t)a.n + chunk - 1) / chunk, (uint64_t)2048)
-                                   : (uint32_t)std::min<uint64_t>(((uint64_t)a.n + 255) / 256, (uint64_t)256 * 16);
+  static const uint32_t ppt = [] { const char *e = std::getenv("GV_POINTS_PPT"); return (uint32_t)(e ? std::max(1, std::atoi(e)) : 1); }();
+  const uint32_t blocks = cache ? (uint32_t)std::min<uint64_t>(((uint64_t)a.n + chunk - 1) / chunk, (uint64_t)2048)
+                                : (uint32_t)std::min<uint64_t>(((uint64_t)a.n + 256 * ppt - 1) / (256 * ppt), (uint64_t)1 << 20);
   const bool keep = a.cell_idx != nullptr;
-#define GV_LP(B, R, X, K) hipLaunchKernelGGL((k_points<B, R, X, K>), dim3(blocks), dim3(threads), 0, s, a)
-  if (a.do_bin && a.do_ray && a.do_bbox && keep) GV_LP(true, true, true, true);
-  else if (a.do_bin && a.do_ray && a.do_bbox) GV_LP(true, true, true, false);
-  else if (a.do_bin && a.do_ray && keep) GV_LP(true, true, false, true);
-  else if (a.do_bin && a.do_ray) GV_LP(true, true, false, false);
-  else if (a.do_bin && a.do_bbox && keep) GV_LP(true, false, true, true);
-  else if (a.do_bin && a.do_bbox) GV_LP(true, false, true, false);
-  else if (a.do_bin && keep) GV_LP(true, false, false, true);
-  else if (a.do_bin) GV_LP(true, false, false, false);
-  else if (a.do_bbox) GV_LP(false, false, true, false);
+#define GV_LP(B, R, X, K, C) hipLaunchKernelGGL((k_points<B, R, X, K, C>), dim3(blocks), dim3(threads), 0, s, a)
+#define GV_LPC(B, R, X, K) do { if (a.counts) GV_LP(B, R, X, K, true); else GV_LP(B, R, X, K, false); } while (0)
+  if (a.do_bin && a.do_ray && a.do_bbox && keep) GV_LPC(true, true, true, true);
+  else if (a.do_bin && a.do_ray && a.do_bbox) GV_LPC(true, true, true, false);
+  else if (a.do_bin && a.do_ray && keep) GV_LPC(true, true, false, true);
+  else if (a.do_bin && a.do_ray) GV_LPC(true, true, false, false);
+  else if (a.do_bin && a.do_bbox && keep) GV_LPC(true, false, true, true);
+  else if (a.do_bin && a.do_bbox) GV_LPC(true, false, true, false);
+  else if (a.do_bin && keep) GV_LPC(true, false, false, true);
+  else if (a.do_bin) GV_LPC(true, false, false, false);
+  else if (a.do_bbox) GV_LP(false, false, true, false, false);
+#undef GV_LPC
 #undef GV_LP
 }
 

@@ -22,11 +22,12 @@ struct PointsArgs {
   const float4 *bbox_f;          // (x_min, y_min, x_max, y_max) as float thresholds
   const unsigned long long *tile_mask;   // [tiles_y][tiles_x][mask_words]
   int32_t tiles_x, tiles_y, mask_words;
-  int32_t *hits;       // G
+  int32_t *hits;       // G   (counts == true: hits[cell] += 1)
+  uint8_t *hit8;       // G   (counts == false: hit8[cell] = 1, the update rule is binary per cell)
   uint8_t *clip_end;   // G
   int32_t *cell_idx;   // N or null
   int32_t *bbox_id;    // N or null
-  bool do_bin, do_ray, do_bbox;
+  bool do_bin, do_ray, do_bbox, counts;
 };
 void launch_points(const PointsArgs &a, hipStream_t s);
 
@@ -74,7 +75,8 @@ void launch_u8_to_i32(const uint8_t *in, int32_t *out, size_t n, hipStream_t s);
 // ---- sector/gather ray stage + tile grid pass (gv_raysector.hip) ----
 struct BitmapArgs {
   int32_t nx, ny;
-  int32_t *hits;          // G   (cleared here when zero_hits)
+  int32_t *hits;          // G   int32 counts (cleared here when zero_hits) -- used when hit8 == nullptr
+  uint8_t *hit8;          // G   byte flags (cleared here when zero_hits), or nullptr
   uint8_t *clip_end;      // G   (always cleared here)
   uint32_t *hitN, *clipN; // bits along x; word(x>>5, y) at (x>>5)*ny_pad + y
   uint32_t *hitT, *clipT; // bits along y; word(y>>5, x) at (y>>5)*nx_pad + x
@@ -119,6 +121,7 @@ struct FinalizeTileArgs {
 void launch_finalize_tiles(const FinalizeTileArgs &a, hipStream_t s);
 void launch_merge_miss(uint8_t *mN, uint8_t *mT, int nx, int ny, hipStream_t s);
 void launch_band_hit_bitmap(const int32_t *hits, int nx, int ny_pad, int y0, int y1, uint32_t *hitN, hipStream_t s);
+void launch_band_hit_bitmap8(const uint8_t *hit8, int nx, int ny_pad, int y0, int y1, uint32_t *hitN, hipStream_t s);
 void launch_miss_to_i32(const uint8_t *mN, const uint8_t *mT, int nx, int ny, int32_t *out, hipStream_t s);
 
 // ---- kNN depth + radius outlier counts (gv_knn_pca.hip) ----

@@ -77,9 +77,67 @@ __global__ void __launch_bounds__(256) k_build_bitmaps(BitmapArgs a)
   }
 }
 
+// Byte-flag variant (production frame): hit8/clip_end hold 0/1 bytes, nx % 4 == 0 (tile path),
+// so one lane takes 4 cells per 32-bit load: 16 lanes per tile row, 4 rows per wavefront load.
+// Nibbles go through LDS (one byte per 4 cells), then the same N / T word assembly.
+__device__ __forceinline__ unsigned nibble_of(unsigned w)   // bit k = byte k of w is non-zero
+{
+  return ((w & 0xFFu) ? 1u : 0u) | ((w & 0xFF00u) ? 2u : 0u) | ((w & 0xFF0000u) ? 4u : 0u) | ((w & 0xFF000000u) ? 8u : 0u);
+}
+__device__ __forceinline__ unsigned pack_nibbles(unsigned w)   // 4 nibble-bytes -> 16 bits
+{
+  return (w & 0xFu) | ((w >> 4) & 0xF0u) | ((w >> 8) & 0xF00u) | ((w >> 12) & 0xF000u);
+}
+
+__global__ void __launch_bounds__(256) k_build_bitmaps8(BitmapArgs a)
+{
+  __shared__ unsigned nib[2][64][4];   // [hit|clip][row][16 nibble bytes]
+  const int x0 = blockIdx.x * 64, y0 = blockIdx.y * 64;
+  const int t = threadIdx.x;
+  unsigned char *nibb = reinterpret_cast<unsigned char *>(&nib[0][0][0]);
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int idx = it * 256 + t;
+    const int yl = idx >> 4, w = idx & 15;
+    const int y = y0 + yl, x = x0 + 4 * w;
+    unsigned hw = 0, cw = 0;
+    if (x < a.nx && y < a.ny) {
+      const size_t cell = (size_t)y * a.nx + x;
+      unsigned *hp = reinterpret_cast<unsigned *>(a.hit8 + cell);
+      unsigned *cp = reinterpret_cast<unsigned *>(a.clip_end + cell);
+      hw = *hp;
+      cw = *cp;
+      if (cw) *cp = 0;
+      if (a.zero_hits && hw) *hp = 0;
+    }
+    nibb[(0 * 64 + yl) * 16 + w] = (unsigned char)nibble_of(hw);
+    nibb[(1 * 64 + yl) * 16 + w] = (unsigned char)nibble_of(cw);
+  }
+  __syncthreads();
+  {
+    // N words: thread (which, half, yl)
+    const int which = t >> 7, half = (t >> 6) & 1, yl = t & 63;
+    const unsigned lo = pack_nibbles(nib[which][yl][2 * half]), hi = pack_nibbles(nib[which][yl][2 * half + 1]);
+    unsigned *dst = which ? a.clipN : a.hitN;
+    dst[(size_t)(2 * blockIdx.x + half) * a.ny_pad + (y0 + yl)] = lo | (hi << 16);
+  }
+  {
+    // T words: thread (which, half, xl) gathers bit xl of rows 32*half .. 32*half+31
+    const int which = t >> 7, half = (t >> 6) & 1, xl = t & 63;
+    const int sh = (xl >> 2) * 8 + (xl & 3);   // bit position inside the row's 4 nibble words
+    unsigned w = 0;
+#pragma unroll
+    for (int r = 0; r < 32; ++r) w |= ((nib[which][half * 32 + r][sh >> 5] >> (sh & 31)) & 1u) << r;
+    unsigned *dst = which ? a.clipT : a.hitT;
+    dst[(size_t)(2 * blockIdx.y + half) * a.nx_pad + (x0 + xl)] = w;
+  }
+}
+
 void launch_build_bitmaps(const BitmapArgs &a, hipStream_t s)
 {
-  hipLaunchKernelGGL(k_build_bitmaps, dim3((a.nx + 63) / 64, (a.ny + 63) / 64), dim3(256), 0, s, a);
+  const dim3 grid((a.nx + 63) / 64, (a.ny + 63) / 64);
+  if (a.hit8) hipLaunchKernelGGL(k_build_bitmaps8, grid, dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(k_build_bitmaps, grid, dim3(256), 0, s, a);
 }
 
 // ------------------------------------------------------- sector gather -----
@@ -892,14 +950,15 @@ void launch_merge_miss(uint8_t *mN, uint8_t *mT, int nx, int ny, hipStream_t s)
 }
 
 // [multi-GPU] hit bitmap (N orientation only) of rows [y0, y1) from the reduced hit counts
-__global__ void __launch_bounds__(256) k_band_hit_bitmap(const int32_t *__restrict__ hits, int nx, int ny_pad, int y0,
+template <typename HT>
+__global__ void __launch_bounds__(256) k_band_hit_bitmap(const HT *__restrict__ hits, int nx, int ny_pad, int y0,
                                                          int y1, unsigned *__restrict__ hitN)
 {
   const int lane = threadIdx.x & 63;
   const int y = y0 + blockIdx.y * 4 + (threadIdx.x >> 6);
   const int x = blockIdx.x * 64 + lane;
   if (y >= y1) return;
-  const int h = (x < nx) ? hits[(size_t)y * nx + x] : 0;
+  const int h = (x < nx) ? (int)hits[(size_t)y * nx + x] : 0;
   const unsigned long long m = __ballot(h > 0);
   if (lane < 2) hitN[(size_t)(2 * blockIdx.x + lane) * ny_pad + y] = (unsigned)(m >> (32 * lane));
 }
@@ -907,8 +966,14 @@ __global__ void __launch_bounds__(256) k_band_hit_bitmap(const int32_t *__restri
 void launch_band_hit_bitmap(const int32_t *hits, int nx, int ny_pad, int y0, int y1, uint32_t *hitN, hipStream_t s)
 {
   if (y1 <= y0) return;
-  hipLaunchKernelGGL(k_band_hit_bitmap, dim3((nx + 63) / 64, (y1 - y0 + 3) / 4), dim3(256), 0, s, hits, nx, ny_pad, y0,
-                     y1, hitN);
+  hipLaunchKernelGGL(k_band_hit_bitmap<int32_t>, dim3((nx + 63) / 64, (y1 - y0 + 3) / 4), dim3(256), 0, s, hits, nx,
+                     ny_pad, y0, y1, hitN);
+}
+void launch_band_hit_bitmap8(const uint8_t *hit8, int nx, int ny_pad, int y0, int y1, uint32_t *hitN, hipStream_t s)
+{
+  if (y1 <= y0) return;
+  hipLaunchKernelGGL(k_band_hit_bitmap<uint8_t>, dim3((nx + 63) / 64, (y1 - y0 + 3) / 4), dim3(256), 0, s, hit8, nx,
+                     ny_pad, y0, y1, hitN);
 }
 
 // miss read-back: N | T^T as int32 0/1

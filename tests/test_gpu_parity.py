@@ -815,3 +815,64 @@ def test_pipelined_equals_serial(gvamd, monkeypatch):
         h.close()
     for a, b in zip(*outs):
         assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("grid,n", [((50, 20, 0.1), 60_000), ((120, 200, 0.25), 40_000), ((50, 20, 0.3), 20_000),
+                                    ((200, 200, 0.1), 1_000_000)])
+@pytest.mark.parametrize("pipeline", ["1", "0"])
+def test_production_frame_byte_flags_vs_oracle(gvamd, monkeypatch, grid, n, pipeline):
+    """The production frame (no KEEP_* flags) marks hits as byte flags instead of counting them
+    (the update rule is binary per cell): grid layers must still equal the oracle's, frame after
+    frame (the flag maps are cleared inside the frame), serial and pipelined, including a grid with
+    nx % 4 != 0 (generic kernels) and config 3 at full size."""
+    monkeypatch.setenv("GV_PIPELINE", pipeline)
+    gx, gy, res = grid
+    h = gvamd.GridVisionHIP(gx, gy, res)
+    og = ol.OGrid(gx, gy, res)
+    tfs = synth.transforms(True)
+    tfs["base_lidar"] = np.array([0.0, 0.0, 0.0, 1.0, gx / 3.0 + 1.7, -gy * 0.21, 1.8])
+    h.set_transforms(tfs["cam_lidar"], tfs["base_cam"], tfs["base_lidar"])
+    st = synth.Stream(4242, gx + n)
+    lx, ly = og.g.len_x, og.g.len_y
+    poses = np.zeros(12, dtype=synth.LSHAPE_DTYPE)
+    poses["px"] = st.uniform(12, og.g.pos_x - lx / 2, og.g.pos_x + lx / 2)
+    poses["py"] = st.uniform(12, -ly / 2, ly / 2)
+    poses["length"] = st.uniform(12, 0.5, 5.0)
+    poses["width"] = st.uniform(12, 0.5, 2.5)
+    bboxes = synth.detections(3, 10)
+    flags = gvamd.FRAME_BIN | gvamd.FRAME_RAYMARCH | gvamd.FRAME_BBOX_TEST
+    for frame in range(3):
+        x = st.uniform(n, -0.8 * lx, 0.8 * lx)
+        y = st.uniform(n, -0.8 * ly, 0.8 * ly)
+        z = st.uniform(n, -1.0, 1.0)
+        h.upload_xyz(x, y, z)
+        h.set_detections(flags, bboxes=bboxes, poses=poses)
+        h.enqueue_frame()
+        h.enqueue_frame()          # the same cloud twice: two frames in flight when pipelined
+        h.synchronize()
+        for _ in range(2):
+            _, _, _, ids, _ = oracle_frame(og, tfs, x, y, z, bboxes, poses)
+        assert np.array_equal(h.bbox_id(), ids)
+        nlo, _, _ = check_grid(h, og)
+        assert nlo == 0
+    h.close()
+
+
+def test_forced_counts_equals_byte_flags(gvamd, monkeypatch):
+    """GV_HIT_COUNTS=1 (int32 counting with atomics in the production frame) and the default
+    byte flags give the same grid."""
+    config = 2
+    x, y, z, _ = synth.cloud_lidar_like(config, 80_000)
+    outs = []
+    for force in ("1", "0"):
+        monkeypatch.setenv("GV_HIT_COUNTS", force)
+        h, tfs = make_handle(gvamd, config, perturbed=True)
+        h.upload_xyz(x, y, z)
+        h.set_detections(gvamd.FRAME_BIN | gvamd.FRAME_RAYMARCH, poses=synth.lshape_poses(config, 10))
+        for _ in range(3):
+            h.enqueue_frame()
+        h.synchronize()
+        outs.append((h.log_odds(), h.occupancy(), h.to_occupancy_grid()[0]))
+        h.close()
+    for a, b in zip(*outs):
+        assert np.array_equal(a, b)
