@@ -55,6 +55,7 @@ struct gv_context {
   int32_t nxw = 0, nyw = 0, nx_pad = 0, ny_pad = 0;
   bool tile_path = false;                   // nx % 4 == 0 and the grid fits the packed (a,b) fields
   bool force_simple = false;                // GV_RAY_IMPL=simple
+  int env_reorder = 1;                      // GV_SECTOR_REORDER=0: workgroups in natural (octant, sector) order
   int32_t last_log2s = 0, last_cap = 0;
   unsigned long long *d_dbg = nullptr;      // GV_SECTOR_DBG=1: phase stamps of the sector kernel
   size_t stat_slots = 1;                    // ray_stats slots written by the last frame
@@ -311,6 +312,19 @@ int fill_sector_args(gv_context *h, SectorArgs &sa)
   sa.log2m = h->env_log2m > 0 ? h->env_log2m : 9;
   while (sa.log2m < 9 && ((1 << sa.log2m) << sa.log2s) <= imax) ++sa.log2m;   // one boundary per bucket
   sa.marks_words = (imax + 3) & ~1;   // one word per wedge column, 0..imax
+  {
+    // octant o: xmaj = bit 2, smaj = bit 1; wedge length = distance to the map edge along the major axis
+    int len[8], ord[8];
+    for (int o = 0; o < 8; ++o) {
+      const bool xmaj = (o >> 2) & 1, pos = (o >> 1) & 1;
+      len[o] = xmaj ? (pos ? h->g.nx - 1 - h->org.cx : h->org.cx) : (pos ? h->g.ny - 1 - h->org.cy : h->org.cy);
+      ord[o] = o;
+    }
+    std::stable_sort(ord, ord + 8, [&](int a, int b) { return len[a] > len[b]; });
+    sa.oct_perm = 0;
+    for (int k = 0; k < 8; ++k) sa.oct_perm |= (uint32_t)ord[k] << (3 * k);
+    sa.reorder = h->env_reorder;
+  }
   sa.hitN = h->hitN; sa.clipN = h->clipN; sa.hitT = h->hitT; sa.clipT = h->clipT;
   sa.nxw = h->nxw; sa.nyw = h->nyw; sa.nx_pad = h->nx_pad; sa.ny_pad = h->ny_pad;
   sa.missN = h->miss;
@@ -708,6 +722,7 @@ int gv_create(gv_handle *out, uint8_t grid_x, uint8_t grid_y, double resolution,
   // grid_map::GridMap::setGeometry + setPosition  (src/occupancy_grid.cpp:10-11)
   GridParams &g = h->g;
   g.res = resolution;
+  g.inv_res = 1.0 / resolution;
   const double sx = std::round((double)grid_x / resolution), sy = std::round((double)grid_y / resolution);
   if (!(sx >= 1.0 && sy >= 1.0) || sx * sy > (double)(1 << 30)) { delete h; return GV_ERR_BAD_ARG; }
   g.nx = (int32_t)sx;
@@ -788,6 +803,7 @@ int gv_create(gv_handle *out, uint8_t grid_x, uint8_t grid_y, double resolution,
     if (const char *e = std::getenv("GV_PIPELINE")) h->no_pipeline = std::atoi(e) == 0;
     if (const char *e = std::getenv("GV_HIT_COUNTS")) h->force_counts = std::atoi(e) != 0;
     if (const char *e = std::getenv("GV_LOG2S")) h->env_log2s = std::atoi(e);
+    if (const char *e = std::getenv("GV_SECTOR_REORDER")) h->env_reorder = std::atoi(e) != 0;
     if (const char *e = std::getenv("GV_CAP")) h->env_cap = std::atoi(e);
     if (const char *e = std::getenv("GV_ABLATE")) h->env_ablate = std::atoi(e);
     if (const char *e = std::getenv("GV_SECTOR_DBG")) {

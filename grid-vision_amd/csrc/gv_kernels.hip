@@ -46,6 +46,52 @@ __device__ __forceinline__ bool get_index(const GridParams &g, double x, double 
   return true;
 }
 
+// Same result as get_index without the two fp64 divisions (the points pass is bound by fp64
+// issue, a division is ~15 dependent fp64 ops): (int)(-(d / res)) only depends on which side
+// of an integer the correctly rounded quotient lies.  q' = (-d) * fl(1/res) is within 3 roundings
+// (< 1e-11 absolute for |q| < 2^14) of that quotient, so whenever q' is further than 1e-6 from
+// every integer both truncate to the same cell; otherwise the exact division decides.
+__device__ __forceinline__ bool get_index_fast(const GridParams &g, double x, double y, int &ix, int &iy)
+{
+  const double tx = -((x - g.pos_x) - g.off_x);
+  const double ty = -((y - g.pos_y) - g.off_y);
+  if (!(tx >= 0.0 && ty >= 0.0 && tx < g.len_x && ty < g.len_y)) return false;  // NaN/inf land here
+  const double dx = (x - g.off_x) - g.pos_x;
+  const double dy = (y - g.off_y) - g.pos_y;
+  double qx = -dx * g.inv_res;
+  double qy = -dy * g.inv_res;
+  if (fabs(qx - rint(qx)) < 1e-6) qx = -(dx / g.res);
+  if (fabs(qy - rint(qy)) < 1e-6) qy = -(dy / g.res);
+  const int jx = (int)qx;
+  const int jy = (int)qy;
+  if (jx < 0 || jy < 0 || jx >= g.nx || jy >= g.ny) return false;
+  ix = jx;
+  iy = jy;
+  return true;
+}
+
+// (float)(n / d) for finite n, d without the division: r ~ 1/d by v_rcp_f64 + two Newton steps
+// (<= 1 ulp), q' = n * r is within a few ulp64 of the correctly rounded quotient, and both round
+// to the same float unless q' sits within 2^-45 (relative) of a float rounding boundary, i.e. its
+// 29 discarded mantissa bits are within 128 of the midpoint pattern; then the exact division
+// decides.  Non-finite or subnormal-float results take the exact path too.
+__device__ __forceinline__ double rcp_newton(double d)
+{
+  double r = __builtin_amdgcn_rcp(d);
+  r = fma(fma(-d, r, 1.0), r, r);
+  r = fma(fma(-d, r, 1.0), r, r);
+  return r;
+}
+__device__ __forceinline__ float div_to_float(double n, double d, double r)
+{
+  const double q = n * r;
+  const unsigned long long bits = (unsigned long long)__double_as_longlong(q);
+  const unsigned low = (unsigned)bits & 0x1FFFFFFFu;
+  const unsigned ex = (unsigned)(bits >> 52) & 0x7FFu;
+  const bool risky = (low - (0x10000000u - 128u)) <= 256u || ex < 1023u - 120u || ex > 1023u + 120u;
+  return risky ? (float)(n / d) : (float)q;
+}
+
 // [EXTENSION] X2 ray end of an out-of-map point: fp64 slab clip of
 // origin + t*(p - origin) against the map rectangle, then the clamped floor cell.
 __device__ __forceinline__ void clip_ray_end(const GridParams &g, const RayOrigin &o, double px, double py,
@@ -115,7 +161,7 @@ __global__ void __launch_bounds__(COUNTS ? 1024 : 256) k_points(PointsArgs a)
       int cell = -1;
       if (isfinite(bx) && isfinite(by) && isfinite(bz)) {
         int ix, iy;
-        if (get_index(a.g, (double)bx, (double)by, ix, iy)) {
+        if (get_index_fast(a.g, (double)bx, (double)by, ix, iy)) {
           cell = iy * a.g.nx + ix;
           if (COUNTS) {
             const unsigned slot = ((unsigned)cell * 2654435761u) >> 20;   // 12 bits
@@ -141,8 +187,9 @@ __global__ void __launch_bounds__(COUNTS ? 1024 : 256) k_points(PointsArgs a)
       if (isfinite(cx) && isfinite(cy) && isfinite(cz) && !(cz <= 0.001f)) {
         const double X = (double)cx, Y = (double)cy, Z = (double)cz;
         const double iz = krow(a.cam.k, 2, X, Y, Z);
-        const float u = (float)(krow(a.cam.k, 0, X, Y, Z) / iz);   // :268-272
-        const float v = (float)(krow(a.cam.k, 1, X, Y, Z) / iz);   // :273
+        const double riz = rcp_newton(iz);
+        const float u = div_to_float(krow(a.cam.k, 0, X, Y, Z), iz, riz);   // :268-272  (float)(n / iz)
+        const float v = div_to_float(krow(a.cam.k, 1, X, Y, Z), iz, riz);   // :273
         if (!(u < 0 || u >= (float)a.cam.W || v < 0 || v >= (float)a.cam.H)) {   // :276
           // :280-288 first match wins.  The reference compares (double)u against the
           // double bounds; bbox_f holds the float thresholds with the identical truth

@@ -93,6 +93,8 @@ struct SectorArgs {
   int32_t cap;            // ends per LDS chunk (>= 2048)
   int32_t log2m;          // slope buckets per sector = 1 << log2m (<= 9)
   int32_t marks_words;    // >= max(nx, ny) + 1
+  uint32_t oct_perm;      // dispatch order of the octants, 3 bits each (longest wedge first); 0 = identity off
+  int32_t reorder;        // 1: longest octants and the rational-gap sectors (0, S/2-1, S/2, S-1) first
   const uint32_t *hitN, *clipN, *hitT, *clipT;
   int32_t nxw, nyw, nx_pad, ny_pad;
   uint8_t *missN;         // G bytes, [y][x]

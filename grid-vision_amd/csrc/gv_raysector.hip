@@ -140,6 +140,44 @@ void launch_build_bitmaps(const BitmapArgs &a, hipStream_t s)
   else hipLaunchKernelGGL(k_build_bitmaps, grid, dim3(256), 0, s, a);
 }
 
+// ------------------------------------------------ wavefront primitives (DPP) --
+// Cross-lane steps as DPP modifiers of VALU ops (gfx9: row_shr, wave_shl:1, row_bcast:15/31)
+// instead of ds_bpermute round trips through the LDS crossbar: a 64-lane scan is six dependent
+// VALU ops (~tens of cycles) rather than six LDS latencies (~hundreds).
+template <int CTRL, int ROW_MASK = 0xF, int BANK_MASK = 0xF>
+__device__ __forceinline__ unsigned dpp_u32(unsigned old, unsigned src)
+{
+  return (unsigned)__builtin_amdgcn_update_dpp((int)old, (int)src, CTRL, ROW_MASK, BANK_MASK, false);
+}
+struct OpAdd { static constexpr unsigned id = 0u; __device__ static unsigned f(unsigned a, unsigned b) { return a + b; } };
+struct OpMax { static constexpr unsigned id = 0u; __device__ static unsigned f(unsigned a, unsigned b) { return a > b ? a : b; } };
+struct OpMin { static constexpr unsigned id = 0xFFFFFFFFu; __device__ static unsigned f(unsigned a, unsigned b) { return a < b ? a : b; } };
+// inclusive scan over the 64 lanes (lane 63 ends up with the reduction)
+template <class Op>
+__device__ __forceinline__ unsigned wave_scan(unsigned v)
+{
+  v = Op::f(v, dpp_u32<0x111>(Op::id, v));        // row_shr:1
+  v = Op::f(v, dpp_u32<0x112>(Op::id, v));        // row_shr:2
+  v = Op::f(v, dpp_u32<0x114>(Op::id, v));        // row_shr:4
+  v = Op::f(v, dpp_u32<0x118>(Op::id, v));        // row_shr:8
+  v = Op::f(v, dpp_u32<0x142, 0xA>(Op::id, v));   // row_bcast:15 -> rows 1, 3
+  v = Op::f(v, dpp_u32<0x143, 0xC>(Op::id, v));   // row_bcast:31 -> rows 2, 3
+  return v;
+}
+template <class Op>
+__device__ __forceinline__ unsigned wave_reduce(unsigned v)   // same value in every lane
+{
+  return (unsigned)__builtin_amdgcn_readlane((int)wave_scan<Op>(v), 63);
+}
+// value of lane + H (H = 1, 2, 4, 8) or `fill` past lane 63: H single-lane wave shifts
+template <int H>
+__device__ __forceinline__ unsigned wave_shift_down(unsigned v, unsigned fill)
+{
+#pragma unroll
+  for (int k = 0; k < H; ++k) v = dpp_u32<0x130>(fill, v);   // wave_shl:1
+  return v;
+}
+
 // ------------------------------------------------------- sector gather -----
 struct Oct {
   int xmaj, smaj, smin;   // major axis is x?; signs of the major / minor step
@@ -211,8 +249,25 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int S = 1 << A.log2s;
-  const int o = blockIdx.x >> A.log2s;
-  const int s = blockIdx.x & (S - 1);
+  // Dispatch order (workgroups start roughly in blockIdx order and the launch is ~2 rounds deep):
+  // octants with the longest wedges first, and inside an octant the sectors next to the slopes
+  // 0, 1/2, 1 first -- the lattice has gaps there, their threshold T stays low and they run long.
+  int o = blockIdx.x >> A.log2s;
+  int s = blockIdx.x & (S - 1);
+  if (A.reorder) {
+    o = (int)(A.oct_perm >> (3 * o)) & 7;
+    if (S >= 8) {
+      const int r = s;
+      if (r < 4) s = (r == 0) ? 0 : (r == 1) ? (S >> 1) - 1 : (r == 2) ? S - 1 : (S >> 1);
+      else s = (r - 4 < (S >> 1) - 2) ? r - 3 : r - 1;
+    }
+  }
+  const int wg = (o << A.log2s) | s;   // logical workgroup id (diagnostics)
+  // a clipped ray that ends in the origin cell itself (a == 0, inclusive end)
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    const unsigned wbit = A.clipN[(size_t)(A.org.cx >> 5) * A.ny_pad + A.org.cy] >> (A.org.cx & 31);
+    if (wbit & 1u) A.missN[(size_t)A.org.cy * A.g.nx + A.org.cx] = 1;
+  }
   const Oct oc = make_octant(o, A.g, A.org);
   if (oc.imax < 1) {
     if (threadIdx.x == 0 && A.stats) { A.stats[2 * blockIdx.x] = 0; A.stats[2 * blockIdx.x + 1] = 0; }
@@ -232,22 +287,21 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
   unsigned short *sfx = reinterpret_cast<unsigned short *>(smem + L.sfx);   // max from m to the block end
   unsigned *raw = reinterpret_cast<unsigned *>(smem + L.raw);               // staging: packed ends, scan order
   unsigned short *bkt = reinterpret_cast<unsigned short *>(smem + L.bkt);   // staging: their slope buckets
-  __shared__ unsigned s_wsum[NT / 64], s_wsum2[NT / 64], s_blkmax[8], s_blkpfx[9], s_blksfx[9], s_lvlmin[16], s_nlong;
-  __shared__ unsigned s_lm[16];
+  __shared__ unsigned s_wsum[NT / 64], s_wsum2[NT / 64], s_blkmax[8], s_blkpfx[9], s_blksfx[9], s_lvlmin[10 * 8], s_nlong, s_T, s_maxreach;
   __shared__ unsigned long long s_wvis[NT / 64];
+  __shared__ unsigned s_rowpart[CH][NT / 64];   // multi-group path: ends per (row, wavefront)
 
   // diagnostic build only (GV_SECTOR_DBG=1): thread 0 stamps the shader clock at phase
   // boundaries into a debug buffer nothing else reads; A.dbg is null in production
   int stamp_n = 0;
   auto stamp = [&]() {
-    if (A.dbg && tid == 0 && stamp_n < 16) A.dbg[(size_t)blockIdx.x * 16 + stamp_n] = __builtin_amdgcn_s_memtime();
+    if (A.dbg && tid == 0 && stamp_n < 16) A.dbg[(size_t)wg * 16 + stamp_n] = __builtin_amdgcn_s_memtime();
     ++stamp_n;
   };
   stamp();
   for (int i = tid; i <= oc.imax; i += NT) marks[i] = 0;
   if (tid < NT / 64) s_wvis[tid] = 0;
   for (int m = tid; m < M; m += NT) { cnt[m] = 0; bmax32[m] = 0; }
-  if (tid < 16) s_lvlmin[tid] = 0xFFFFFFFFu;
   if (tid == 0) s_nlong = 0;
   __syncthreads();
   stamp();   // 1: init done
@@ -256,7 +310,7 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
   const unsigned *bmH = oc.xmaj ? A.hitT : A.hitN;
   const unsigned *bmC = oc.xmaj ? A.clipT : A.clipN;
   const int roww = oc.xmaj ? A.nyw : A.nxw;                 // words along the minor axis
-  const size_t major_pad = oc.xmaj ? A.nx_pad : A.ny_pad;   // word-row stride
+  const unsigned major_pad = (unsigned)(oc.xmaj ? A.nx_pad : A.ny_pad);   // word-row stride
   const int oc_major = oc.xmaj ? A.org.cx : A.org.cy;
   const int oc_minor = oc.xmaj ? A.org.cy : A.org.cx;
 
@@ -268,17 +322,9 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
     else if (r >= Q) ++q;
     return q;
   };
-  // wavefront sum / min by butterfly shuffles (no same-address LDS atomics: those serialise)
-  auto wave_sum = [](unsigned v) -> unsigned {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-    return v;
-  };
-  auto wave_min = [](unsigned v) -> unsigned {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = min(v, (unsigned)__shfl_xor(v, off));
-    return v;
-  };
+  // wavefront sum / min (no same-address LDS atomics: those serialise)
+  auto wave_sum = [](unsigned v) -> unsigned { return wave_reduce<OpAdd>(v); };
+  auto wave_min = [](unsigned v) -> unsigned { return wave_reduce<OpMin>(v); };
   // slope bucket of an end: floor((b*S - a*s) * M / a); slope 1 (last sector) -> M-1
   auto bucket_of_end = [&](int a, int b) -> int {
     const int rel = b * S - a * s;
@@ -301,36 +347,40 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
     return mx;
   };
 
-  // ---- scan: CH columns per thread (a = 1 + tid + NT*c), bitmap loads issued back to back
+  // minor-offset range [blo, bhi] of the wedge in column a (empty when blo > bhi)
+  auto col_bounds = [&](int a, int &blo, int &bhi) {
+    const int bmaxa = oc.xmaj ? a : a - 1;
+    blo = (a * s + S - 1) >> A.log2s;
+    bhi = ((a * (s + 1) + S - 1) >> A.log2s) - 1;
+    if (s == S - 1) bhi = bmaxa;
+    blo = max(blo, oc.bmin);
+    bhi = min(min(bhi, bmaxa), oc.jmaxo);
+  };
+  // ---- scan: CH columns per thread (a = 1 + tid + NT*c), bitmap loads issued back to back.
+  // ends / vcs live only from here to the staging loop of the group that consumes them; the
+  // (rare) multi-group path re-reads its rows instead of keeping CH columns in registers.
   unsigned ends[CH], vcs[CH];
-  int blos[CH], bhis[CH];
-  {
+  auto scan_columns = [&](unsigned rowmask) {
     unsigned h0[CH], h1[CH], c0[CH], c1[CH];
     int shs[CH], ws[CH];
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
       const int a = 1 + tid + NT * c;
-      const bool in = a <= oc.imax;
+      const bool in = (a <= oc.imax) && ((rowmask >> c) & 1u);
       const int ac = in ? a : 1;
-      const int bmaxa = oc.xmaj ? ac : ac - 1;
-      int blo = (ac * s + S - 1) >> A.log2s;
-      int bhi = ((ac * (s + 1) + S - 1) >> A.log2s) - 1;
-      if (s == S - 1) bhi = bmaxa;
-      blo = max(blo, oc.bmin);
-      bhi = min(min(bhi, bmaxa), oc.jmaxo);
+      int blo, bhi;
+      col_bounds(ac, blo, bhi);
       const bool ok = in && blo <= bhi;
       const int w = ok ? bhi - blo + 1 : 0;   // <= 32 (host guarantees imax <= 30*S)
       const int major_abs = oc_major + oc.smaj * ac;
       const int m_lo = ok ? ((oc.smin > 0) ? oc_minor + blo : oc_minor - bhi) : 0;
       const int w0 = m_lo >> 5;
-      const size_t base = (size_t)w0 * major_pad + major_abs;
-      const size_t base1 = (w0 + 1 < roww) ? base + major_pad : base;
+      const unsigned base = (unsigned)w0 * major_pad + (unsigned)major_abs;   // < 2^21 words
+      const unsigned base1 = (w0 + 1 < roww) ? base + major_pad : base;
       h0[c] = bmH[base]; c0[c] = bmC[base];
       h1[c] = bmH[base1]; c1[c] = bmC[base1];
       shs[c] = m_lo & 31;
       ws[c] = w;
-      blos[c] = blo;
-      bhis[c] = bhi;
     }
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
@@ -341,18 +391,39 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
       vcs[c] = (unsigned)(c64 >> shs[c]) & wm;
       ends[c] = vh | vcs[c];   // bit t <-> b = blo + t (positive minor side) or bhi - t
     }
-  }
+  };
+  scan_columns((1u << CH) - 1u);
+  // one row only (multi-group path): the other rows read as empty
+  auto scan_row = [&](int c) {
+    const int a = 1 + tid + NT * c;
+    unsigned e = 0, vc = 0;
+    int blo, bhi;
+    col_bounds(a, blo, bhi);
+    if (a <= oc.imax && blo <= bhi) {
+      const int w = bhi - blo + 1;
+      const int major_abs = oc_major + oc.smaj * a;
+      const int m_lo = (oc.smin > 0) ? oc_minor + blo : oc_minor - bhi;
+      const int w0 = m_lo >> 5;
+      const unsigned base = (unsigned)w0 * major_pad + (unsigned)major_abs;
+      const unsigned base1 = (w0 + 1 < roww) ? base + major_pad : base;
+      const unsigned long long h64 = ((unsigned long long)bmH[base1] << 32) | bmH[base];
+      const unsigned long long c64 = ((unsigned long long)bmC[base1] << 32) | bmC[base];
+      const unsigned wm = (w >= 32) ? 0xFFFFFFFFu : ((1u << w) - 1u);
+      vc = (unsigned)(c64 >> (m_lo & 31)) & wm;
+      e = ((unsigned)(h64 >> (m_lo & 31)) & wm) | vc;
+    }
+#pragma unroll
+    for (int cc = 0; cc < CH; ++cc) {
+      ends[cc] = (cc == c) ? e : 0u;
+      vcs[cc] = (cc == c) ? vc : 0u;
+    }
+  };
   // ends per thread -> inclusive prefix inside the wavefront, wavefront totals in LDS: gives
   // the total AND (fast path) every thread's slot range without another barrier
   unsigned scan_mine = 0;
 #pragma unroll
   for (int c = 0; c < CH; ++c) scan_mine += (unsigned)__popc(ends[c]);
-  unsigned scan_incl = scan_mine;
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    const unsigned v = __shfl_up(scan_incl, off);
-    if (lane >= off) scan_incl += v;
-  }
+  const unsigned scan_incl = wave_scan<OpAdd>(scan_mine);
   if (lane == 63) s_wsum[wave] = scan_incl;
   __syncthreads();
   int total = 0;
@@ -379,18 +450,12 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
     } else {
       __syncthreads();   // previous group fully done with the tables
       for (int m = tid; m < M; m += NT) { cnt[m] = 0; bmax32[m] = 0; }
-      if (tid < 16) s_lvlmin[tid] = 0xFFFFFFFFu;
       if (tid == 0) s_nlong = 0;
       mycnt = 0;
 #pragma unroll
       for (int c = 0; c < CH; ++c)
         if (((rowmask >> c) & 1u) && mine_w) mycnt += (unsigned)__popc(ends[c]);
-      incl = mycnt;
-#pragma unroll
-      for (int off = 1; off < 64; off <<= 1) {
-        const unsigned v = __shfl_up(incl, off);
-        if (lane >= off) incl += v;
-      }
+      incl = wave_scan<OpAdd>(mycnt);
       if (lane == 63) s_wsum[wave] = incl;
       __syncthreads();
     }
@@ -408,10 +473,12 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
       if (!((rowmask >> c) & 1u) || !mine_w) continue;
       const int a = 1 + tid + NT * c;
       unsigned e = ends[c];
+      int blo, bhi;
+      col_bounds(a, blo, bhi);
       while (e) {
         const int t = __ffs(e) - 1;
         e &= e - 1;
-        const int b = (oc.smin > 0) ? blos[c] + t : bhis[c] - t;
+        const int b = (oc.smin > 0) ? blo + t : bhi - t;
         const int bk = bucket_of_end(a, b);
         raw[slot] = pack_ab(a, b, (int)((vcs[c] >> t) & 1u));
         bkt[slot] = (unsigned short)bk;
@@ -424,16 +491,15 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
     // exclusive prefix over the M bucket counts (thread m owns bucket m; M <= NT)
     {
       const unsigned bc = (tid < M) ? cnt[tid] : 0u;
-      unsigned in2 = bc;
-#pragma unroll
-      for (int off = 1; off < 64; off <<= 1) {
-        const unsigned v = __shfl_up(in2, off);
-        if (lane >= off) in2 += v;
-      }
+      const unsigned in2 = wave_scan<OpAdd>(bc);
       if (lane == 63) s_wsum2[wave] = in2;
       __syncthreads();
       unsigned base = 0;
-      for (int wv = 0; wv < wave; ++wv) base += s_wsum2[wv];
+#pragma unroll
+      for (int wv = 0; wv < NT / 64; ++wv) {   // independent reads, selected afterwards
+        const unsigned t = s_wsum2[wv];
+        if (wv < wave) base += t;
+      }
       if (tid < M) {
         bstart[tid] = base + in2 - bc;
         cnt[tid] = base + in2 - bc;   // placement cursor
@@ -444,7 +510,7 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
     stamp();   // 4: prefix
     // place the packed ends into their buckets; bucket max reach; visit statistics
     {
-      unsigned long long vis = 0;
+      unsigned vis = 0;   // <= 9 ends x reach < 2^13 per thread: the wavefront sum fits 32 bits
       for (unsigned k = tid; k < n; k += NT) {
         const unsigned p = raw[k];
         const unsigned m = bkt[k];
@@ -453,44 +519,48 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
         atomicMax(&bmax32[m], rch);
         vis += rch;
       }
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) vis += __shfl_xor(vis, off);
+      vis = wave_sum(vis);
       if (lane == 0 && vis) s_wvis[wave] += vis;   // one owner per slot
     }
     __syncthreads();
     stamp();   // 5: placed
-    // range-max structure: wavefront `wave` owns the 64-bucket block `wave` (shuffles only)
+    // range-max structure: wavefront `wave` owns the 64-bucket block `wave` (cross-lane ops only)
     if (wave < NB) {
       const int m = wave * 64 + lane;
       const unsigned v0 = (m < M) ? bmax32[m] : 0u;
       unsigned v = v0;
       if (m < M) lvl[m] = (unsigned short)v;
-      // level minima: s_lvlmin[Lv] = min over the 2^Lv aligned groups of M>>Lv buckets of the
-      // group's max reach (0 if a group is empty).  Groups of <= 64 buckets live inside one
-      // block: reduce them here; coarser levels are read off s_blkmax at query time.
+      // level minima: s_lvlmin[Lv * 8 + block] = min over the aligned groups of M>>Lv buckets inside
+      // this block of the group's max reach (0 if a group is empty).  Groups of <= 64 buckets live
+      // inside one block; coarser levels are read off s_blkmax at query time.
       // only levels Lv <= lv_max are ever queried (2^Lv >= 2i/S, i <= imax)
       if (LM <= lv_max) {
         const unsigned mn = wave_min((m < M) ? v : 0xFFFFFFFFu);
-        if (lane == 0) atomicMin(&s_lvlmin[LM], mn);
+        if (lane == 0) s_lvlmin[LM * 8 + wave] = mn;
       }
 #pragma unroll
       for (int l = 1; l <= 6; ++l) {
-        const int h = 1 << (l - 1);
-        const unsigned up = __shfl_down(v, h);
-        if (lane + h < 64) v = max(v, up);
+        constexpr unsigned kNone = 0u;   // max with 0 = no-op: lanes past the block end keep v
+        unsigned up;
+        if (l == 1) up = wave_shift_down<1>(v, kNone);
+        else if (l == 2) up = wave_shift_down<2>(v, kNone);
+        else if (l == 3) up = wave_shift_down<4>(v, kNone);
+        else if (l == 4) up = wave_shift_down<8>(v, kNone);
+        else {
+          const int h = 1 << (l - 1);
+          up = __shfl_down(v, h);
+          if (lane + h >= 64) up = 0u;
+        }
+        v = max(v, up);
         if (m < M) lvl[l * M + m] = (unsigned short)v;
         if (l <= LM && LM - l <= lv_max) {
           const unsigned mn = wave_min(((lane & ((1 << l) - 1)) == 0 && m < M) ? v : 0xFFFFFFFFu);
-          if (lane == 0) atomicMin(&s_lvlmin[LM - l], mn);
+          if (lane == 0) s_lvlmin[(LM - l) * 8 + wave] = mn;
         }
       }
-      unsigned p = v0, q = v0;
-#pragma unroll
-      for (int off = 1; off < 64; off <<= 1) {
-        const unsigned pu = __shfl_up(p, off), qd = __shfl_down(q, off);
-        if (lane >= off) p = max(p, pu);
-        if (lane + off < 64) q = max(q, qd);
-      }
+      // in-block prefix maxima by a DPP scan; suffix maxima = the same scan on the mirrored lanes
+      const unsigned p = wave_scan<OpMax>(v0);
+      const unsigned q = __shfl(wave_scan<OpMax>(__shfl(v0, 63 - lane)), 63 - lane);
       if (m < M) { pfx[m] = (unsigned short)p; sfx[m] = (unsigned short)q; }
       if (lane == 63) s_blkmax[wave] = p;
     }
@@ -500,45 +570,84 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
     // (the test is monotone in i).  Columns beyond T are crossed only by the few rays with
     // reach > T+1: when that is cheap, march exactly those rays over exactly those columns
     // instead of evaluating every cell there.
-    // per-level minima in parallel (thread Lv), block prefix/suffix tables (threads 32, 33),
-    // then a short serial combine by thread 0
-    if (tid <= lv_max && tid <= LM) {
-      const int Lv = tid;
-      unsigned lm;
-      if (LM - Lv <= 6) lm = s_lvlmin[Lv];
-      else {
-        const int gb = 1 << (LM - Lv - 6);
-        lm = 0xFFFFFFFFu;
-        for (int g0 = 0; g0 < NB; g0 += gb) {
-          unsigned gm = 0;
-          for (int bk = g0; bk < g0 + gb; ++bk) gm = max(gm, s_blkmax[bk]);
-          lm = min(lm, gm);
-        }
+    // Wavefront 0 does the whole (tiny, mostly scalar) computation and publishes T and the largest
+    // reach; the other seven go straight to the barrier.  One LDS read per lane fetches the
+    // per-block level minima (lanes 0..55: level offset l = lane>>3, block lane&7) and the block
+    // maxima (lanes 56..63); 8-lane minima by DPP, then everything is scalar (readlane).
+    if (wave == 0) {
+    unsigned vread = 0xFFFFFFFFu;
+    {
+      const int l = lane >> 3, bk = lane & 7;
+      if (lane < 56) {
+        const int Lv = LM - l;
+        if (bk < NB && Lv >= 0 && Lv <= lv_max) vread = s_lvlmin[Lv * 8 + bk];
+      } else {
+        vread = (bk < NB) ? s_blkmax[bk] : 0u;
       }
-      s_lm[Lv] = lm;
     }
-    if (tid == 32) {   // exclusive prefix maxima over the 64-bucket blocks (edge-cell queries)
+    unsigned vmin = vread;   // lane 8l+7 <- min over the blocks of level LM-l
+    vmin = min(vmin, dpp_u32<0x111>(0xFFFFFFFFu, vmin));
+    vmin = min(vmin, dpp_u32<0x112>(0xFFFFFFFFu, vmin));
+    vmin = min(vmin, dpp_u32<0x114>(0xFFFFFFFFu, vmin));
+    unsigned bm[8];
+#pragma unroll
+    for (int bk = 0; bk < 8; ++bk) bm[bk] = (unsigned)__builtin_amdgcn_readlane((int)vread, 56 + bk);
+    unsigned maxreach0 = 0;
+    {
+      // exclusive prefix / suffix maxima over the blocks (edge-cell queries), one writer each
       unsigned run = 0;
-      for (int bk = 0; bk < NB; ++bk) { s_blkpfx[bk] = run; run = max(run, s_blkmax[bk]); }
+#pragma unroll
+      for (int bk = 0; bk < 8; ++bk) {
+        if (lane == 0 && bk < NB) s_blkpfx[bk] = run;
+        run = max(run, bm[bk]);
+      }
+      maxreach0 = run;
+      run = 0;
+#pragma unroll
+      for (int bk = 7; bk >= 0; --bk) {
+        if (lane == 1 && bk < NB) s_blksfx[bk] = run;
+        run = max(run, bm[bk]);
+      }
     }
-    if (tid == 33) {
-      unsigned run = 0;
-      for (int bk = NB - 1; bk >= 0; --bk) { s_blksfx[bk] = run; run = max(run, s_blkmax[bk]); }
-    }
-    __syncthreads();
-    int T = 0;
+    int T0 = 0;
     {
       bool open = true;
-      for (int Lv = 0; Lv <= lv_max && Lv <= LM && open; ++Lv) {
+      const int lv_top = min(lv_max, LM);
+      const unsigned q01 = max(bm[0], bm[1]), q23 = max(bm[2], bm[3]), q45 = max(bm[4], bm[5]), q67 = max(bm[6], bm[7]);
+#pragma unroll
+      for (int Lv = 0; Lv <= 9; ++Lv) {
+        if (Lv > lv_top || !open) continue;
+        unsigned lm;
+        const int l = LM - Lv;
+        if (l <= 6) {
+          lm = (unsigned)__builtin_amdgcn_readlane((int)vmin, l * 8 + 7);
+        } else if (l == 7) {   // groups of 2 whole blocks
+          lm = q01;
+          if (NB > 2) lm = min(lm, q23);
+          if (NB > 4) lm = min(min(lm, q45), q67);
+        } else if (l == 8) {   // groups of 4 whole blocks
+          lm = max(q01, q23);
+          if (NB > 4) lm = min(lm, max(q45, q67));
+        } else {               // one group: everything
+          lm = maxreach0;
+        }
         // columns whose cell width asks for level Lv: ceil(2i/S) in (2^(Lv-1), 2^Lv]
         const int hiL = min(oc.imax, (Lv == 0) ? (S >> 1) : (int)(((long long)S << Lv) >> 1));
-        const unsigned lm = s_lm[Lv];
-        if (lm > (unsigned)hiL) T = hiL;
-        else { T = max(T, min(hiL, (int)lm - 1)); open = false; }
+        if (lm > (unsigned)hiL) T0 = hiL;
+        else { T0 = max(T0, min(hiL, (int)lm - 1)); open = false; }
       }
-      if (A.ablate & 64) T = 0;
+      if (A.ablate & 64) T0 = 0;
     }
+    if (lane == 0) { s_T = (unsigned)T0; s_maxreach = maxreach0; }
+    }
+    __syncthreads();   // s_T, s_maxreach, s_blkpfx, s_blksfx visible
+    const int T = (int)s_T;
+    const unsigned maxreach = s_maxreach;
     stamp();   // 7: threshold
+    if (A.dbg && tid == 0) {
+      const unsigned mr = maxreach;
+      A.dbg[(size_t)wg * 16 + 12] = ((unsigned long long)T << 48) | ((unsigned long long)mr << 32) | ((unsigned long long)oc.imax << 16) | (unsigned long long)min(n, 65535u);
+    }
     // long rays (reach > T+1) -> compact list in the (now free) cursor array `cnt`
     bool march_tail = false;
     if (T < oc.imax && !(A.ablate & 256)) {
@@ -570,6 +679,9 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
       for (int wv = 0; wv < NT / 64; ++wv) tail_steps += s_wsum[wv];
       const unsigned nlong = s_nlong;
       march_tail = (nlong <= (unsigned)M) && (tail_steps <= 64u * NT);
+      if (A.dbg && tid == 0) {
+        A.dbg[(size_t)wg * 16 + 13] = ((unsigned long long)tail_steps << 32) | nlong;
+      }
       stamp();   // 8: long rays compacted
       if (march_tail) {
         // one ray per wavefront, lanes over consecutive columns: distinct LDS words
@@ -600,6 +712,7 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
         marks[0] |= 1u;   // every ray (reach >= 1) starts in the origin cell
         continue;
       }
+      if ((unsigned)i >= maxreach) continue;   // no ray of this group gets this far
       const int jlo = (2 * i * s + S) >> (A.log2s + 1);
       const int jhi = (2 * i * (s + 1) + S) >> (A.log2s + 1);
       const int w = jhi - jlo + 1;
@@ -614,44 +727,38 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
       unsigned mask = 0;
       if (interior_free) {
         mask = ((w >= 32) ? 0xFFFFFFFFu : ((1u << w) - 1u)) & ~1u & ~(1u << (w - 1));
-        // edge cell 0: slopes below the first interior boundary
-        {
-          const int Phi = 2 * jlo + 1;
-          const int hi = bucket_of_boundary(Phi, Q);
-          // max reach over buckets [0, hi-1]: in-block prefix + whole blocks before it
-          unsigned mx = 0u;
-          if (hi >= 1) {
-            const int r = min(hi, M) - 1;
-            mx = max((unsigned)pfx[r], s_blkpfx[r >> 6]);
+        // the two edge cells: all table reads of both issued before anything is evaluated
+        // edge cell 0: slopes below the first interior boundary -> buckets [0, hi-1] + part of hi
+        const int Phi = 2 * jlo + 1;
+        const int hi = bucket_of_boundary(Phi, Q);
+        // edge cell w-1: slopes at or above the last interior boundary -> part of lo + [lo+1, M-1]
+        const int Plo = 2 * jhi - 1;
+        const int lo = bucket_of_boundary(Plo, Q);
+        const int r = min(max(hi, 1), M) - 1;              // last whole bucket below the boundary
+        const int l = min(max(lo + 1, 0), M - 1);          // first whole bucket above it
+        const int hic = min(max(hi, 0), M - 1), loc = min(max(lo, 0), M - 1);
+        const unsigned pf = pfx[r], bpf = s_blkpfx[r >> 6];
+        const unsigned sf = sfx[l], bsf = s_blksfx[l >> 6];
+        const unsigned e0h = bstart[hic], e1h = bstart[hic + 1];
+        const unsigned e0l = bstart[loc], e1l = bstart[loc + 1];
+        unsigned mxh = (hi >= 1) ? max(pf, bpf) : 0u;
+        unsigned mxl = (lo + 1 <= M - 1) ? max(sf, bsf) : 0u;
+        if (mxh <= (unsigned)i && hi >= 0 && hi < M) {
+          for (unsigned e = e0h; e < e1h; ++e) {
+            const unsigned p = abv[e];
+            const int a = ab_a(p);
+            if (ab_b(p) * Q < Phi * a) mxh = max(mxh, (unsigned)(a + (int)(p & 1u)));
           }
-          if (mx <= (unsigned)i && hi >= 0 && hi < M) {
-            for (unsigned e = bstart[hi]; e < bstart[hi + 1]; ++e) {
-              const unsigned p = abv[e];
-              const int a = ab_a(p);
-              if (ab_b(p) * Q < Phi * a) mx = max(mx, (unsigned)(a + (int)(p & 1u)));
-            }
-          }
-          if (mx > (unsigned)i) mask |= 1u;
         }
-        // edge cell w-1: slopes at or above the last interior boundary
-        {
-          const int Plo = 2 * jhi - 1;
-          const int lo = bucket_of_boundary(Plo, Q);
-          // max reach over buckets [lo+1, M-1]: in-block suffix + whole blocks after it
-          unsigned mx = 0u;
-          if (lo + 1 <= M - 1) {
-            const int l = max(lo + 1, 0);
-            mx = max((unsigned)sfx[l], s_blksfx[l >> 6]);
+        if (mxl <= (unsigned)i && lo >= 0 && lo < M) {
+          for (unsigned e = e0l; e < e1l; ++e) {
+            const unsigned p = abv[e];
+            const int a = ab_a(p);
+            if (ab_b(p) * Q >= Plo * a) mxl = max(mxl, (unsigned)(a + (int)(p & 1u)));
           }
-          if (mx <= (unsigned)i && lo >= 0 && lo < M) {
-            for (unsigned e = bstart[lo]; e < bstart[lo + 1]; ++e) {
-              const unsigned p = abv[e];
-              const int a = ab_a(p);
-              if (ab_b(p) * Q >= Plo * a) mx = max(mx, (unsigned)(a + (int)(p & 1u)));
-            }
-          }
-          if (mx > (unsigned)i) mask |= 1u << (w - 1);
         }
+        if (mxh > (unsigned)i) mask |= 1u;
+        if (mxl > (unsigned)i) mask |= 1u << (w - 1);
       } else {
         int lo = -1;             // bucket holding the cell's lower boundary (-1: below the sector)
         unsigned above = 0;      // max reach of the ends of bucket `lo` at or above that boundary
@@ -688,27 +795,27 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
   };
 
   if (A.ablate & 32) return;   // timing experiment
+  // Normally the whole wedge is one group.  With more ends than one LDS group holds: one group
+  // per row of columns, and per wavefront (64 columns x <= 32 ends <= 2048 <= cap) where a row
+  // alone is too big.
   if (total <= cap) {
     process_group((1u << CH) - 1u, -1, true);
   } else {
-    // more ends than one LDS group holds: one group per row of columns, and per
-    // wavefront (64 columns x <= 32 ends <= 2048 <= cap) where a row alone is too big
-    for (int c = 0; c < CH; ++c) {
-      unsigned mine = 0;
 #pragma unroll
-      for (int cc = 0; cc < CH; ++cc)
-        if (cc == c) mine = (unsigned)__popc(ends[cc]);
-      const unsigned r = wave_sum(mine);
-      __syncthreads();
-      if (lane == 0) s_wsum[wave] = r;
-      __syncthreads();
+    for (int c = 0; c < CH; ++c) {
+      const unsigned r = wave_sum((unsigned)__popc(ends[c]));
+      if (lane == 0) s_rowpart[c][wave] = r;
+    }
+    __syncthreads();
+    for (int c = 0; c < CH; ++c) {
       int rt = 0;
-      for (int wv = 0; wv < NT / 64; ++wv) rt += (int)s_wsum[wv];
-      __syncthreads();
+      for (int wv = 0; wv < NT / 64; ++wv) rt += (int)s_rowpart[c][wv];
       if (rt == 0) continue;
-      if (rt <= cap) process_group(1u << c, -1, false);
-      else
-        for (int wv = 0; wv < NT / 64; ++wv) process_group(1u << c, wv, false);
+      const int nw = (rt <= cap) ? 1 : NT / 64;
+      for (int wi = 0; wi < nw; ++wi) {
+        scan_row(c);
+        process_group(1u << c, (nw == 1) ? -1 : wi, false);
+      }
     }
   }
 
@@ -738,11 +845,6 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
       for (int wv = 0; wv < NT / 64; ++wv) vsum += s_wvis[wv];
       A.stats[2 * blockIdx.x] = (unsigned long long)total;
       A.stats[2 * blockIdx.x + 1] = vsum;
-    }
-    // a clipped ray that ends in the origin cell itself (a == 0, inclusive)
-    if (blockIdx.x == 0) {
-      const unsigned wbit = A.clipN[(size_t)(A.org.cx >> 5) * A.ny_pad + A.org.cy] >> (A.org.cx & 31);
-      if (wbit & 1u) A.missN[(size_t)A.org.cy * A.g.nx + A.org.cx] = 1;
     }
   }
 }

@@ -17,6 +17,7 @@ struct GridParams {
   double len_x, len_y;   // size * res
   double pos_x, pos_y;   // map centre
   double off_x, off_y;   // 0.5 * len
+  double inv_res;        // fl64(1 / res): quotient estimate of the points pass (never the result itself)
 };
 
 // Row-major 3x4 fp32 rigid transform (the top of PCL's 4x4).

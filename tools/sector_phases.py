@@ -35,3 +35,30 @@ for k, nme in enumerate(names):
 tot = t[full][:, NS] - t[full][:, 0]
 print(f"total    mean {tot.mean():9.0f}  max {tot.max():9.0f} cycles ; kernel span {(t[full][:, NS].max() - t[full][:, 0].min())} ticks")
 print("stage", h.time_frame_stages(20))
+if "detail" in sys.argv:
+    S = 1 << log2s
+    order = np.argsort(-tot)[:12]
+    t0 = t[full][:, 0].min()
+    print("heaviest workgroups: wg octant sector start end | phases")
+    for i in order:
+        v12, v13 = int(buf[i, 12]), int(buf[i, 13])
+        print(i, i >> log2s, i & (S - 1), "T", v12 >> 48, "maxreach", (v12 >> 32) & 0xFFFF, "imax", (v12 >> 16) & 0xFFFF, "n", v12 & 0xFFFF,
+              "nlong", v13 & 0xFFFFFFFF, "tail_steps", v13 >> 32, d[i].tolist())
+    print("total percentiles", [int(np.percentile(tot, q)) for q in (10, 50, 90, 99, 100)])
+    st = t[full][:, 0] - t0
+    print("start-time percentiles", [int(np.percentile(st, q)) for q in (10, 50, 60, 90, 99, 100)], "last end", int((t[full][:, NS] - t0).max()))
+    # per-octant mean total
+    for o in range(8):
+        sel = (np.arange(nwg) >> log2s) == o
+        print("octant", o, "mean", int(tot[sel].mean()), "max", int(tot[sel].max()), "argmax sector", int(np.argmax(tot[sel])))
+
+    b12 = buf[:, 12].astype(np.uint64)
+    Tv = (b12 >> np.uint64(48)).astype(np.int64); mr = ((b12 >> np.uint64(32)) & np.uint64(0xFFFF)).astype(np.int64)
+    im = ((b12 >> np.uint64(16)) & np.uint64(0xFFFF)).astype(np.int64); nn = (b12 & np.uint64(0xFFFF)).astype(np.int64)
+    nl = (buf[:, 13] & np.uint64(0xFFFFFFFF)).astype(np.int64); ts = (buf[:, 13] >> np.uint64(32)).astype(np.int64)
+    print("T>=imax:", int((Tv >= im).sum()), " marched tails:", int(((Tv < im) & (nl <= 512) & (ts <= 32768)).sum()),
+          " full-loop tails:", int(((Tv < im) & ~((nl <= 512) & (ts <= 32768))).sum()))
+    fl = (Tv < im) & ~((nl <= 512) & (ts <= 32768))
+    print("full-loop WGs: mean edge", d[fl][:, 9].mean() if fl.any() else 0, "others mean edge", d[~fl][:, 9].mean())
+    print("full-loop: columns beyond T mean", (im - Tv)[fl].mean() if fl.any() else 0, " of which beyond maxreach", np.maximum(im - np.maximum(mr, Tv), 0)[fl].mean() if fl.any() else 0)
+    print("n ends: mean", nn.mean(), "max", nn.max())
