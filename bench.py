@@ -76,6 +76,77 @@ def cpu_baseline(config, cloud_fn, tfs, bboxes, poses, budget_s):
             "sample": f"{n} whole frames of the same workload (per-point Bresenham, no dedupe), {dt:.1f} s"}
 
 
+def cpu_baseline_all_cores(config, cloud_fn, tfs, bboxes, poses, budget_s):
+    """the same oracle on every host core.  The points are split into one chunk per
+    thread (ctypes releases the GIL inside the C calls); each thread bins, ray-marches and bbox-tests
+    its chunk into private grids, which are then summed / OR-ed and finalised once."""
+    from concurrent.futures import ThreadPoolExecutor
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as ol
+    from gvamd import synth
+    cores = max(1, min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), 32))
+    g = synth.CONFIGS[config]["grid"]
+    og = ol.OGrid(g.grid_x, g.grid_y, g.resolution)
+    workers = [ol.OGrid(g.grid_x, g.grid_y, g.resolution) for _ in range(cores)]   # geometry holders
+    x, y, z, _ = cloud_fn(config)
+    m_base = ol.tf_to_matrix4f(tfs["base_lidar"])
+    m_cam = ol.tf_to_matrix4f(tfs["cam_lidar"])
+    K = ol.set_intrinsic(synth.FX, synth.FY, synth.CX, synth.CY)
+    cuts = [len(x) * k // cores for k in range(cores + 1)]
+
+    def chunk(k):
+        sl = slice(cuts[k], cuts[k + 1])
+        w = workers[k]
+        hits, _ = w.bin_points(m_base, x[sl], y[sl], z[sl])
+        miss, _ = w.raymarch(m_base, x[sl], y[sl], z[sl], dedupe=False)
+        cx, cy, cz = ol.transform_cloud(m_cam, x[sl], y[sl], z[sl])
+        ol.extract_cloud_per_bbox(K, cx, cy, cz, bboxes, synth.IMG_W, synth.IMG_H)
+        return hits, miss
+
+    pool = ThreadPoolExecutor(cores)
+
+    def frame():
+        parts = list(pool.map(chunk, range(cores)))
+        hits, miss = parts[0]
+        for h2, m2 in parts[1:]:
+            hits = hits + h2
+            miss = np.maximum(miss, m2)
+        og.frame_update(poses, hits, miss)
+        og.to_occupancy_grid()
+
+    frame()
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        frame()
+        n += 1
+        if time.perf_counter() - t0 >= budget_s or n >= 100:
+            break
+    dt = time.perf_counter() - t0
+    pool.shutdown()
+    return {"value": n / dt, "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"{n} whole frames, points split over {cores} threads with private grids, reduced and finalised once, {dt:.1f} s"}
+
+
+def measured_copy_rate(torch):
+    """device-to-device copy rate of this box (read + write bytes / time): the second peak of SURVEY 8(d)"""
+    n = 256 << 20
+    a_ = torch.empty(n, dtype=torch.uint8, device="cuda")
+    b_ = torch.empty(n, dtype=torch.uint8, device="cuda")
+    for _ in range(3):
+        b_.copy_(a_)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        b_.copy_(a_)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 10
+    del a_, b_
+    return 2.0 * n / (ms * 1e-3) / 1e9
+
+
 def main():
     a = parse()
     # RCCL (and some HIP runtime paths) print banners on stdout; the contract is ONE JSON line
@@ -219,9 +290,19 @@ def main():
                           "mcell_visits_per_s": (n_visits / (stages["ray_march"] * 1e-3) / 1e6) if stages["ray_march"] > 0 else None},
             "roofline": roof,
         }
+        try:
+            copy_gbps = measured_copy_rate(torch)
+            out["frame_roofline"]["measured_copy_GBps"] = copy_gbps
+            out["frame_roofline"]["frac_of_measured_copy"] = bytes_frame * fps / world / 1e9 / copy_gbps
+            roof["peak_measured_copy"] = copy_gbps
+        except Exception as e:   # never fail the bench line over the auxiliary peak
+            out["frame_roofline"]["measured_copy_GBps"] = None
+            print("copy-rate measurement failed:", e, file=sys.stderr)
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(config, cloud_fn, tfs, bboxes, poses, a.cpu_seconds)
             out["gpu_over_cpu"] = fps / out["cpu_baseline"]["value"]
+            out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(config, cloud_fn, tfs, bboxes, poses, a.cpu_seconds)
+            out["gpu_over_cpu_all_cores"] = fps / out["cpu_baseline_all_cores"]["value"]
         else:
             out["cpu_baseline"] = None
     h.close()
