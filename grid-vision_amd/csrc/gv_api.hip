@@ -20,8 +20,10 @@ struct gv_context {
   int device = 0;
   hipStream_t stream = nullptr;
   // frame pipelining: points/bitmaps of frame f+1 (stream) overlap sectors/grid pass of frame f (stream2)
-  hipStream_t stream2 = nullptr;
-  hipEvent_t ev_build[2]{}, ev_fin[2]{};
+  hipStream_t stream2 = nullptr, stream3 = nullptr;   // B: sector ray stage, C: grid pass
+  hipEvent_t ev_build[2]{}, ev_sec[2]{}, ev_fin[2]{};
+  uint8_t *miss2 = nullptr, *missT2 = nullptr;        // second set of miss grids (pipelined frames alternate)
+  bool three_streams = true;                         // GV_PIPELINE=2: grid pass on stream B (two streams)
   uint32_t *hitN2 = nullptr, *clipN2 = nullptr, *hitT2 = nullptr, *clipT2 = nullptr;   // second bitmap set
   Rect *d_rects2 = nullptr;
   uint64_t frame_no = 0;
@@ -212,6 +214,7 @@ int use_device(gv_context *h)
   if (h->pipe_busy) {
     GV_HIP(hipStreamSynchronize(h->stream));
     GV_HIP(hipStreamSynchronize(h->stream2));
+    GV_HIP(hipStreamSynchronize(h->stream3));
     h->pipe_busy = false;
     h->since_drain = 0;
   }
@@ -540,12 +543,22 @@ int enqueue_frame_pipelined(gv_context *h)
   }
   GV_HIP(hipEventRecord(h->ev_build[p], sA));
   GV_HIP(hipStreamWaitEvent(sB, h->ev_build[p], 0));
+  // the grid pass runs on its own stream: HBM-bound, it overlaps the issue-bound sector kernel of the
+  // next frame; the miss grids alternate with the frame parity like the bitmaps do
+  hipStream_t sC = h->three_streams ? h->stream3 : sB;
+  uint8_t *missN = p ? h->miss2 : h->miss, *missT = p ? h->missT2 : h->missT;
+  if (h->three_streams && h->since_drain >= 2) GV_HIP(hipStreamWaitEvent(sB, h->ev_fin[p], 0));   // miss set p cleared by its last reader
   if (do_ray && h->org.valid) {
     SectorArgs sa{};
     int rc = fill_sector_args(h, sa);
     if (rc) return rc;
     sa.hitN = hitN; sa.clipN = clipN; sa.hitT = hitT; sa.clipT = clipT;
+    sa.missN = missN; sa.missT = missT;
     launch_ray_sectors(sa, sB);
+  }
+  if (h->three_streams) {
+    GV_HIP(hipEventRecord(h->ev_sec[p], sB));
+    GV_HIP(hipStreamWaitEvent(sC, h->ev_sec[p], 0));
   }
   FinalizeTileArgs t{};
   t.g = h->g;
@@ -557,15 +570,15 @@ int enqueue_frame_pipelined(gv_context *h)
   t.hitN = hitN;
   t.nxw = h->nxw;
   t.ny_pad = h->ny_pad;
-  t.missN = h->miss;
-  t.missT = h->missT;
+  t.missN = missN;
+  t.missT = missT;
   t.counts = do_bin;
   t.zero = do_bin;
   t.use_missT = true;
   t.y_begin = 0;
   t.y_end = h->g.ny;
-  launch_finalize_tiles(t, sB);
-  GV_HIP(hipEventRecord(h->ev_fin[p], sB));
+  launch_finalize_tiles(t, sC);
+  GV_HIP(hipEventRecord(h->ev_fin[p], sC));
   GV_HIP(hipGetLastError());
   h->frame_no++;
   if (h->since_drain < 2) h->since_drain++;
@@ -754,10 +767,12 @@ int gv_create(gv_handle *out, uint8_t grid_x, uint8_t grid_y, double resolution,
     const int mode = pe ? std::atoi(pe) : 0;
     GV_C(hipStreamCreateWithPriority(&h->stream, hipStreamNonBlocking, mode == 1 ? hi : (mode == 2 ? lo : 0)));
     GV_C(hipStreamCreateWithPriority(&h->stream2, hipStreamNonBlocking, mode == 2 ? hi : (mode == 1 ? lo : 0)));
+    GV_C(hipStreamCreateWithPriority(&h->stream3, hipStreamNonBlocking, mode == 3 ? hi : 0));
   }
   for (int i = 0; i < 2; ++i) {
     GV_C(hipEventCreateWithFlags(&h->ev_build[i], hipEventDisableTiming));
     GV_C(hipEventCreateWithFlags(&h->ev_fin[i], hipEventDisableTiming));
+    GV_C(hipEventCreateWithFlags(&h->ev_sec[i], hipEventDisableTiming));
   }
   const size_t G = (size_t)g.G;
   GV_C(hipMalloc(reinterpret_cast<void **>(&h->log_odds), G * sizeof(float)));
@@ -772,6 +787,10 @@ int gv_create(gv_handle *out, uint8_t grid_x, uint8_t grid_y, double resolution,
   GV_C(hipMalloc(reinterpret_cast<void **>(&h->ray_stats), kMaxStatSlots * 2 * sizeof(unsigned long long)));
   GV_C(hipMalloc(reinterpret_cast<void **>(&h->scratch_i32), G * sizeof(int32_t)));
   GV_C(hipMalloc(reinterpret_cast<void **>(&h->missT), G + 16));
+  GV_C(hipMalloc(reinterpret_cast<void **>(&h->miss2), G + 16));
+  GV_C(hipMalloc(reinterpret_cast<void **>(&h->missT2), G + 16));
+  GV_C(hipMemsetAsync(h->miss2, 0, G + 16, h->stream));
+  GV_C(hipMemsetAsync(h->missT2, 0, G + 16, h->stream));
   h->nxw = 2 * ((g.nx + 63) / 64);
   h->nyw = 2 * ((g.ny + 63) / 64);
   h->nx_pad = 64 * ((g.nx + 63) / 64);
@@ -800,7 +819,7 @@ int gv_create(gv_handle *out, uint8_t grid_x, uint8_t grid_y, double resolution,
   {
     const char *impl = std::getenv("GV_RAY_IMPL");
     h->force_simple = impl && std::strcmp(impl, "simple") == 0;
-    if (const char *e = std::getenv("GV_PIPELINE")) h->no_pipeline = std::atoi(e) == 0;
+    if (const char *e = std::getenv("GV_PIPELINE")) { h->no_pipeline = std::atoi(e) == 0; h->three_streams = std::atoi(e) != 2; }
     if (const char *e = std::getenv("GV_HIT_COUNTS")) h->force_counts = std::atoi(e) != 0;
     if (const char *e = std::getenv("GV_LOG2S")) h->env_log2s = std::atoi(e);
     if (const char *e = std::getenv("GV_SECTOR_REORDER")) h->env_reorder = std::atoi(e) != 0;
@@ -833,9 +852,10 @@ int gv_destroy(gv_handle h)
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   if (h->stream2) (void)hipStreamSynchronize(h->stream2);
+  if (h->stream3) (void)hipStreamSynchronize(h->stream3);
   if (h->comm) { ncclCommDestroy(h->comm); h->comm = nullptr; }
   void *bufs[] = {h->log_odds, h->occupancy, h->occ_i8, h->hits, h->miss, h->clip_end, h->hit8, h->ray_list, h->ray_count,
-                  h->ray_stats, h->scratch_i32, h->d_dbg, h->hitN2, h->clipN2, h->hitT2, h->clipT2, h->d_rects2, h->missT, h->hitN, h->clipN, h->hitT, h->clipT, h->cx, h->cy, h->cz, h->tx, h->ty, h->tz, h->raw, h->cell_idx,
+                  h->ray_stats, h->scratch_i32, h->d_dbg, h->hitN2, h->clipN2, h->hitT2, h->clipT2, h->d_rects2, h->miss2, h->missT2, h->missT, h->hitN, h->clipN, h->hitT, h->clipT, h->cx, h->cy, h->cz, h->tx, h->ty, h->tz, h->raw, h->cell_idx,
                   h->bbox_id, h->d_bboxes, h->d_poses, h->d_rects, h->d_orient, h->d_conf, h->d_dims, h->d_vout,
                   h->d_pts, h->d_bbox_f, h->d_tile_mask, h->knn_partial, h->d_depths, h->d_knn_d2, h->d_idx, h->d_segof,
                   h->d_segstart, h->gx, h->gy, h->gz, h->d_keep, h->d_planes, h->d_plane_counts, h->d_ground};
@@ -846,7 +866,9 @@ int gv_destroy(gv_handle h)
   for (int i = 0; i < 2; ++i) {
     if (h->ev_build[i]) (void)hipEventDestroy(h->ev_build[i]);
     if (h->ev_fin[i]) (void)hipEventDestroy(h->ev_fin[i]);
+    if (h->ev_sec[i]) (void)hipEventDestroy(h->ev_sec[i]);
   }
+  if (h->stream3) (void)hipStreamDestroy(h->stream3);
   if (h->stream2) (void)hipStreamDestroy(h->stream2);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
@@ -1349,9 +1371,11 @@ int gv_time_frames(gv_handle h, int32_t frames, float *ms_total)
   GV_HIP(hipEventRecord(e0, h->stream));
   for (int32_t i = 0; i < frames; ++i)
     if ((rc = gv_frame_enqueue(h))) return rc;
-  if (h->pipe_busy) {   // join stream B into stream A before the closing event
+  if (h->pipe_busy) {   // join streams B and C into stream A before the closing event
     GV_HIP(hipEventRecord(h->ev[1], h->stream2));
     GV_HIP(hipStreamWaitEvent(h->stream, h->ev[1], 0));
+    GV_HIP(hipEventRecord(h->ev[2], h->stream3));
+    GV_HIP(hipStreamWaitEvent(h->stream, h->ev[2], 0));
   }
   GV_HIP(hipEventRecord(e1, h->stream));
   GV_HIP(hipEventSynchronize(e1));

@@ -152,16 +152,31 @@ __global__ void __launch_bounds__(COUNTS ? 1024 : 256) k_points(PointsArgs a)
     for (int k = threadIdx.x; k < kHitSlots; k += blockDim.x) { s_key[k] = kHitEmpty; s_cnt[k] = 0; }
     __syncthreads();
   }
+  // Out-of-map points (a minority) need the fp64 slab clip, ~10x the work of an in-map point: they
+  // are compacted through LDS so that the clip runs on dense lanes of as few wavefronts as
+  // possible instead of on a few lanes of every wavefront.
+  constexpr bool CLIP = BIN && RAY;
+  constexpr int kMaxThreads = COUNTS ? 1024 : 256;
+  __shared__ float2 s_out[CLIP ? kMaxThreads : 1];
+  __shared__ unsigned s_nout;
   const uint32_t stride = gridDim.x * blockDim.x;
-  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += stride) {
-    const float px = a.x[i], py = a.y[i], pz = a.z[i];
+  for (uint32_t base = blockIdx.x * blockDim.x; base < a.n; base += stride) {   // uniform per workgroup
+    const uint32_t i = base + threadIdx.x;
+    const bool live = i < a.n;
+    if (CLIP) {
+      if (threadIdx.x == 0) s_nout = 0;
+      __syncthreads();
+    }
+    float px = 0.f, py = 0.f, pz = 0.f;
+    if (live) { px = a.x[i]; py = a.y[i]; pz = a.z[i]; }
     if (BIN) {
       float bx, by, bz;
       xform34(a.m_base, px, py, pz, bx, by, bz);
       int cell = -1;
-      if (isfinite(bx) && isfinite(by) && isfinite(bz)) {
+      bool outside = false;
+      if (live && isfinite(bx) && isfinite(by) && isfinite(bz)) {
         int ix, iy;
-        if (get_index_fast(a.g, (double)bx, (double)by, ix, iy)) {
+        if ((a.ablate & 32) ? false : get_index_fast(a.g, (double)bx, (double)by, ix, iy)) {
           cell = iy * a.g.nx + ix;
           if (COUNTS) {
             const unsigned slot = ((unsigned)cell * 2654435761u) >> 20;   // 12 bits
@@ -169,28 +184,36 @@ __global__ void __launch_bounds__(COUNTS ? 1024 : 256) k_points(PointsArgs a)
             if (old == kHitEmpty || old == (unsigned)cell) atomicAdd(&s_cnt[slot], 1u);
             else atomicAdd(&a.hits[cell], 1);   // no-return global_atomic_add
           } else {
-            a.hit8[cell] = 1;   // idempotent byte store
+            if (!(a.ablate & 1)) a.hit8[cell] = 1;   // idempotent byte store
           }
         } else if (RAY && a.org.valid) {
-          int ex, ey;
-          clip_ray_end(a.g, a.org, (double)bx, (double)by, ex, ey);
-          a.clip_end[ey * a.g.nx + ex] = 1;   // idempotent byte store
+          outside = true;
         }
       }
-      if (KEEPCELL) a.cell_idx[i] = cell;
+      if (CLIP) {
+        const unsigned long long bm = __ballot(outside);
+        if (bm) {
+          const int lane = threadIdx.x & 63;
+          unsigned wbase = 0;
+          if (lane == 0) wbase = atomicAdd(&s_nout, (unsigned)__popcll(bm));
+          wbase = (unsigned)__builtin_amdgcn_readfirstlane((int)wbase);
+          if (outside) s_out[wbase + (unsigned)__popcll(bm & ((1ull << lane) - 1ull))] = make_float2(bx, by);
+        }
+      }
+      if (KEEPCELL && live) a.cell_idx[i] = cell;
     }
     if (BBOX) {
       float cx, cy, cz;
       xform34(a.m_cam, px, py, pz, cx, cy, cz);
       int id = -1;
       // :264 pcl::isFinite(pt) && pt.z > 0.001f
-      if (isfinite(cx) && isfinite(cy) && isfinite(cz) && !(cz <= 0.001f)) {
+      if (live && isfinite(cx) && isfinite(cy) && isfinite(cz) && !(cz <= 0.001f) && !(a.ablate & 16)) {
         const double X = (double)cx, Y = (double)cy, Z = (double)cz;
         const double iz = krow(a.cam.k, 2, X, Y, Z);
         const double riz = rcp_newton(iz);
         const float u = div_to_float(krow(a.cam.k, 0, X, Y, Z), iz, riz);   // :268-272  (float)(n / iz)
         const float v = div_to_float(krow(a.cam.k, 1, X, Y, Z), iz, riz);   // :273
-        if (!(u < 0 || u >= (float)a.cam.W || v < 0 || v >= (float)a.cam.H)) {   // :276
+        if (!(u < 0 || u >= (float)a.cam.W || v < 0 || v >= (float)a.cam.H) && !(a.ablate & 4)) {   // :276
           // :280-288 first match wins.  The reference compares (double)u against the
           // double bounds; bbox_f holds the float thresholds with the identical truth
           // table (host: smallest float >= x_min, largest float <= x_max), and the
@@ -211,7 +234,18 @@ __global__ void __launch_bounds__(COUNTS ? 1024 : 256) k_points(PointsArgs a)
           }
         }
       }
-      a.bbox_id[i] = id;
+      if (live && !(a.ablate & 2)) a.bbox_id[i] = id;
+    }
+    if (CLIP) {
+      __syncthreads();
+      const unsigned nout = (a.ablate & 8) ? 0u : s_nout;
+      for (unsigned k = threadIdx.x; k < nout; k += blockDim.x) {
+        const float2 p = s_out[k];
+        int ex, ey;
+        clip_ray_end(a.g, a.org, (double)p.x, (double)p.y, ex, ey);
+        a.clip_end[ey * a.g.nx + ex] = 1;   // idempotent byte store
+      }
+      __syncthreads();   // the list is reused by the next chunk
     }
   }
   if (CACHE) {
@@ -223,9 +257,11 @@ __global__ void __launch_bounds__(COUNTS ? 1024 : 256) k_points(PointsArgs a)
   }
 }
 
-void launch_points(const PointsArgs &a, hipStream_t s)
+void launch_points(const PointsArgs &a_in, hipStream_t s)
 {
-  if (a.n == 0) return;
+  if (a_in.n == 0) return;
+  PointsArgs a = a_in;
+  { static const int ab = [] { const char *e = std::getenv("GV_POINTS_ABLATE"); return e ? std::atoi(e) : 0; }(); a.ablate = ab; }
   // counting: 8192 points per 1024-thread workgroup (measured best of 2k..16k) so that the LDS hit cache sees the
   // duplicates of the hot cells; byte marking / bbox-only: plain streaming configuration
   const bool cache = a.do_bin && a.counts;

@@ -28,6 +28,7 @@ struct PointsArgs {
   int32_t *cell_idx;   // N or null
   int32_t *bbox_id;    // N or null
   bool do_bin, do_ray, do_bbox, counts;
+  int32_t ablate;      // timing experiments only (GV_POINTS_ABLATE)
 };
 void launch_points(const PointsArgs &a, hipStream_t s);
 
