@@ -252,7 +252,7 @@ def main():
         # (2 bits/cell in both orientations = G/2 B) and one miss byte per cell out.
         alg = {"points": 12.0 * N, "ray_ends": 5.0 * G, "ray_march": 1.5 * G, "finalize": 13.0 * G,
                "detections": 120.0 * (len(bboxes) + len(poses))}
-        kern = {"points": "k_points", "ray_ends": "k_build_bitmaps", "ray_march": "k_ray_sectors",
+        kern = {"points": "k_points", "ray_ends": "k_build_bitmaps8", "ray_march": "k_ray_sectors",
                 "finalize": "k_finalize_tiles", "detections": "k_rects_from_poses"}
         dom = max(stages, key=stages.get)
         kernels = [{"stage": k, "kernel": kern[k], "ms": stages[k], "algorithmic_bytes": alg[k],
