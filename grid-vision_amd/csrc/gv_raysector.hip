@@ -347,6 +347,30 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
     return mx;
   };
 
+  // one cell (column i, minor offset jc), exactly: whole buckets between its two boundary buckets by
+  // range-max, the boundary buckets themselves end by end
+  auto cell_exact = [&](int i, int Q, int jc) -> bool {
+    const int Plo = 2 * jc - 1, Phi = 2 * jc + 1;
+    const int lo = bucket_of_boundary(Plo, Q), hi = bucket_of_boundary(Phi, Q);   // lo < hi unless both outside
+    unsigned mx = 0;
+    const int l = lo + 1, r = min(hi - 1, M - 1);
+    if (l <= r) mx = rmq(l, r);
+    if (mx <= (unsigned)i && lo >= 0 && lo < M) {
+      for (unsigned e = bstart[lo]; e < bstart[lo + 1]; ++e) {
+        const unsigned p = abv[e];
+        const int a = ab_a(p), bq = ab_b(p) * Q;
+        if (bq >= Plo * a && (hi != lo || bq < Phi * a)) mx = max(mx, (unsigned)(a + (int)(p & 1u)));
+      }
+    }
+    if (mx <= (unsigned)i && hi >= 0 && hi < M && hi != lo) {
+      for (unsigned e = bstart[hi]; e < bstart[hi + 1]; ++e) {
+        const unsigned p = abv[e];
+        const int a = ab_a(p);
+        if (ab_b(p) * Q < Phi * a) mx = max(mx, (unsigned)(a + (int)(p & 1u)));
+      }
+    }
+    return mx > (unsigned)i;
+  };
   // minor-offset range [blo, bhi] of the wedge in column a (empty when blo > bhi)
   auto col_bounds = [&](int a, int &blo, int &bhi) {
     const int bmaxa = oc.xmaj ? a : a - 1;
@@ -441,6 +465,32 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
   // highest level of aligned bucket groups a column of this wedge can ask for
   const int tqmax = (2 * oc.imax + S - 1) >> A.log2s;
   const int lv_max = (tqmax <= 1) ? 0 : 32 - __clz(tqmax - 1);
+  // Lattice gaps.  Ends are integer points (a, b), a <= imax, so no end has a slope strictly
+  // within 1/(q*imax) of a rational p/q without being p/q itself.  A sector that starts at slope 0
+  // or 1/2 (ends at 1/2 or 1) therefore has a run of slope buckets next to that boundary that is
+  // empty whatever the cloud: Z*M buckets, Z = S/(q*imax).  The "every aligned bucket group holds a
+  // long ray" test must not count groups inside such a run (they would pin T at 512 or 1024 for good,
+  // and those 16 workgroups would run 2.5x the mean), and because a run is narrower than one cell
+  // (1/(q*imax) <= 1/i) only the cell next to the edge cell can reach into it: that one is
+  // evaluated exactly below (cell 1 resp. w-2), like the edge cells themselves.
+  int xb0 = 0, xb1 = 0, xt0 = 0, xt1 = 0;   // excluded buckets [xb0, xb1) at the bottom, [xt0, xt1) at the top
+  if (S >= 8) {
+    const long long SM = (long long)S << LM;
+    const int qlo = (s == 0) ? 1 : ((s == (S >> 1)) ? 2 : 0);
+    const int qhi = (s == S - 1) ? 1 : ((s == (S >> 1) - 1) ? 2 : 0);
+    if (qlo) {   // bucket k lies inside (0, Z) iff k + 1 <= Z*M; bucket 0 also holds the rational itself
+      xb0 = (s == 0 && oc.bmin == 1) ? 0 : 1;
+      xb1 = (int)min((long long)M, SM / ((long long)qlo * oc.imax));
+    }
+    if (qhi) {   // bucket k lies inside (1 - Z, 1) iff k > M - Z*M; the last bucket of sector S-1 holds slope 1
+      const long long c = (SM + (long long)qhi * oc.imax - 1) / ((long long)qhi * oc.imax);   // ceil(Z*M)
+      xt0 = (int)max(0ll, (long long)M - c + 1);
+      xt1 = (s == S - 1) ? M - 1 : M;
+    }
+  }
+  auto gap_group = [&](int g0, int size) -> bool {   // aligned group [g0, g0+size) entirely inside a gap run
+    return (g0 >= xb0 && g0 + size <= xb1) || (g0 >= xt0 && g0 + size <= xt1);
+  };
   auto process_group = [&](unsigned rowmask, int wsel, bool first) {
     const bool mine_w = (wsel < 0) || (wave == wsel);
     unsigned mycnt, incl;
@@ -535,7 +585,7 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
       // inside one block; coarser levels are read off s_blkmax at query time.
       // only levels Lv <= lv_max are ever queried (2^Lv >= 2i/S, i <= imax)
       if (LM <= lv_max) {
-        const unsigned mn = wave_min((m < M) ? v : 0xFFFFFFFFu);
+        const unsigned mn = wave_min((m < M && !gap_group(m, 1)) ? v : 0xFFFFFFFFu);
         if (lane == 0) s_lvlmin[LM * 8 + wave] = mn;
       }
 #pragma unroll
@@ -554,7 +604,7 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
         v = max(v, up);
         if (m < M) lvl[l * M + m] = (unsigned short)v;
         if (l <= LM && LM - l <= lv_max) {
-          const unsigned mn = wave_min(((lane & ((1 << l) - 1)) == 0 && m < M) ? v : 0xFFFFFFFFu);
+          const unsigned mn = wave_min(((lane & ((1 << l) - 1)) == 0 && m < M && !gap_group(m, 1 << l)) ? v : 0xFFFFFFFFu);
           if (lane == 0) s_lvlmin[(LM - l) * 8 + wave] = mn;
         }
       }
@@ -622,14 +672,17 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
         if (l <= 6) {
           lm = (unsigned)__builtin_amdgcn_readlane((int)vmin, l * 8 + 7);
         } else if (l == 7) {   // groups of 2 whole blocks
-          lm = q01;
-          if (NB > 2) lm = min(lm, q23);
-          if (NB > 4) lm = min(min(lm, q45), q67);
+          lm = gap_group(0, 128) ? 0xFFFFFFFFu : q01;
+          if (NB > 2 && !gap_group(128, 128)) lm = min(lm, q23);
+          if (NB > 4) {
+            if (!gap_group(256, 128)) lm = min(lm, q45);
+            if (!gap_group(384, 128)) lm = min(lm, q67);
+          }
         } else if (l == 8) {   // groups of 4 whole blocks
-          lm = max(q01, q23);
-          if (NB > 4) lm = min(lm, max(q45, q67));
+          lm = gap_group(0, 256) ? 0xFFFFFFFFu : max(q01, q23);
+          if (NB > 4 && !gap_group(256, 256)) lm = min(lm, max(q45, q67));
         } else {               // one group: everything
-          lm = maxreach0;
+          lm = gap_group(0, 512) ? 0xFFFFFFFFu : maxreach0;
         }
         // columns whose cell width asks for level Lv: ceil(2i/S) in (2^(Lv-1), 2^Lv]
         const int hiL = min(oc.imax, (Lv == 0) ? (S >> 1) : (int)(((long long)S << Lv) >> 1));
@@ -759,6 +812,9 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
         }
         if (mxh > (unsigned)i) mask |= 1u;
         if (mxl > (unsigned)i) mask |= 1u << (w - 1);
+        // sectors with a lattice-gap run: the cell next to the edge cell is not covered by the level test
+        if (xb0 < xb1 && !cell_exact(i, Q, jlo + 1)) mask &= ~2u;
+        if (xt0 < xt1 && !cell_exact(i, Q, jhi - 1)) mask &= ~(1u << (w - 2));
       } else {
         int lo = -1;             // bucket holding the cell's lower boundary (-1: below the sector)
         unsigned above = 0;      // max reach of the ends of bucket `lo` at or above that boundary
