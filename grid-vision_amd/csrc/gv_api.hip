@@ -61,6 +61,7 @@ struct gv_context {
   int32_t last_log2s = 0, last_cap = 0;
   unsigned long long *d_dbg = nullptr;      // GV_SECTOR_DBG=1: phase stamps of the sector kernel
   size_t stat_slots = 1;                    // ray_stats slots written by the last frame
+  int32_t env_log2s_oct[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // GV_LOG2S_OCT="a,b,..." per octant index (experiments)
   int32_t env_log2s = 0, env_cap = 0, env_ablate = 0, env_log2m = 0;   // GV_LOG2S / GV_CAP / GV_ABLATE (experiments)
 
   // resident cloud
@@ -294,48 +295,62 @@ int fill_sector_args(gv_context *h, SectorArgs &sa)
 {
   sa.g = h->g;
   sa.org = h->org;
-  // sectors per octant: wedge width <= 32 cells (imax <= 30*S) and ~<= cap ends per sector
   const int imax = std::max(std::max(h->org.cx, h->g.nx - 1 - h->org.cx), std::max(h->org.cy, h->g.ny - 1 - h->org.cy));
-  // Measured on config 3 (tools/sweep_sectors.sh): 128 sectors per octant with 4096-end
-  // LDS chunks beats 256 x 2048 (62 vs 79 us): the kernel is bound by per-workgroup
-  // latency chains, so fewer, fatter wedges win as long as a wedge fits one chunk.
-  int log2s = 7;
-  while ((30 << log2s) < imax) ++log2s;
-  const double dens = std::min((double)h->n, (double)h->g.G) / (double)h->g.G;
-  double est = 1.5 * dens * (double)imax * (double)imax / (double)(2 << log2s);
-  while (est > 5000.0 && log2s < 12) {
-    ++log2s;
-    est *= 0.5;
+  // octant o: xmaj = bit 2, smaj = bit 1; wedge length = distance to the map edge along the major axis
+  int len[8], ord[8];
+  for (int o = 0; o < 8; ++o) {
+    const bool xmaj = (o >> 2) & 1, pos = (o >> 1) & 1;
+    len[o] = xmaj ? (pos ? h->g.nx - 1 - h->org.cx : h->org.cx) : (pos ? h->g.ny - 1 - h->org.cy : h->org.cy);
+    ord[o] = o;
   }
-  if (h->env_log2s > 0) log2s = h->env_log2s;
-  sa.log2s = log2s;
-  sa.cap = h->env_cap > 0 ? std::max(2048, h->env_cap) : ((est <= 1700.0 && h->env_log2s <= 0) ? 2048 : 4096);
+  // Sectors per octant: the far end of a wedge about 16 cells wide (len <= 16*S; the kernel needs
+  // <= 32) and an estimated <= 5000 ends per sector so that a wedge fits one LDS chunk.  Measured on
+  // config 3 (tools/sweep_oct.sh, tools/sweep_sectors.sh): the kernel is bound by per-workgroup
+  // latency chains, so fewer, fatter wedges win as long as those two hold, and an octant whose wedge
+  // is short (origin near that map edge) gets proportionally fewer sectors: 128/64/32 sectors for
+  // wedges of 1660/1000/340 columns instead of 128 everywhere does the same frame in 576 instead of
+  // 1024 workgroups, 84 -> 76 us pipelined.  Wider wedges (S = 16 for 340 columns) lose again.
+  const double dens = std::min((double)h->n, (double)h->g.G) / (double)h->g.G;
+  double est_max = 0.0;
+  int log2s_max = 0;
+  for (int o = 0; o < 8; ++o) {
+    int l2 = 3;   // the gap-sector logic wants S >= 8
+    while ((16 << l2) < len[o]) ++l2;
+    double est = 1.5 * dens * (double)len[o] * (double)len[o] / (double)(2 << l2);
+    while (est > 5000.0 && l2 < 12) {
+      ++l2;
+      est *= 0.5;
+    }
+    if (h->env_log2s > 0) { l2 = h->env_log2s; est = 1.5 * dens * (double)len[o] * (double)len[o] / (double)(2 << l2); }
+    if (h->env_log2s_oct[o] > 0) { l2 = h->env_log2s_oct[o]; est = 1.5 * dens * (double)len[o] * (double)len[o] / (double)(2 << l2); }
+    sa.log2s_oct[o] = (uint8_t)l2;
+    est_max = std::max(est_max, est);
+    log2s_max = std::max(log2s_max, l2);
+  }
+  sa.cap = h->env_cap > 0 ? std::max(2048, h->env_cap) : ((est_max <= 1700.0 && h->env_log2s <= 0) ? 2048 : 4096);
   sa.ablate = h->env_ablate;
   sa.dbg = h->d_dbg;
   sa.log2m = h->env_log2m > 0 ? h->env_log2m : 9;
-  while (sa.log2m < 9 && ((1 << sa.log2m) << sa.log2s) <= imax) ++sa.log2m;   // one boundary per bucket
   sa.marks_words = (imax + 3) & ~1;   // one word per wedge column, 0..imax
-  {
-    // octant o: xmaj = bit 2, smaj = bit 1; wedge length = distance to the map edge along the major axis
-    int len[8], ord[8];
-    for (int o = 0; o < 8; ++o) {
-      const bool xmaj = (o >> 2) & 1, pos = (o >> 1) & 1;
-      len[o] = xmaj ? (pos ? h->g.nx - 1 - h->org.cx : h->org.cx) : (pos ? h->g.ny - 1 - h->org.cy : h->org.cy);
-      ord[o] = o;
-    }
-    std::stable_sort(ord, ord + 8, [&](int a, int b) { return len[a] > len[b]; });
-    sa.oct_perm = 0;
-    for (int k = 0; k < 8; ++k) sa.oct_perm |= (uint32_t)ord[k] << (3 * k);
-    sa.reorder = h->env_reorder;
+  std::stable_sort(ord, ord + 8, [&](int a, int b) { return len[a] > len[b]; });
+  sa.oct_perm = 0;
+  sa.reorder = h->env_reorder;
+  uint32_t base = 0;
+  for (int k = 0; k < 8; ++k) {
+    sa.oct_perm |= (uint32_t)ord[k] << (3 * k);
+    sa.wg_base[k] = (uint16_t)base;
+    base += 1u << sa.log2s_oct[sa.reorder ? ord[k] : k];
   }
+  if (base > kMaxStatSlots || base > 65535u) { h->err = "too many sector workgroups"; return GV_ERR_BAD_ARG; }
+  sa.wg_base[8] = (uint16_t)base;
   sa.hitN = h->hitN; sa.clipN = h->clipN; sa.hitT = h->hitT; sa.clipT = h->clipT;
   sa.nxw = h->nxw; sa.nyw = h->nyw; sa.nx_pad = h->nx_pad; sa.ny_pad = h->ny_pad;
   sa.missN = h->miss;
   sa.missT = h->missT;
   sa.stats = h->ray_stats;
-  h->last_log2s = sa.log2s;
+  h->last_log2s = log2s_max;
   h->last_cap = sa.cap;
-  h->stat_slots = (size_t)8 << sa.log2s;
+  h->stat_slots = (size_t)sa.wg_base[8];
   return GV_OK;
 }
 
@@ -822,6 +837,14 @@ int gv_create(gv_handle *out, uint8_t grid_x, uint8_t grid_y, double resolution,
     if (const char *e = std::getenv("GV_PIPELINE")) { h->no_pipeline = std::atoi(e) == 0; h->three_streams = std::atoi(e) != 2; }
     if (const char *e = std::getenv("GV_HIT_COUNTS")) h->force_counts = std::atoi(e) != 0;
     if (const char *e = std::getenv("GV_LOG2S")) h->env_log2s = std::atoi(e);
+    if (const char *e = std::getenv("GV_LOG2S_OCT")) {
+      int k = 0;
+      for (const char *q = e; *q && k < 8; ++k) {
+        h->env_log2s_oct[k] = std::atoi(q);
+        while (*q && *q != ',') ++q;
+        if (*q == ',') ++q;
+      }
+    }
     if (const char *e = std::getenv("GV_SECTOR_REORDER")) h->env_reorder = std::atoi(e) != 0;
     if (const char *e = std::getenv("GV_CAP")) h->env_cap = std::atoi(e);
     if (const char *e = std::getenv("GV_ABLATE")) h->env_ablate = std::atoi(e);

@@ -90,7 +90,8 @@ void launch_build_bitmaps(const BitmapArgs &a, hipStream_t s);
 struct SectorArgs {
   GridParams g;
   RayOrigin org;
-  int32_t log2s;          // sectors per octant = 1 << log2s
+  uint8_t log2s_oct[8];   // sectors of octant o = 1 << log2s_oct[o]: short wedges get fewer, fatter sectors
+  uint16_t wg_base[9];    // first workgroup of the k-th octant in dispatch order (oct_perm); [8] = grid size
   int32_t cap;            // ends per LDS chunk (>= 2048)
   int32_t log2m;          // slope buckets per sector = 1 << log2m (<= 9)
   int32_t marks_words;    // >= max(nx, ny) + 1

@@ -248,21 +248,24 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
   extern __shared__ __align__(16) unsigned char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
-  const int S = 1 << A.log2s;
   // Dispatch order (workgroups start roughly in blockIdx order and the launch is ~2 rounds deep):
   // octants with the longest wedges first, and inside an octant the sectors next to the slopes
-  // 0, 1/2, 1 first -- the lattice has gaps there, their threshold T stays low and they run long.
-  int o = blockIdx.x >> A.log2s;
-  int s = blockIdx.x & (S - 1);
-  if (A.reorder) {
-    o = (int)(A.oct_perm >> (3 * o)) & 7;
-    if (S >= 8) {
-      const int r = s;
-      if (r < 4) s = (r == 0) ? 0 : (r == 1) ? (S >> 1) - 1 : (r == 2) ? S - 1 : (S >> 1);
-      else s = (r - 4 < (S >> 1) - 2) ? r - 3 : r - 1;
-    }
+  // 0, 1/2, 1 first (they run longest).  Every octant has its own sector count: a short wedge
+  // (origin close to that map edge) split into as many sectors as a long one would be all
+  // fixed per-workgroup cost and no ends.
+  int k_oct = 0;
+#pragma unroll
+  for (int k = 1; k < 8; ++k) k_oct += ((int)blockIdx.x >= (int)A.wg_base[k]) ? 1 : 0;
+  const int o = A.reorder ? ((int)(A.oct_perm >> (3 * k_oct)) & 7) : k_oct;
+  const int log2s = A.log2s_oct[o];
+  const int S = 1 << log2s;
+  int s = (int)blockIdx.x - (int)A.wg_base[k_oct];
+  if (A.reorder && S >= 8) {
+    const int r = s;
+    if (r < 4) s = (r == 0) ? 0 : (r == 1) ? (S >> 1) - 1 : (r == 2) ? S - 1 : (S >> 1);
+    else s = (r - 4 < (S >> 1) - 2) ? r - 3 : r - 1;
   }
-  const int wg = (o << A.log2s) | s;   // logical workgroup id (diagnostics)
+  const int wg = blockIdx.x;   // diagnostics slot
   // a clipped ray that ends in the origin cell itself (a == 0, inclusive end)
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     const unsigned wbit = A.clipN[(size_t)(A.org.cx >> 5) * A.ny_pad + A.org.cy] >> (A.org.cx & 31);
@@ -299,6 +302,7 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
     ++stamp_n;
   };
   stamp();
+  if (A.dbg && tid == 0) A.dbg[(size_t)wg * 16 + 14] = ((unsigned long long)o << 32) | (unsigned)s | ((unsigned long long)log2s << 40);
   for (int i = tid; i <= oc.imax; i += NT) marks[i] = 0;
   if (tid < NT / 64) s_wvis[tid] = 0;
   for (int m = tid; m < M; m += NT) { cnt[m] = 0; bmax32[m] = 0; }
@@ -374,8 +378,8 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
   // minor-offset range [blo, bhi] of the wedge in column a (empty when blo > bhi)
   auto col_bounds = [&](int a, int &blo, int &bhi) {
     const int bmaxa = oc.xmaj ? a : a - 1;
-    blo = (a * s + S - 1) >> A.log2s;
-    bhi = ((a * (s + 1) + S - 1) >> A.log2s) - 1;
+    blo = (a * s + S - 1) >> log2s;
+    bhi = ((a * (s + 1) + S - 1) >> log2s) - 1;
     if (s == S - 1) bhi = bmaxa;
     blo = max(blo, oc.bmin);
     bhi = min(min(bhi, bmaxa), oc.jmaxo);
@@ -463,7 +467,7 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
   // One group = the ends of the selected (row c, wavefront) sets; at most cap of them.
   // rowmask: rows taking part; wsel: -1 = every wavefront, else only that one.
   // highest level of aligned bucket groups a column of this wedge can ask for
-  const int tqmax = (2 * oc.imax + S - 1) >> A.log2s;
+  const int tqmax = (2 * oc.imax + S - 1) >> log2s;
   const int lv_max = (tqmax <= 1) ? 0 : 32 - __clz(tqmax - 1);
   // Lattice gaps.  Ends are integer points (a, b), a <= imax, so no end has a slope strictly
   // within 1/(q*imax) of a rational p/q without being p/q itself.  A sector that starts at slope 0
@@ -750,7 +754,7 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
             const int rem = num - q * a;
             if (rem < 0) --q;
             else if (rem >= a) ++q;
-            const int bit = q - ((2 * i * s + S) >> (A.log2s + 1));
+            const int bit = q - ((2 * i * s + S) >> (log2s + 1));
             atomicOr(&marks[i], 1u << bit);
           }
         }
@@ -766,8 +770,8 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
         continue;
       }
       if ((unsigned)i >= maxreach) continue;   // no ray of this group gets this far
-      const int jlo = (2 * i * s + S) >> (A.log2s + 1);
-      const int jhi = (2 * i * (s + 1) + S) >> (A.log2s + 1);
+      const int jlo = (2 * i * s + S) >> (log2s + 1);
+      const int jhi = (2 * i * (s + 1) + S) >> (log2s + 1);
       const int w = jhi - jlo + 1;
       const int Q = 2 * i;
       // a cell interval (width 1/i in slope) fully contains an aligned group of level Lv
@@ -879,7 +883,7 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
   for (int i = tid; i <= ((A.ablate & 4) ? -1 : oc.imax); i += NT) {
     unsigned w = marks[i];
     if (!w) continue;
-    const int jlo = (2 * i * s + S) >> (A.log2s + 1);
+    const int jlo = (2 * i * s + S) >> (log2s + 1);
     const int major_abs = oc_major + oc.smaj * i;
     while (w) {
       const int t = __ffs(w) - 1;
@@ -917,11 +921,11 @@ void launch_ray_sectors(const SectorArgs &a, hipStream_t s)
   const int imax = std::max(std::max(a.org.cx, a.g.nx - 1 - a.org.cx), std::max(a.org.cy, a.g.ny - 1 - a.org.cy));
   // every wedge column lives in a register slot of one thread: CH * 512 >= imax
   if (imax <= 4 * kSecThreads)
-    hipLaunchKernelGGL(k_ray_sectors<4>, dim3(8u << a.log2s), dim3(kSecThreads), lds, s, a);
+    hipLaunchKernelGGL(k_ray_sectors<4>, dim3(a.wg_base[8]), dim3(kSecThreads), lds, s, a);
   else if (imax <= 8 * kSecThreads)
-    hipLaunchKernelGGL(k_ray_sectors<8>, dim3(8u << a.log2s), dim3(kSecThreads), lds, s, a);
+    hipLaunchKernelGGL(k_ray_sectors<8>, dim3(a.wg_base[8]), dim3(kSecThreads), lds, s, a);
   else
-    hipLaunchKernelGGL(k_ray_sectors<16>, dim3(8u << a.log2s), dim3(kSecThreads), lds, s, a);
+    hipLaunchKernelGGL(k_ray_sectors<16>, dim3(a.wg_base[8]), dim3(kSecThreads), lds, s, a);
 }
 
 // ------------------------------------------------------ tile grid pass -----
