@@ -665,33 +665,34 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
     }
     int T0 = 0;
     {
-      bool open = true;
+      // lane Lv holds level Lv: its minimum over (non-gap) groups and the last column hiL that asks
+      // for it (ceil(2i/S) in (2^(Lv-1), 2^Lv]); the first level whose minimum does not clear hiL
+      // ends the run of "every interior cell free" columns
       const int lv_top = min(lv_max, LM);
       const unsigned q01 = max(bm[0], bm[1]), q23 = max(bm[2], bm[3]), q45 = max(bm[4], bm[5]), q67 = max(bm[6], bm[7]);
-#pragma unroll
-      for (int Lv = 0; Lv <= 9; ++Lv) {
-        if (Lv > lv_top || !open) continue;
-        unsigned lm;
-        const int l = LM - Lv;
-        if (l <= 6) {
-          lm = (unsigned)__builtin_amdgcn_readlane((int)vmin, l * 8 + 7);
-        } else if (l == 7) {   // groups of 2 whole blocks
-          lm = gap_group(0, 128) ? 0xFFFFFFFFu : q01;
-          if (NB > 2 && !gap_group(128, 128)) lm = min(lm, q23);
-          if (NB > 4) {
-            if (!gap_group(256, 128)) lm = min(lm, q45);
-            if (!gap_group(384, 128)) lm = min(lm, q67);
-          }
-        } else if (l == 8) {   // groups of 4 whole blocks
-          lm = gap_group(0, 256) ? 0xFFFFFFFFu : max(q01, q23);
-          if (NB > 4 && !gap_group(256, 256)) lm = min(lm, max(q45, q67));
-        } else {               // one group: everything
-          lm = gap_group(0, 512) ? 0xFFFFFFFFu : maxreach0;
-        }
-        // columns whose cell width asks for level Lv: ceil(2i/S) in (2^(Lv-1), 2^Lv]
-        const int hiL = min(oc.imax, (Lv == 0) ? (S >> 1) : (int)(((long long)S << Lv) >> 1));
-        if (lm > (unsigned)hiL) T0 = hiL;
-        else { T0 = max(T0, min(hiL, (int)lm - 1)); open = false; }
+      unsigned lm7 = gap_group(0, 128) ? 0xFFFFFFFFu : q01;   // groups of 2 whole blocks
+      if (NB > 2 && !gap_group(128, 128)) lm7 = min(lm7, q23);
+      if (NB > 4) {
+        if (!gap_group(256, 128)) lm7 = min(lm7, q45);
+        if (!gap_group(384, 128)) lm7 = min(lm7, q67);
+      }
+      unsigned lm8 = gap_group(0, 256) ? 0xFFFFFFFFu : max(q01, q23);   // groups of 4 whole blocks
+      if (NB > 4 && !gap_group(256, 256)) lm8 = min(lm8, max(q45, q67));
+      const unsigned lm9 = gap_group(0, 512) ? 0xFFFFFFFFu : maxreach0;   // one group: everything
+      const int Lv = lane, l = LM - Lv;
+      const unsigned fine = (unsigned)__shfl((int)vmin, (l >= 0 && l <= 6) ? l * 8 + 7 : 0);
+      const unsigned lmv = (l <= 6) ? fine : (l == 7) ? lm7 : (l == 8) ? lm8 : lm9;
+      const int hiL = min(oc.imax, (Lv == 0) ? (S >> 1) : (int)(((long long)S << min(Lv, 20)) >> 1));
+      const bool valid = Lv <= lv_top;
+      const unsigned long long failm = __ballot(valid && !(lmv > (unsigned)hiL));
+      if (failm == 0ull) {
+        T0 = __builtin_amdgcn_readlane(hiL, lv_top);
+      } else {
+        const int f = __ffsll((long long)failm) - 1;
+        const int prev = (f > 0) ? __builtin_amdgcn_readlane(hiL, f - 1) : 0;
+        const int hf = __builtin_amdgcn_readlane(hiL, f);
+        const int lf = __builtin_amdgcn_readlane((int)lmv, f);
+        T0 = max(prev, min(hf, lf - 1));
       }
       if (A.ablate & 64) T0 = 0;
     }

@@ -83,6 +83,9 @@ def load(build_if_missing: bool = True):
     global _LIB
     if _LIB is None:
         path = _build.build() if build_if_missing else _build.LIB
+        alt = os.environ.get("GV_LIB_AB")   # A/B measurements only: another build of the same library
+        if alt:
+            path = alt
         if not os.path.exists(path):
             raise RuntimeError(f"{path} is missing: build it with hipcc (python -m gvamd.build)")
         _LIB = C.CDLL(path)
