@@ -21,11 +21,14 @@ struct gv_context {
   hipStream_t stream = nullptr;
   // frame pipelining: points/bitmaps of frame f+1 (stream) overlap sectors/grid pass of frame f (stream2)
   hipStream_t stream2 = nullptr, stream3 = nullptr;   // B: sector ray stage, C: grid pass
-  hipEvent_t ev_build[2]{}, ev_sec[2]{}, ev_fin[2]{};
-  uint8_t *miss2 = nullptr, *missT2 = nullptr;        // second set of miss grids (pipelined frames alternate)
+  static constexpr int kSets = 4;                     // buffer sets the pipelined frames rotate through (n_sets in use)
+  hipEvent_t ev_build[kSets]{}, ev_sec[kSets]{}, ev_fin[kSets]{};
+  int n_sets = 3;                                     // GV_PIPE_SETS (2..4): how far stream A may run ahead
+  // sets 1..: bitmaps, rectangles and miss grids of the frames in flight (set 0 = the primary buffers)
+  uint32_t *x_hitN[kSets]{}, *x_clipN[kSets]{}, *x_hitT[kSets]{}, *x_clipT[kSets]{};
+  Rect *x_rects[kSets]{};
+  uint8_t *x_miss[kSets]{}, *x_missT[kSets]{};
   bool three_streams = true;                         // GV_PIPELINE=2: grid pass on stream B (two streams)
-  uint32_t *hitN2 = nullptr, *clipN2 = nullptr, *hitT2 = nullptr, *clipT2 = nullptr;   // second bitmap set
-  Rect *d_rects2 = nullptr;
   uint64_t frame_no = 0;
   int since_drain = 0;       // pipelined frames enqueued since both streams were last idle
   bool pipe_busy = false;
@@ -191,7 +194,9 @@ int ensure_det(gv_context *h, int32_t n)
   if ((rc = re(h->d_bboxes, (size_t)want * sizeof(gv_bbox)))) return rc;
   if ((rc = re(h->d_poses, (size_t)want * sizeof(gv_lshape_pose)))) return rc;
   if ((rc = re(h->d_rects, (size_t)want * sizeof(Rect)))) return rc;
-  if ((rc = re(h->d_rects2, (size_t)want * sizeof(Rect)))) return rc;
+  for (int k = 1; k < gv_context::kSets; ++k)
+    if ((rc = re(h->x_rects[k], (size_t)want * sizeof(Rect)))) return rc;
+  h->x_rects[0] = h->d_rects;
   if ((rc = re(h->d_orient, (size_t)want * 4 * sizeof(float)))) return rc;
   if ((rc = re(h->d_conf, (size_t)want * 2 * sizeof(float)))) return rc;
   if ((rc = re(h->d_dims, (size_t)want * 3 * sizeof(float)))) return rc;
@@ -507,12 +512,11 @@ int enqueue_frame_pipelined(gv_context *h)
   if (do_bbox && !h->has_cl) return GV_ERR_TF;
   if (vision && !h->has_bc) return GV_ERR_TF;
   if (h->counts_dirty) { int rc = clear_counts(h); if (rc) return rc; }
-  const int p = (int)(h->frame_no & 1);
+  const int p = (int)(h->frame_no % (unsigned)h->n_sets);
   hipStream_t sA = h->stream, sB = h->stream2;
-  uint32_t *hitN = p ? h->hitN2 : h->hitN, *clipN = p ? h->clipN2 : h->clipN;
-  uint32_t *hitT = p ? h->hitT2 : h->hitT, *clipT = p ? h->clipT2 : h->clipT;
-  Rect *rects = p ? h->d_rects2 : h->d_rects;
-  if (h->since_drain >= 2) GV_HIP(hipStreamWaitEvent(sA, h->ev_fin[p], 0));   // set p is free again
+  uint32_t *hitN = h->x_hitN[p], *clipN = h->x_clipN[p], *hitT = h->x_hitT[p], *clipT = h->x_clipT[p];
+  Rect *rects = h->x_rects[p];
+  if (h->since_drain >= h->n_sets) GV_HIP(hipStreamWaitEvent(sA, h->ev_fin[p], 0));   // set p is free again
 
   int32_t n_rects = 0;
   if (vision && h->nb > 0) {
@@ -561,8 +565,8 @@ int enqueue_frame_pipelined(gv_context *h)
   // the grid pass runs on its own stream: HBM-bound, it overlaps the issue-bound sector kernel of the
   // next frame; the miss grids alternate with the frame parity like the bitmaps do
   hipStream_t sC = h->three_streams ? h->stream3 : sB;
-  uint8_t *missN = p ? h->miss2 : h->miss, *missT = p ? h->missT2 : h->missT;
-  if (h->three_streams && h->since_drain >= 2) GV_HIP(hipStreamWaitEvent(sB, h->ev_fin[p], 0));   // miss set p cleared by its last reader
+  uint8_t *missN = h->x_miss[p], *missT = h->x_missT[p];
+  if (h->three_streams && h->since_drain >= h->n_sets) GV_HIP(hipStreamWaitEvent(sB, h->ev_fin[p], 0));   // miss set p cleared by its last reader
   if (do_ray && h->org.valid) {
     SectorArgs sa{};
     int rc = fill_sector_args(h, sa);
@@ -596,7 +600,7 @@ int enqueue_frame_pipelined(gv_context *h)
   GV_HIP(hipEventRecord(h->ev_fin[p], sC));
   GV_HIP(hipGetLastError());
   h->frame_no++;
-  if (h->since_drain < 2) h->since_drain++;
+  if (h->since_drain < h->n_sets) h->since_drain++;
   h->pipe_busy = true;
   h->counts_dirty = false;
   h->have_counts = false;
@@ -784,7 +788,7 @@ int gv_create(gv_handle *out, uint8_t grid_x, uint8_t grid_y, double resolution,
     GV_C(hipStreamCreateWithPriority(&h->stream2, hipStreamNonBlocking, mode == 2 ? hi : (mode == 1 ? lo : 0)));
     GV_C(hipStreamCreateWithPriority(&h->stream3, hipStreamNonBlocking, mode == 3 ? hi : 0));
   }
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < gv_context::kSets; ++i) {
     GV_C(hipEventCreateWithFlags(&h->ev_build[i], hipEventDisableTiming));
     GV_C(hipEventCreateWithFlags(&h->ev_fin[i], hipEventDisableTiming));
     GV_C(hipEventCreateWithFlags(&h->ev_sec[i], hipEventDisableTiming));
@@ -802,10 +806,14 @@ int gv_create(gv_handle *out, uint8_t grid_x, uint8_t grid_y, double resolution,
   GV_C(hipMalloc(reinterpret_cast<void **>(&h->ray_stats), kMaxStatSlots * 2 * sizeof(unsigned long long)));
   GV_C(hipMalloc(reinterpret_cast<void **>(&h->scratch_i32), G * sizeof(int32_t)));
   GV_C(hipMalloc(reinterpret_cast<void **>(&h->missT), G + 16));
-  GV_C(hipMalloc(reinterpret_cast<void **>(&h->miss2), G + 16));
-  GV_C(hipMalloc(reinterpret_cast<void **>(&h->missT2), G + 16));
-  GV_C(hipMemsetAsync(h->miss2, 0, G + 16, h->stream));
-  GV_C(hipMemsetAsync(h->missT2, 0, G + 16, h->stream));
+  h->x_miss[0] = h->miss;
+  h->x_missT[0] = h->missT;
+  for (int k = 1; k < gv_context::kSets; ++k) {
+    GV_C(hipMalloc(reinterpret_cast<void **>(&h->x_miss[k]), G + 16));
+    GV_C(hipMalloc(reinterpret_cast<void **>(&h->x_missT[k]), G + 16));
+    GV_C(hipMemsetAsync(h->x_miss[k], 0, G + 16, h->stream));
+    GV_C(hipMemsetAsync(h->x_missT[k], 0, G + 16, h->stream));
+  }
   h->nxw = 2 * ((g.nx + 63) / 64);
   h->nyw = 2 * ((g.ny + 63) / 64);
   h->nx_pad = 64 * ((g.nx + 63) / 64);
@@ -820,14 +828,17 @@ int gv_create(gv_handle *out, uint8_t grid_x, uint8_t grid_y, double resolution,
     GV_C(hipMemsetAsync(h->clipN, 0, nN * sizeof(uint32_t), h->stream));
     GV_C(hipMemsetAsync(h->hitT, 0, nT * sizeof(uint32_t), h->stream));
     GV_C(hipMemsetAsync(h->clipT, 0, nT * sizeof(uint32_t), h->stream));
-    GV_C(hipMalloc(reinterpret_cast<void **>(&h->hitN2), nN * sizeof(uint32_t)));
-    GV_C(hipMalloc(reinterpret_cast<void **>(&h->clipN2), nN * sizeof(uint32_t)));
-    GV_C(hipMalloc(reinterpret_cast<void **>(&h->hitT2), nT * sizeof(uint32_t)));
-    GV_C(hipMalloc(reinterpret_cast<void **>(&h->clipT2), nT * sizeof(uint32_t)));
-    GV_C(hipMemsetAsync(h->hitN2, 0, nN * sizeof(uint32_t), h->stream));
-    GV_C(hipMemsetAsync(h->clipN2, 0, nN * sizeof(uint32_t), h->stream));
-    GV_C(hipMemsetAsync(h->hitT2, 0, nT * sizeof(uint32_t), h->stream));
-    GV_C(hipMemsetAsync(h->clipT2, 0, nT * sizeof(uint32_t), h->stream));
+    h->x_hitN[0] = h->hitN; h->x_clipN[0] = h->clipN; h->x_hitT[0] = h->hitT; h->x_clipT[0] = h->clipT;
+    for (int k = 1; k < gv_context::kSets; ++k) {
+      GV_C(hipMalloc(reinterpret_cast<void **>(&h->x_hitN[k]), nN * sizeof(uint32_t)));
+      GV_C(hipMalloc(reinterpret_cast<void **>(&h->x_clipN[k]), nN * sizeof(uint32_t)));
+      GV_C(hipMalloc(reinterpret_cast<void **>(&h->x_hitT[k]), nT * sizeof(uint32_t)));
+      GV_C(hipMalloc(reinterpret_cast<void **>(&h->x_clipT[k]), nT * sizeof(uint32_t)));
+      GV_C(hipMemsetAsync(h->x_hitN[k], 0, nN * sizeof(uint32_t), h->stream));
+      GV_C(hipMemsetAsync(h->x_clipN[k], 0, nN * sizeof(uint32_t), h->stream));
+      GV_C(hipMemsetAsync(h->x_hitT[k], 0, nT * sizeof(uint32_t), h->stream));
+      GV_C(hipMemsetAsync(h->x_clipT[k], 0, nT * sizeof(uint32_t), h->stream));
+    }
   }
   // packed (a,b) fields hold 13 bits each; vector stores need nx % 4 == 0
   h->tile_path = (g.nx % 4 == 0) && g.nx <= 8000 && g.ny <= 8000;
@@ -836,6 +847,7 @@ int gv_create(gv_handle *out, uint8_t grid_x, uint8_t grid_y, double resolution,
     h->force_simple = impl && std::strcmp(impl, "simple") == 0;
     if (const char *e = std::getenv("GV_PIPELINE")) { h->no_pipeline = std::atoi(e) == 0; h->three_streams = std::atoi(e) != 2; }
     if (const char *e = std::getenv("GV_HIT_COUNTS")) h->force_counts = std::atoi(e) != 0;
+    if (const char *e = std::getenv("GV_PIPE_SETS")) h->n_sets = std::min(gv_context::kSets, std::max(2, std::atoi(e)));
     if (const char *e = std::getenv("GV_LOG2S")) h->env_log2s = std::atoi(e);
     if (const char *e = std::getenv("GV_LOG2S_OCT")) {
       int k = 0;
@@ -878,15 +890,20 @@ int gv_destroy(gv_handle h)
   if (h->stream3) (void)hipStreamSynchronize(h->stream3);
   if (h->comm) { ncclCommDestroy(h->comm); h->comm = nullptr; }
   void *bufs[] = {h->log_odds, h->occupancy, h->occ_i8, h->hits, h->miss, h->clip_end, h->hit8, h->ray_list, h->ray_count,
-                  h->ray_stats, h->scratch_i32, h->d_dbg, h->hitN2, h->clipN2, h->hitT2, h->clipT2, h->d_rects2, h->miss2, h->missT2, h->missT, h->hitN, h->clipN, h->hitT, h->clipT, h->cx, h->cy, h->cz, h->tx, h->ty, h->tz, h->raw, h->cell_idx,
+                  h->ray_stats, h->scratch_i32, h->d_dbg, h->missT, h->hitN, h->clipN, h->hitT, h->clipT, h->cx, h->cy, h->cz, h->tx, h->ty, h->tz, h->raw, h->cell_idx,
                   h->bbox_id, h->d_bboxes, h->d_poses, h->d_rects, h->d_orient, h->d_conf, h->d_dims, h->d_vout,
                   h->d_pts, h->d_bbox_f, h->d_tile_mask, h->knn_partial, h->d_depths, h->d_knn_d2, h->d_idx, h->d_segof,
                   h->d_segstart, h->gx, h->gy, h->gz, h->d_keep, h->d_planes, h->d_plane_counts, h->d_ground};
   for (void *p : bufs)
     if (p) (void)hipFree(p);
+  for (int k = 1; k < gv_context::kSets; ++k) {
+    void *xs[] = {h->x_hitN[k], h->x_clipN[k], h->x_hitT[k], h->x_clipT[k], h->x_rects[k], h->x_miss[k], h->x_missT[k]};
+    for (void *p : xs)
+      if (p) (void)hipFree(p);
+  }
   for (auto &e : h->ev)
     if (e) (void)hipEventDestroy(e);
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < gv_context::kSets; ++i) {
     if (h->ev_build[i]) (void)hipEventDestroy(h->ev_build[i]);
     if (h->ev_fin[i]) (void)hipEventDestroy(h->ev_fin[i]);
     if (h->ev_sec[i]) (void)hipEventDestroy(h->ev_sec[i]);

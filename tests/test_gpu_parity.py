@@ -876,3 +876,38 @@ def test_forced_counts_equals_byte_flags(gvamd, monkeypatch):
         h.close()
     for a, b in zip(*outs):
         assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("origin", ["corner++", "corner--", "edge_x", "edge_y", "near_corner", "centre"])
+def test_sector_counts_follow_origin(gvamd, origin):
+    """The sector count of every octant follows the length of its wedge (distance from the origin cell
+    to the map edge): origins in a corner, on an edge and next to them give octants with zero, a
+    handful and the full number of columns in one launch.  Miss grid and layers vs the oracle."""
+    gx, gy, res = 120, 100, 0.25        # 480 x 400 cells
+    h = gvamd.GridVisionHIP(gx, gy, res)
+    og = ol.OGrid(gx, gy, res)
+    lx, ly = og.g.len_x, og.g.len_y
+    hix, hiy = og.g.pos_x + lx / 2, ly / 2
+    pos = {"corner++": (hix - 0.01, hiy - 0.01), "corner--": (hix - lx + 0.26, hiy - ly + 0.26),
+           "edge_x": (hix - 0.1, 0.3), "edge_y": (og.g.pos_x + 1.0, hiy - ly + 0.3),
+           "near_corner": (hix - 3.1, hiy - 2.2), "centre": (og.g.pos_x, 0.0)}[origin]
+    tfs = synth.transforms(True)
+    tfs["base_lidar"] = np.array([0.0, 0.0, 0.0, 1.0, pos[0], pos[1], 1.8])
+    h.set_transforms(tfs["cam_lidar"], tfs["base_cam"], tfs["base_lidar"])
+    st = synth.Stream(777, len(origin))
+    n = 120_000
+    # lidar-frame points = base-frame minus the translation: cover the map and 10 % beyond
+    x = st.uniform(n, hix - 1.1 * lx - pos[0], hix + 0.1 * lx - pos[0])
+    y = st.uniform(n, hiy - 1.1 * ly - pos[1], hiy + 0.1 * ly - pos[1])
+    z = st.uniform(n, -1.0, 1.0)
+    h.upload_xyz(x, y, z)
+    flags = gvamd.FRAME_BIN | gvamd.FRAME_RAYMARCH | gvamd.FRAME_KEEP_COUNTS
+    for frame in range(2):
+        h.process_frame(flags)
+        hits, cell, miss, _, _ = oracle_frame(og, tfs, x, y, z)
+        assert np.array_equal(h.hits(), hits)
+        assert np.array_equal(h.miss(), miss.astype(np.int32))
+        nlo, _, _ = check_grid(h, og)
+        assert nlo == 0
+    assert miss.sum() > 1000
+    h.close()
