@@ -91,14 +91,16 @@ __device__ __forceinline__ unsigned pack_nibbles(unsigned w)   // 4 nibble-bytes
 
 __global__ void __launch_bounds__(256) k_build_bitmaps8(BitmapArgs a)
 {
-  __shared__ unsigned nib[2][64][4];   // [hit|clip][row][16 nibble bytes]
-  const int x0 = blockIdx.x * 64, y0 = blockIdx.y * 64;
+  // 128 (x) by 32 (y) cells per workgroup: a tile row is one full 128-byte line of each flag map
+  // (64-wide tiles fetched every line twice), 4 N words per row, one T word per column
+  __shared__ unsigned nib[2][32][8];   // [hit|clip][row][32 nibble bytes]
+  const int x0 = blockIdx.x * 128, y0 = blockIdx.y * 32;
   const int t = threadIdx.x;
   unsigned char *nibb = reinterpret_cast<unsigned char *>(&nib[0][0][0]);
 #pragma unroll
   for (int it = 0; it < 4; ++it) {
     const int idx = it * 256 + t;
-    const int yl = idx >> 4, w = idx & 15;
+    const int yl = idx >> 5, w = idx & 31;
     const int y = y0 + yl, x = x0 + 4 * w;
     unsigned hw = 0, cw = 0;
     if (x < a.nx && y < a.ny) {
@@ -110,34 +112,33 @@ __global__ void __launch_bounds__(256) k_build_bitmaps8(BitmapArgs a)
       if (cw) *cp = 0;
       if (a.zero_hits && hw) *hp = 0;
     }
-    nibb[(0 * 64 + yl) * 16 + w] = (unsigned char)nibble_of(hw);
-    nibb[(1 * 64 + yl) * 16 + w] = (unsigned char)nibble_of(cw);
+    nibb[(0 * 32 + yl) * 32 + w] = (unsigned char)nibble_of(hw);
+    nibb[(1 * 32 + yl) * 32 + w] = (unsigned char)nibble_of(cw);
   }
   __syncthreads();
   {
-    // N words: thread (which, half, yl)
-    const int which = t >> 7, half = (t >> 6) & 1, yl = t & 63;
-    const unsigned lo = pack_nibbles(nib[which][yl][2 * half]), hi = pack_nibbles(nib[which][yl][2 * half + 1]);
+    // N words: thread (which, yl, q): cells 32q .. 32q+31 of row yl
+    const int which = t >> 7, yl = (t >> 2) & 31, q = t & 3;
+    const unsigned lo = pack_nibbles(nib[which][yl][2 * q]), hi = pack_nibbles(nib[which][yl][2 * q + 1]);
     unsigned *dst = which ? a.clipN : a.hitN;
-    dst[(size_t)(2 * blockIdx.x + half) * a.ny_pad + (y0 + yl)] = lo | (hi << 16);
+    if (4 * (int)blockIdx.x + q < a.nxw) dst[(size_t)(4 * blockIdx.x + q) * a.ny_pad + (y0 + yl)] = lo | (hi << 16);
   }
   {
-    // T words: thread (which, half, xl) gathers bit xl of rows 32*half .. 32*half+31
-    const int which = t >> 7, half = (t >> 6) & 1, xl = t & 63;
-    const int sh = (xl >> 2) * 8 + (xl & 3);   // bit position inside the row's 4 nibble words
+    // T words: thread (which, xl) gathers bit xl of the 32 rows (y0 is a multiple of 32)
+    const int which = t >> 7, xl = t & 127;
+    const int sh = (xl >> 2) * 8 + (xl & 3);   // bit position inside the row's 8 nibble words
     unsigned w = 0;
 #pragma unroll
-    for (int r = 0; r < 32; ++r) w |= ((nib[which][half * 32 + r][sh >> 5] >> (sh & 31)) & 1u) << r;
+    for (int r = 0; r < 32; ++r) w |= ((nib[which][r][sh >> 5] >> (sh & 31)) & 1u) << r;
     unsigned *dst = which ? a.clipT : a.hitT;
-    dst[(size_t)(2 * blockIdx.y + half) * a.nx_pad + (x0 + xl)] = w;
+    if (x0 + xl < a.nx_pad) dst[(size_t)blockIdx.y * a.nx_pad + (x0 + xl)] = w;
   }
 }
 
 void launch_build_bitmaps(const BitmapArgs &a, hipStream_t s)
 {
-  const dim3 grid((a.nx + 63) / 64, (a.ny + 63) / 64);
-  if (a.hit8) hipLaunchKernelGGL(k_build_bitmaps8, grid, dim3(256), 0, s, a);
-  else hipLaunchKernelGGL(k_build_bitmaps, grid, dim3(256), 0, s, a);
+  if (a.hit8) hipLaunchKernelGGL(k_build_bitmaps8, dim3((a.nx_pad + 127) / 128, a.ny_pad / 32), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(k_build_bitmaps, dim3((a.nx + 63) / 64, (a.ny + 63) / 64), dim3(256), 0, s, a);
 }
 
 // ------------------------------------------------ wavefront primitives (DPP) --
@@ -880,20 +881,24 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
     }
   }
 
-  // ---- flush the wedge's marks as bytes: N grid for x-major, T grid for y-major
-  for (int i = tid; i <= ((A.ablate & 4) ? -1 : oc.imax); i += NT) {
-    unsigned w = marks[i];
-    if (!w) continue;
-    const int jlo = (2 * i * s + S) >> (log2s + 1);
-    const int major_abs = oc_major + oc.smaj * i;
-    while (w) {
-      const int t = __ffs(w) - 1;
-      w &= w - 1;
-      const int j = jlo + t;
-      if (j > oc.jmaxo) continue;
-      const int minor_abs = oc_minor + oc.smin * j;
-      if (oc.xmaj) A.missN[(size_t)minor_abs * A.g.nx + major_abs] = 1;
-      else A.missT[(size_t)minor_abs * A.g.ny + major_abs] = 1;
+  // ---- flush the wedge's marks as bytes: N grid for x-major, T grid for y-major.  One byte per
+  // free cell: bit t of column i goes to base + t*step (32-bit offsets: the grids are < 2^31 bytes)
+  {
+    uint8_t *grid = oc.xmaj ? A.missN : A.missT;
+    const int pitch = oc.xmaj ? A.g.nx : A.g.ny;
+    const int step = oc.smin * pitch;
+    for (int i = tid; i <= ((A.ablate & 4) ? -1 : oc.imax); i += NT) {
+      unsigned w = marks[i];
+      const int jlo = (2 * i * s + S) >> (log2s + 1);
+      const int tmax = oc.jmaxo - jlo;                        // bits beyond it are outside the map
+      if (tmax < 31) w &= (tmax < 0) ? 0u : ((2u << tmax) - 1u);
+      if (!w) continue;
+      uint8_t *base = grid + ((oc_minor + oc.smin * jlo) * pitch + (oc_major + oc.smaj * i));
+      while (w) {
+        const int t = __ffs(w) - 1;
+        w &= w - 1;
+        base[t * step] = 1;
+      }
     }
   }
   __syncthreads();
