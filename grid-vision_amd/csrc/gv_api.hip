@@ -23,6 +23,7 @@ struct gv_context {
   hipStream_t stream2 = nullptr, stream3 = nullptr;   // B: sector ray stage, C: grid pass
   static constexpr int kSets = 4;                     // buffer sets the pipelined frames rotate through (n_sets in use)
   hipEvent_t ev_build[kSets]{}, ev_sec[kSets]{}, ev_fin[kSets]{};
+  std::vector<hipEvent_t> *trace = nullptr;         // diagnostic: timing events around every pipelined kernel (gv_debug_pipeline_trace)
   int n_sets = 3;                                     // GV_PIPE_SETS (2..4): how far stream A may run ahead
   // sets 1..: bitmaps, rectangles and miss grids of the frames in flight (set 0 = the primary buffers)
   uint32_t *x_hitN[kSets]{}, *x_clipN[kSets]{}, *x_hitT[kSets]{}, *x_clipT[kSets]{};
@@ -504,6 +505,14 @@ int enqueue_frame(gv_context *h, bool stage_events, bool sharded = false)
 // private to one stream (hits/clip_end: A; miss grids, grid layers: B) or ordered by events.
 int enqueue_frame_pipelined(gv_context *h)
 {
+  auto mark = [&](hipStream_t st) {   // diagnostic build-up of a device timeline; null in production
+    if (!h->trace) return;
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) return;
+    (void)hipEventRecord(e, st);
+    h->trace->push_back(e);
+  };
+
   const uint32_t fl = h->frame_flags;
   const bool do_bin = fl & GV_FRAME_BIN, do_ray = fl & GV_FRAME_RAYMARCH, do_bbox = fl & GV_FRAME_BBOX_TEST;
   const bool vision = fl & GV_FRAME_VISION_ORIENT;
@@ -524,7 +533,9 @@ int enqueue_frame_pipelined(gv_context *h)
     launch_rects_from_poses(h->d_poses, h->nb, h->g, true, h->x_bc, rects, sA);
     n_rects = h->nb;
   } else if (h->n_poses > 0) {
+    mark(sA);
     launch_rects_from_poses(h->d_poses, h->n_poses, h->g, false, h->x_bc, rects, sA);
+    mark(sA);
     n_rects = h->n_poses;
   }
   if (do_bin || do_bbox) {
@@ -548,7 +559,9 @@ int enqueue_frame_pipelined(gv_context *h)
     a.bbox_id = h->bbox_id;
     a.do_bin = do_bin; a.do_ray = do_ray; a.do_bbox = do_bbox;
     a.counts = h->force_counts;
+    mark(sA);
     launch_points(a, sA);
+    mark(sA);
   }
   if (do_bin) {
     BitmapArgs b{};
@@ -558,7 +571,9 @@ int enqueue_frame_pipelined(gv_context *h)
     b.hitN = hitN; b.clipN = clipN; b.hitT = hitT; b.clipT = clipT;
     b.nxw = h->nxw; b.nyw = h->nyw; b.nx_pad = h->nx_pad; b.ny_pad = h->ny_pad;
     b.zero_hits = true;
+    mark(sA);
     launch_build_bitmaps(b, sA);
+    mark(sA);
   }
   GV_HIP(hipEventRecord(h->ev_build[p], sA));
   GV_HIP(hipStreamWaitEvent(sB, h->ev_build[p], 0));
@@ -573,7 +588,9 @@ int enqueue_frame_pipelined(gv_context *h)
     if (rc) return rc;
     sa.hitN = hitN; sa.clipN = clipN; sa.hitT = hitT; sa.clipT = clipT;
     sa.missN = missN; sa.missT = missT;
+    mark(sB);
     launch_ray_sectors(sa, sB);
+    mark(sB);
   }
   if (h->three_streams) {
     GV_HIP(hipEventRecord(h->ev_sec[p], sB));
@@ -596,7 +613,9 @@ int enqueue_frame_pipelined(gv_context *h)
   t.use_missT = true;
   t.y_begin = 0;
   t.y_end = h->g.ny;
+  mark(sC);
   launch_finalize_tiles(t, sC);
+  mark(sC);
   GV_HIP(hipEventRecord(h->ev_fin[p], sC));
   GV_HIP(hipGetLastError());
   h->frame_no++;
@@ -1397,6 +1416,32 @@ int gv_debug_sector_stamps(gv_handle h, unsigned long long *out, size_t n_wg)
 {
   if (!h || !out || !h->d_dbg) return GV_ERR_STATE;
   return copy_out(h, out, h->d_dbg, n_wg * 16 * sizeof(unsigned long long));
+}
+
+// diagnostic (not part of the ABI): enqueue `frames` pipelined frames with timing events around every
+// kernel; out[frame*10 + 2*k + {0,1}] = start/end in us of kernel k (rects, points, bitmaps, sectors, grid pass)
+extern "C" int gv_debug_pipeline_trace(gv_handle h, int32_t frames, float *out)
+{
+  if (!h || frames <= 0 || !out) return GV_ERR_BAD_ARG;
+  GV_TRY
+  int rc = use_device(h);
+  if (rc) return rc;
+  std::vector<hipEvent_t> ev;
+  hipEvent_t e0;
+  GV_HIP(hipEventCreate(&e0));
+  GV_HIP(hipEventRecord(e0, h->stream));
+  h->trace = &ev;
+  for (int32_t i = 0; i < frames && rc == GV_OK; ++i) rc = gv_frame_enqueue(h);
+  h->trace = nullptr;
+  int rc2 = use_device(h);
+  for (size_t k = 0; k < ev.size(); ++k) {
+    float ms = 0.f;
+    if (k < (size_t)frames * 10 && hipEventElapsedTime(&ms, e0, ev[k]) == hipSuccess) out[k] = ms * 1000.f;
+    (void)hipEventDestroy(ev[k]);
+  }
+  (void)hipEventDestroy(e0);
+  return rc ? rc : rc2;
+  GV_CATCH
 }
 
 void *gv_stream(gv_handle h) { return h ? (void *)h->stream : nullptr; }
