@@ -911,3 +911,46 @@ def test_sector_counts_follow_origin(gvamd, origin):
         assert nlo == 0
     assert miss.sum() > 1000
     h.close()
+
+
+def test_sector_path_random_scenes(gvamd):
+    """Randomised scenes for the sector ray stage (seeded): grid shape and resolution, origin anywhere
+    in or next to the map, cloud density from a few points to several per cell, clouds with angular
+    gaps and axis-aligned walls (many ends on one slope).  Hits and miss grids vs the oracle."""
+    st = synth.Stream(20260104, 7)
+    for case in range(24):
+        k = int(st.integers(1, 2, 60)[0]); gy = int(st.integers(1, 5, 120)[0])
+        res = [0.25, 0.5, 0.2, 1.0][case % 4]
+        gx = [k, 2 * k, 4 * k, 4 * k][case % 4]      # nx = gx / res is a multiple of 4: the tile (sector) path
+        h = gvamd.GridVisionHIP(gx, gy, res)
+        assert h.nx % 4 == 0
+        og = ol.OGrid(gx, gy, res)
+        lx, ly = og.g.len_x, og.g.len_y
+        hix, hiy = og.g.pos_x + lx / 2, ly / 2
+        ox = float(st.uniform(1, hix - lx - 0.05 * lx, hix + 0.05 * lx)[0])
+        oy = float(st.uniform(1, hiy - ly - 0.05 * ly, hiy + 0.05 * ly)[0])
+        tfs = synth.transforms(case % 2 == 0)
+        tfs["base_lidar"] = np.array([0.0, 0.0, 0.0, 1.0, ox, oy, 1.8])
+        h.set_transforms(tfs["cam_lidar"], tfs["base_cam"], tfs["base_lidar"])
+        n = [50, 2_000, 40_000, 200_000][case % 4]
+        kind = case % 3
+        if kind == 0:      # uniform over the map and 10 % beyond
+            x = st.uniform(n, hix - 1.1 * lx - ox, hix + 0.1 * lx - ox)
+            y = st.uniform(n, hiy - 1.1 * ly - oy, hiy + 0.1 * ly - oy)
+        elif kind == 1:    # a 90 degree fan of ranges: most sectors see nothing
+            r = st.uniform(n, 0.5, 1.2 * max(lx, ly)).astype(np.float64)
+            az = st.uniform(n, 0.3, 0.3 + np.pi / 2).astype(np.float64)
+            x = (r * np.cos(az)).astype(np.float32); y = (r * np.sin(az)).astype(np.float32)
+        else:              # two walls: ends share columns / rows (slopes 0 and infinity dominate)
+            half = n // 2
+            x = np.concatenate([st.uniform(half, -0.4 * lx, 0.4 * lx), np.full(n - half, 0.31 * lx, np.float32)]).astype(np.float32)
+            y = np.concatenate([np.full(half, 0.27 * ly, np.float32), st.uniform(n - half, -0.4 * ly, 0.4 * ly)]).astype(np.float32)
+        z = st.uniform(n, -1.0, 1.0)
+        h.upload_xyz(x, y, z)
+        h.process_frame(gvamd.FRAME_BIN | gvamd.FRAME_RAYMARCH | gvamd.FRAME_KEEP_COUNTS)
+        hits, cell, miss, _, _ = oracle_frame(og, tfs, x, y, z)
+        assert np.array_equal(h.hits(), hits), case
+        assert np.array_equal(h.miss(), miss.astype(np.int32)), (case, gx, gy, res, ox, oy, n, kind)
+        nlo, _, _ = check_grid(h, og)
+        assert nlo == 0, case
+        h.close()
