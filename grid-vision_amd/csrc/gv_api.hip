@@ -310,7 +310,9 @@ int fill_sector_args(gv_context *h, SectorArgs &sa)
     ord[o] = o;
   }
   // Sectors per octant: the far end of a wedge about 16 cells wide (len <= 16*S; the kernel needs
-  // <= 32) and an estimated <= 5000 ends per sector so that a wedge fits one LDS chunk.  Measured on
+  // <= 32) and an estimated <= 12000 ends per sector (the estimate runs ~2x high; above one LDS chunk
+  // of 4096 ends a wedge is processed in row groups, which measured better on config 5 -- 10 M points,
+  // 160 vs 390 us -- than four times as many, thinner wedges).  Measured on
   // config 3 (tools/sweep_oct.sh, tools/sweep_sectors.sh): the kernel is bound by per-workgroup
   // latency chains, so fewer, fatter wedges win as long as those two hold, and an octant whose wedge
   // is short (origin near that map edge) gets proportionally fewer sectors: 128/64/32 sectors for
@@ -323,7 +325,7 @@ int fill_sector_args(gv_context *h, SectorArgs &sa)
     int l2 = 3;   // the gap-sector logic wants S >= 8
     while ((16 << l2) < len[o]) ++l2;
     double est = 1.5 * dens * (double)len[o] * (double)len[o] / (double)(2 << l2);
-    while (est > 5000.0 && l2 < 12) {
+    while (est > 12000.0 && l2 < 12) {
       ++l2;
       est *= 0.5;
     }
