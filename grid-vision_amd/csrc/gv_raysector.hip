@@ -487,10 +487,11 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
       xb0 = (s == 0 && oc.bmin == 1) ? 0 : 1;
       xb1 = (int)min((long long)M, SM / ((long long)qlo * oc.imax));
     }
-    if (qhi) {   // bucket k lies inside (1 - Z, 1) iff k > M - Z*M; the last bucket of sector S-1 holds slope 1
+    if (qhi) {   // bucket k lies inside (1 - Z, 1) iff k > M - Z*M; the last bucket of sector S-1 holds slope 1,
+                 // which only the x-major octants own (the diagonal is theirs: bmaxa)
       const long long c = (SM + (long long)qhi * oc.imax - 1) / ((long long)qhi * oc.imax);   // ceil(Z*M)
       xt0 = (int)max(0ll, (long long)M - c + 1);
-      xt1 = (s == S - 1) ? M - 1 : M;
+      xt1 = (s == S - 1 && oc.xmaj) ? M - 1 : M;
     }
   }
   auto gap_group = [&](int g0, int size) -> bool {   // aligned group [g0, g0+size) entirely inside a gap run
