@@ -279,7 +279,7 @@ def main():
             "vs_baseline": None, "dtype": "f32 grid / f64 index / i32 counts", "data": "synthetic",
             "config": {"workload": f"BASELINE configs[{config - 1}]: {N}-point {a.cloud} cloud per GPU, "
                                    f"{g.nx}x{g.ny} @ {g.resolution} m grid, {len(bboxes)} bboxes + {len(poses)} poses, "
-                                   "bin + ray-march + bbox test + grid pass",
+                                   "bin (hit flags; counts: see with_hit_counts) + ray-march + bbox test + grid pass",
                        "points": N, "cells": G, "parallelism": (f"points-sharded x{world} + RCCL reduce-scatter" if sharded else f"frame-per-gpu x{world}"),
                        "devices_visible": ndev},
             "mpoints_per_s": N_total * fps / 1e6,
@@ -290,6 +290,32 @@ def main():
                           "mcell_visits_per_s": (n_visits / (stages["ray_march"] * 1e-3) / 1e6) if stages["ray_march"] > 0 else None},
             "roofline": roof,
         }
+        # The production frame marks hit cells with byte flags (the update rule is binary per cell);
+        # the int32 hit counts of SURVEY X1 are produced on request.  Same workload with the counts
+        # computed every frame (atomics behind the LDS hit cache), reported next to the headline:
+        if not sharded:
+            try:
+                os.environ["GV_HIT_COUNTS"] = "1"
+                hc = gvamd.GridVisionHIP(g.grid_x, g.grid_y, g.resolution, device=local_rank)
+                del os.environ["GV_HIT_COUNTS"]
+                hc.set_transforms(tfs["cam_lidar"], tfs["base_cam"], tfs["base_lidar"])
+                hc.upload_xyz(x, y, z)
+                hc.set_detections(flags, bboxes=bboxes, poses=poses)
+                kc = max(20, min(a.steps, 200))
+                for _ in range(10):
+                    hc.enqueue_frame()
+                hc.synchronize()
+                tc0 = time.perf_counter()
+                for _ in range(kc):
+                    hc.enqueue_frame()
+                hc.synchronize()
+                dtc = time.perf_counter() - tc0
+                hc.close()
+                out["with_hit_counts"] = {"value": kc / dtc, "unit": "frames/s", "ms_per_step": dtc / kc * 1e3, "steps": kc,
+                                          "note": "int32 hits[cell] += 1 per point (GV_HIT_COUNTS=1) instead of byte flags; same grid"}
+            except Exception as e:
+                os.environ.pop("GV_HIT_COUNTS", None)
+                print("with_hit_counts measurement failed:", e, file=sys.stderr)
         try:
             copy_gbps = measured_copy_rate(torch)
             out["frame_roofline"]["measured_copy_GBps"] = copy_gbps
