@@ -954,3 +954,43 @@ def test_sector_path_random_scenes(gvamd):
         nlo, _, _ = check_grid(h, og)
         assert nlo == 0, case
         h.close()
+
+
+@pytest.mark.parametrize("grid", [(50, 20, 0.1), (100, 100, 0.5), (120, 60, 0.3), (200, 200, 0.05)])
+def test_cell_index_on_cell_boundaries(gvamd, grid):
+    """The points pass derives (int)(-(d / res)) from a reciprocal-multiply estimate and only divides
+    when the estimate is within 1e-6 of an integer.  Points ON cell boundaries (base-frame x, y =
+    k * res as fp32, and their fp32 neighbours) are exactly those cases; SURVEY 8(c)'s canary
+    (getIndex(40.7) = 2, not 3, on the default grid) is among them.  cell_idx vs the oracle."""
+    gx, gy, res = grid
+    h = gvamd.GridVisionHIP(gx, gy, res)
+    og = ol.OGrid(gx, gy, res)
+    tfs = synth.transforms(False)
+    tfs["base_lidar"] = np.array([0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0])   # identity: lidar frame = base frame
+    h.set_transforms(tfs["cam_lidar"], tfs["base_cam"], tfs["base_lidar"])
+    lx, ly = og.g.len_x, og.g.len_y
+    hix, hiy = og.g.pos_x + lx / 2, ly / 2
+    kx = np.arange(og.nx + 1, dtype=np.float64)
+    ky = np.arange(og.ny + 1, dtype=np.float64)
+    bx = (hix - kx * res).astype(np.float32)            # every cell boundary along x, as fp32
+    by = (hiy - ky * res).astype(np.float32)
+    xs, ys = [], []
+    for d in (0, 1, -1, 2, -2):                        # the boundary and its fp32 neighbours
+        nbx = bx.copy(); nby = by.copy()
+        for _ in range(abs(d)):
+            nbx = np.nextafter(nbx, np.float32(np.inf if d > 0 else -np.inf), dtype=np.float32)
+            nby = np.nextafter(nby, np.float32(np.inf if d > 0 else -np.inf), dtype=np.float32)
+        xs.append(np.repeat(nbx, 3)); ys.append(np.tile(np.float32([0.0, by[1], by[len(by) // 2]]), len(nbx)))
+        ys.append(np.repeat(nby, 3)); xs.append(np.tile(np.float32([og.g.pos_x, bx[1], bx[len(bx) // 2]]), len(nby)))
+    x = np.concatenate(xs + [np.float32([40.7, 40.8, 40.9, 41.0, -9.0])])
+    y = np.concatenate(ys + [np.float32([0.0, 0.0, 0.0, 0.0, 0.0])])
+    z = np.zeros_like(x)
+    h.upload_xyz(x, y, z)
+    h.process_frame(gvamd.FRAME_BIN | gvamd.FRAME_KEEP_CELL_IDX | gvamd.FRAME_KEEP_COUNTS)
+    m_base = ol.tf_to_matrix4f(tfs["base_lidar"])
+    hits, cell = og.bin_points(m_base, x, y, z)
+    got = h.cell_idx()
+    assert np.array_equal(got, cell), np.flatnonzero(got != cell)[:10]
+    assert np.array_equal(h.hits(), hits)
+    assert (cell >= 0).sum() > len(x) // 2
+    h.close()
