@@ -994,3 +994,37 @@ def test_cell_index_on_cell_boundaries(gvamd, grid):
     assert np.array_equal(h.hits(), hits)
     assert (cell >= 0).sum() > len(x) // 2
     h.close()
+
+
+def test_projection_on_float_rounding_boundaries(gvamd):
+    """The points pass forms (float)(n / iz) from a reciprocal-multiply estimate and only divides when
+    the estimate is within 2^-45 of a float rounding boundary.  tests/golden/projection_canaries.npz
+    holds camera-frame points whose exact fp64 quotient lies within 6 ulp of such a boundary (found by
+    tests/golden/make_projection_canaries.py).  Each point gets a bbox that is exactly one pixel value
+    wide in u and v: it is inside iff both projections round like the reference's division."""
+    d = np.load(os.path.join(HERE, "golden", "projection_canaries.npz"))
+    x, y, z = d["x"], d["y"], d["z"]
+    K = ol.set_intrinsic(synth.FX, synth.FY, synth.CX, synth.CY)
+    u = (((synth.FX * x.astype(np.float64) + 0.0 * y.astype(np.float64)) + synth.CX * z.astype(np.float64)) / z.astype(np.float64)).astype(np.float32)
+    v = (((0.0 * x.astype(np.float64) + synth.FY * y.astype(np.float64)) + synth.CY * z.astype(np.float64)) / z.astype(np.float64)).astype(np.float32)
+    inside = (u >= 0) & (u < synth.IMG_W) & (v >= 0) & (v < synth.IMG_H)
+    x, y, z, u, v = x[inside], y[inside], z[inside], u[inside], v[inside]
+    assert len(x) >= 24
+    n = min(len(x), 60)
+    x, y, z, u, v = x[:n], y[:n], z[:n], u[:n], v[:n]
+    bboxes = np.zeros(n, dtype=synth.BBOX_DTYPE)
+    bboxes["x_min"] = u.astype(np.float64); bboxes["x_max"] = u.astype(np.float64)
+    bboxes["y_min"] = v.astype(np.float64); bboxes["y_max"] = v.astype(np.float64)
+    bboxes["confidence"] = 0.9
+    want = ol.extract_cloud_per_bbox(K, x, y, z, bboxes, synth.IMG_W, synth.IMG_H)
+    assert (want >= 0).all(), "the oracle itself must put every canary into a one-value-wide bbox"
+    g = synth.CONFIGS[1]["grid"]
+    h = gvamd.GridVisionHIP(g.grid_x, g.grid_y, g.resolution)
+    ident = np.array([0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0])          # camera frame = lidar frame: the transform is exact
+    h.set_transforms(ident, ident, ident)
+    # the same canaries many times over, so that every lane position and wavefront sees them
+    reps = 40
+    h.upload_xyz(np.tile(x, reps), np.tile(y, reps), np.tile(z, reps))
+    ids, counts = h.extract_cloud_per_bbox(bboxes)
+    assert np.array_equal(ids, np.tile(want, reps))
+    h.close()
