@@ -1,4 +1,5 @@
 // Micro-benchmark (GPU experiment): latency of a cross-stream dependency (hipEventRecord on one stream,
+// build: hipcc --offload-arch=gfx950 -O2 tools/micro/hop_latency.hip -o tools/micro/hop_latency
 // hipStreamWaitEvent on another) compared with back-to-back launches on one stream.
 #include <hip/hip_runtime.h>
 #include <chrono>
