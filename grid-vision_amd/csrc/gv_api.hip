@@ -22,6 +22,8 @@ struct gv_context {
   hipStream_t stream = nullptr;
   // frame pipelining: points/bitmaps of frame f+1 (stream) overlap sectors/grid pass of frame f (stream2)
   hipStream_t stream2 = nullptr, stream3 = nullptr;   // B: sector ray stage, C: grid pass
+  hipStream_t stream4 = nullptr;                      // D: bbox test of the points pass when split off (GV_SPLIT_POINTS=1)
+  bool split_points = false;
   hipStream_t stream2b = nullptr;                     // B': sector kernels of odd frames, so that one frame's sector
                                                       // kernel fills the CUs its predecessor's tail leaves idle
   int sector_streams = 1;                             // GV_SECTOR_STREAMS=2 alternates two sector streams: measured slower (75.9 vs 69.0 us)
@@ -229,6 +231,7 @@ int use_device(gv_context *h)
     GV_HIP(hipStreamSynchronize(h->stream2));
     GV_HIP(hipStreamSynchronize(h->stream2b));
     GV_HIP(hipStreamSynchronize(h->stream3));
+    GV_HIP(hipStreamSynchronize(h->stream4));
     h->pipe_busy = false;
     h->since_drain = 0;
   }
@@ -571,7 +574,17 @@ int enqueue_frame_pipelined(gv_context *h)
     a.do_bin = do_bin; a.do_ray = do_ray; a.do_bbox = do_bbox;
     a.counts = h->force_counts;
     mark(sA);
-    launch_points(a, sA);
+    if (h->split_points && do_bin && do_bbox) {
+      // binning (what the bitmaps wait for) on stream A, the bbox test on its own stream: two lighter
+      // kernels (46 and 30 VGPRs, no SGPR spills) instead of one fused pass over the cloud
+      PointsArgs ab = a, ax = a;
+      ab.do_bbox = false;
+      ax.do_bin = false; ax.do_ray = false; ax.counts = false;
+      launch_points(ab, sA);
+      launch_points(ax, h->stream4);
+    } else {
+      launch_points(a, sA);
+    }
     mark(sA);
   }
   if (do_bin) {
@@ -817,6 +830,7 @@ int gv_create(gv_handle *out, uint8_t grid_x, uint8_t grid_y, double resolution,
     GV_C(hipStreamCreateWithPriority(&h->stream, hipStreamNonBlocking, mode == 1 ? hi : (mode == 2 ? lo : 0)));
     GV_C(hipStreamCreateWithPriority(&h->stream2, hipStreamNonBlocking, mode == 2 ? hi : (mode == 1 ? lo : 0)));
     GV_C(hipStreamCreateWithPriority(&h->stream3, hipStreamNonBlocking, mode == 3 ? hi : 0));
+    GV_C(hipStreamCreateWithPriority(&h->stream4, hipStreamNonBlocking, 0));
     GV_C(hipStreamCreateWithPriority(&h->stream2b, hipStreamNonBlocking, mode == 2 ? hi : (mode == 1 ? lo : 0)));
   }
   for (int i = 0; i < gv_context::kSets; ++i) {
@@ -878,6 +892,7 @@ int gv_create(gv_handle *out, uint8_t grid_x, uint8_t grid_y, double resolution,
     h->force_simple = impl && std::strcmp(impl, "simple") == 0;
     if (const char *e = std::getenv("GV_PIPELINE")) { h->no_pipeline = std::atoi(e) == 0; h->three_streams = std::atoi(e) != 2; }
     if (const char *e = std::getenv("GV_HIT_COUNTS")) h->force_counts = std::atoi(e) != 0;
+    if (const char *e = std::getenv("GV_SPLIT_POINTS")) h->split_points = std::atoi(e) != 0;
     if (const char *e = std::getenv("GV_SECTOR_STREAMS")) h->sector_streams = std::max(1, std::min(2, std::atoi(e)));
     if (!h->three_streams) h->sector_streams = 1;
     if (const char *e = std::getenv("GV_PIPE_SETS")) h->n_sets = std::min(gv_context::kSets, std::max(2, std::atoi(e)));
@@ -927,6 +942,7 @@ int gv_destroy(gv_handle h)
   if (h->stream2) (void)hipStreamSynchronize(h->stream2);
   if (h->stream3) (void)hipStreamSynchronize(h->stream3);
   if (h->stream2b) (void)hipStreamSynchronize(h->stream2b);
+  if (h->stream4) (void)hipStreamSynchronize(h->stream4);
   if (h->comm) { ncclCommDestroy(h->comm); h->comm = nullptr; }
   void *bufs[] = {h->log_odds, h->occupancy, h->occ_i8, h->hits, h->miss, h->clip_end, h->hit8, h->ray_list, h->ray_count,
                   h->ray_stats, h->scratch_i32, h->d_dbg, h->missT, h->hitN, h->clipN, h->hitT, h->clipT, h->cx, h->cy, h->cz, h->tx, h->ty, h->tz, h->raw, h->cell_idx,
@@ -949,6 +965,7 @@ int gv_destroy(gv_handle h)
   }
   if (h->stream3) (void)hipStreamDestroy(h->stream3);
   if (h->stream2b) (void)hipStreamDestroy(h->stream2b);
+  if (h->stream4) (void)hipStreamDestroy(h->stream4);
   if (h->stream2) (void)hipStreamDestroy(h->stream2);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
@@ -1484,6 +1501,8 @@ int gv_time_frames(gv_handle h, int32_t frames, float *ms_total)
     GV_HIP(hipStreamWaitEvent(h->stream, h->ev[2], 0));
     GV_HIP(hipEventRecord(h->ev[3], h->stream2b));
     GV_HIP(hipStreamWaitEvent(h->stream, h->ev[3], 0));
+    GV_HIP(hipEventRecord(h->ev[4], h->stream4));
+    GV_HIP(hipStreamWaitEvent(h->stream, h->ev[4], 0));
   }
   GV_HIP(hipEventRecord(e1, h->stream));
   GV_HIP(hipEventSynchronize(e1));
