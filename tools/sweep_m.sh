@@ -1,0 +1,11 @@
+#!/bin/bash
+cd $GRAFT_REPO_ROOT
+for c in uniform lidar; do
+  for m in 9 8 7; do
+    for p in 1 0; do
+    GV_PIPELINE=$p GV_LOG2M=$m python bench.py --cloud $c --steps 300 --warmup 30 --no-cpu-baseline 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('log2m=$m pipe=$p', '$c', round(d['value']), round(d['ms_per_step']*1000,1), round(d['stage_ms']['ray_march']*1000,1))"
+    done
+  done
+done
