@@ -766,7 +766,8 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
     if (A.dbg) __syncthreads();
     stamp();   // 9: tail marched (barrier only in the diagnostic build)
     // gather: one lane per column of the wedge
-    const int gather_hi = march_tail ? T : oc.imax;
+    const bool flat_tail = !march_tail && T < oc.imax && !(A.ablate & 512);   // columns beyond T, every cell exactly
+    const int gather_hi = (march_tail || flat_tail) ? T : oc.imax;
     for (int i = tid; i <= ((A.ablate & 2) ? -1 : gather_hi); i += NT) {
       if (i == 0) {
         marks[0] |= 1u;   // every ray (reach >= 1) starts in the origin cell
@@ -784,7 +785,7 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
       bool interior_free = (w > 2) && (i <= T);
       if (A.ablate & 64) interior_free = false;           // timing experiment: always the full loop
       if ((A.ablate & 128) && !interior_free) continue;   // timing experiment: skip the full loop
-      unsigned mask = 0;
+      unsigned mask = 0, todo = 0;   // todo: cells of this column to evaluate exactly
       if (interior_free) {
         mask = ((w >= 32) ? 0xFFFFFFFFu : ((1u << w) - 1u)) & ~1u & ~(1u << (w - 1));
         // the two edge cells: all table reads of both issued before anything is evaluated
@@ -820,38 +821,41 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
         if (mxh > (unsigned)i) mask |= 1u;
         if (mxl > (unsigned)i) mask |= 1u << (w - 1);
         // sectors with a lattice-gap run: the cell next to the edge cell is not covered by the level test
-        if (xb0 < xb1 && !cell_exact(i, Q, jlo + 1)) mask &= ~2u;
-        if (xt0 < xt1 && !cell_exact(i, Q, jhi - 1)) mask &= ~(1u << (w - 2));
+        if (xb0 < xb1) todo |= 2u;
+        if (xt0 < xt1) todo |= 1u << (w - 2);
+        mask &= ~todo;
       } else {
-        int lo = -1;             // bucket holding the cell's lower boundary (-1: below the sector)
-        unsigned above = 0;      // max reach of the ends of bucket `lo` at or above that boundary
-        for (int k = 0; k < w; ++k) {
-          const int Phi = 2 * (jlo + k) + 1;
-          const int hi = (k < w - 1) ? bucket_of_boundary(Phi, Q) : M;
-          // whole buckets strictly between the two boundary buckets
-          unsigned mx = above;
-          const int l = lo + 1, r = min(hi - 1, M - 1);
-          if (l <= r) mx = max(mx, rmq(l, r));
-          // the upper boundary's bucket, read once: ends below the boundary belong to this
-          // cell, the others to the next one (S*M > imax: two boundaries never share a bucket)
-          above = 0;
-          if (hi >= 0 && hi < M) {
-            unsigned below = 0;
-            for (unsigned e = bstart[hi]; e < bstart[hi + 1]; ++e) {
-              const unsigned p = abv[e];
-              const int a = ab_a(p);
-              const unsigned rch = (unsigned)(a + (int)(p & 1u));
-              if (ab_b(p) * Q < Phi * a) below = max(below, rch);
-              else above = max(above, rch);
-            }
-            mx = max(mx, below);
-          }
-          if (mx > (unsigned)i) mask |= 1u << k;
-          lo = hi;
-          if (hi >= M) break;
-        }
+        // narrow columns (w <= 2: edge cells only), or -- without the flattened pass -- any column
+        // beyond T: every cell exactly
+        todo = (w >= 32) ? 0xFFFFFFFFu : ((1u << w) - 1u);
+      }
+      while (todo) {
+        const int k = __ffs(todo) - 1;
+        todo &= todo - 1;
+        if (cell_exact(i, Q, jlo + k)) mask |= 1u << k;
       }
       if (mask) marks[i] |= mask;
+    }
+    if (flat_tail) {
+      // Too many long rays to march them: every cell of the columns T+1 .. (largest reach - 1) is
+      // evaluated exactly, one (column, cell) pair per lane -- balanced over the 512 lanes, where a
+      // lane per column would leave 60 % of them idle and walk ~16 cells in sequence.
+      const int first = T + 1;
+      const int last = min(oc.imax, (int)maxreach - 1);
+      if (last >= first) {
+        const int wlast = ((2 * last * (s + 1) + S) >> (log2s + 1)) - ((2 * last * s + S) >> (log2s + 1)) + 1;
+        const int wfirst = ((2 * first * (s + 1) + S) >> (log2s + 1)) - ((2 * first * s + S) >> (log2s + 1)) + 1;
+        const int wmax = max(wlast, wfirst) + 1;                 // w(i) grows with i, +-1 by rounding
+        const int lw = 32 - __clz(max(wmax - 1, 1));             // cells per column rounded up to a power of two
+        const int ntask = (last - first + 1) << lw;
+        for (int t = tid; t < ntask; t += NT) {
+          const int i = first + (t >> lw), k = t & ((1 << lw) - 1);
+          const int jlo = (2 * i * s + S) >> (log2s + 1);
+          const int jhi = (2 * i * (s + 1) + S) >> (log2s + 1);
+          if (k > jhi - jlo) continue;
+          if (cell_exact(i, 2 * i, jlo + k)) atomicOr(&marks[i], 1u << k);
+        }
+      }
     }
     __syncthreads();
     stamp();   // 10: gather done
