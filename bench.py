@@ -37,6 +37,7 @@ def parse():
     ap.add_argument("--config", type=int, default=0, help="0 = 3 at N=1 / 4 at N>1")
     ap.add_argument("--cloud", choices=["uniform", "lidar"], default="uniform")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-hit-counts", action="store_true", help="skip the second measurement with int32 hit counts (profiling runs)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     return ap.parse_args()
 
@@ -293,7 +294,7 @@ def main():
         # The production frame marks hit cells with byte flags (the update rule is binary per cell);
         # the int32 hit counts of SURVEY X1 are produced on request.  Same workload with the counts
         # computed every frame (atomics behind the LDS hit cache), reported next to the headline:
-        if not sharded:
+        if not sharded and not a.no_hit_counts:
             try:
                 os.environ["GV_HIT_COUNTS"] = "1"
                 hc = gvamd.GridVisionHIP(g.grid_x, g.grid_y, g.resolution, device=local_rank)

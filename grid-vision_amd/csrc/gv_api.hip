@@ -24,6 +24,7 @@ struct gv_context {
   hipStream_t stream2 = nullptr, stream3 = nullptr;   // B: sector ray stage, C: grid pass
   hipStream_t stream4 = nullptr;                      // D: bbox test of the points pass when split off (GV_SPLIT_POINTS=1)
   bool split_points = false;
+  bool rects_on_c = false;                            // GV_RECTS_ON_C=1: rectangle kernels on the grid-pass stream (lidar-like cloud -6 %, uniform +10 %)
   hipStream_t stream2b = nullptr;                     // B': sector kernels of odd frames, so that one frame's sector
                                                       // kernel fills the CUs its predecessor's tail leaves idle
   int sector_streams = 1;                             // GV_SECTOR_STREAMS=2 alternates two sector streams: measured slower (75.9 vs 69.0 us)
@@ -74,6 +75,7 @@ struct gv_context {
   unsigned long long *d_dbg = nullptr;      // GV_SECTOR_DBG=1: phase stamps of the sector kernel
   size_t stat_slots = 1;                    // ray_stats slots written by the last frame
   int32_t env_log2s_oct[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // GV_LOG2S_OCT="a,b,..." per octant index (experiments)
+  int32_t env_flat_k = 8;                   // GV_FLAT_K: exact-cell : marched-cell cost ratio (tools/flatk.sh: 8 is best on both clouds; 0 = always march)
   int32_t env_log2s = 0, env_cap = 0, env_ablate = 0, env_log2m = 0;   // GV_LOG2S / GV_CAP / GV_ABLATE (experiments)
 
   // resident cloud
@@ -347,6 +349,7 @@ int fill_sector_args(gv_context *h, SectorArgs &sa)
   }
   sa.cap = h->env_cap > 0 ? std::max(2048, h->env_cap) : ((est_max <= 1700.0 && h->env_log2s <= 0) ? 2048 : 4096);
   sa.ablate = h->env_ablate;
+  sa.flat_k = h->env_flat_k;
   sa.dbg = h->d_dbg;
   sa.log2m = h->env_log2m > 0 ? h->env_log2m : 9;
   sa.marks_words = (imax + 3) & ~1;   // one word per wedge column, 0..imax
@@ -541,17 +544,23 @@ int enqueue_frame_pipelined(gv_context *h)
   Rect *rects = h->x_rects[p];
   if (h->since_drain >= h->n_sets) GV_HIP(hipStreamWaitEvent(sA, h->ev_fin[p], 0));   // set p is free again
 
-  int32_t n_rects = 0;
-  if (vision && h->nb > 0) {
-    launch_vision(h->d_orient, h->d_conf, h->d_dims, h->d_bboxes, h->nb, h->cam, h->d_vout, h->d_poses, sA);
-    launch_rects_from_poses(h->d_poses, h->nb, h->g, true, h->x_bc, rects, sA);
-    n_rects = h->nb;
-  } else if (h->n_poses > 0) {
-    mark(sA);
-    launch_rects_from_poses(h->d_poses, h->n_poses, h->g, false, h->x_bc, rects, sA);
-    mark(sA);
-    n_rects = h->n_poses;
-  }
+  // the detection -> rectangle kernels are tiny and only the grid pass reads their output: they run on
+  // the grid-pass stream right before it (same-stream order, no event), off the stream the sector
+  // kernel waits for
+  const bool rects_on_c = h->three_streams && h->rects_on_c;
+  hipStream_t sR = rects_on_c ? h->stream3 : sA;
+  int32_t n_rects = (vision && h->nb > 0) ? h->nb : ((!vision || h->nb <= 0) && h->n_poses > 0 ? h->n_poses : 0);
+  auto launch_rects = [&]() {
+    if (vision && h->nb > 0) {
+      launch_vision(h->d_orient, h->d_conf, h->d_dims, h->d_bboxes, h->nb, h->cam, h->d_vout, h->d_poses, sR);
+      launch_rects_from_poses(h->d_poses, h->nb, h->g, true, h->x_bc, rects, sR);
+    } else if (h->n_poses > 0) {
+      mark(sR);
+      launch_rects_from_poses(h->d_poses, h->n_poses, h->g, false, h->x_bc, rects, sR);
+      mark(sR);
+    }
+  };
+  if (!rects_on_c) launch_rects();
   if (do_bin || do_bbox) {
     PointsArgs a{};
     a.x = h->cx; a.y = h->cy; a.z = h->cz;
@@ -616,6 +625,7 @@ int enqueue_frame_pipelined(gv_context *h)
     launch_ray_sectors(sa, sB);
     mark(sB);
   }
+  if (rects_on_c) launch_rects();   // before the wait: they do not depend on the sector kernel
   if (h->three_streams) {
     GV_HIP(hipEventRecord(h->ev_sec[p], sB));
     GV_HIP(hipStreamWaitEvent(sC, h->ev_sec[p], 0));
@@ -892,6 +902,7 @@ int gv_create(gv_handle *out, uint8_t grid_x, uint8_t grid_y, double resolution,
     h->force_simple = impl && std::strcmp(impl, "simple") == 0;
     if (const char *e = std::getenv("GV_PIPELINE")) { h->no_pipeline = std::atoi(e) == 0; h->three_streams = std::atoi(e) != 2; }
     if (const char *e = std::getenv("GV_HIT_COUNTS")) h->force_counts = std::atoi(e) != 0;
+    if (const char *e = std::getenv("GV_RECTS_ON_C")) h->rects_on_c = std::atoi(e) != 0;
     if (const char *e = std::getenv("GV_SPLIT_POINTS")) h->split_points = std::atoi(e) != 0;
     if (const char *e = std::getenv("GV_SECTOR_STREAMS")) h->sector_streams = std::max(1, std::min(2, std::atoi(e)));
     if (!h->three_streams) h->sector_streams = 1;
@@ -908,6 +919,7 @@ int gv_create(gv_handle *out, uint8_t grid_x, uint8_t grid_y, double resolution,
     if (const char *e = std::getenv("GV_SECTOR_REORDER")) h->env_reorder = std::atoi(e) != 0;
     if (const char *e = std::getenv("GV_CAP")) h->env_cap = std::atoi(e);
     if (const char *e = std::getenv("GV_ABLATE")) h->env_ablate = std::atoi(e);
+    if (const char *e = std::getenv("GV_FLAT_K")) h->env_flat_k = std::max(0, std::atoi(e));
     if (const char *e = std::getenv("GV_SECTOR_DBG")) {
       if (std::atoi(e) > 0) {
         GV_C(hipMalloc(reinterpret_cast<void **>(&h->d_dbg), kMaxStatSlots * 16 * sizeof(unsigned long long)));

@@ -102,6 +102,7 @@ struct SectorArgs {
   uint8_t *missN;         // G bytes, [y][x]
   uint8_t *missT;         // G bytes, [x][y]
   unsigned long long *stats;
+  int32_t flat_k;         // cost ratio exact-cell evaluation : marched cell for the choice beyond T (0: always march when possible)
   int32_t ablate;         // timing experiments only: 2 skip gather, 4 skip flush, 8/16/32 early exits
   unsigned long long *dbg; // diagnostic phase stamps, 16 per workgroup (null in production)
 };

@@ -739,6 +739,17 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
       for (int wv = 0; wv < NT / 64; ++wv) tail_steps += s_wsum[wv];
       const unsigned nlong = s_nlong;
       march_tail = (nlong <= (unsigned)M) && (tail_steps <= 64u * NT);
+      if (march_tail && A.flat_k > 0) {
+        // marching costs ~ one wavefront step per 64 ray cells (+ a partial step per ray); evaluating every
+        // cell beyond T exactly costs ~ flat_k times that per cell: take the cheaper one
+        const int first = T + 1, last = min(oc.imax, (int)maxreach - 1);
+        if (last >= first) {
+          const int wl = ((2 * last * (s + 1) + S) >> (log2s + 1)) - ((2 * last * s + S) >> (log2s + 1)) + 1;
+          const int wf = ((2 * first * (s + 1) + S) >> (log2s + 1)) - ((2 * first * s + S) >> (log2s + 1)) + 1;
+          const unsigned ncells = (unsigned)(last - first + 1) * (unsigned)(wl + wf) / 2u;
+          if ((unsigned)A.flat_k * ncells < tail_steps + 32u * nlong) march_tail = false;
+        }
+      }
       if (A.dbg && tid == 0) {
         A.dbg[(size_t)wg * 16 + 13] = ((unsigned long long)tail_steps << 32) | nlong;
       }
