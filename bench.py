@@ -253,7 +253,7 @@ def main():
         # (2 bits/cell in both orientations = G/2 B) and one miss byte per cell out.
         alg = {"points": 12.0 * N, "ray_ends": 5.0 * G, "ray_march": 1.5 * G, "finalize": 13.0 * G,
                "detections": 120.0 * (len(bboxes) + len(poses))}
-        kern = {"points": "k_points", "ray_ends": "k_build_bitmaps8", "ray_march": "k_ray_sectors",
+        kern = {"points": "k_bin_partition", "ray_ends": "k_bin_tiles", "ray_march": "k_ray_sectors",
                 "finalize": "k_finalize_tiles", "detections": "k_rects_from_poses"}
         dom = max(stages, key=stages.get)
         kernels = [{"stage": k, "kernel": kern[k], "ms": stages[k], "algorithmic_bytes": alg[k],
@@ -277,10 +277,10 @@ def main():
             "metric": f"frames/sec into grid ({N_total // 1000000}M-pt cloud / {g.nx}x{g.ny} @ {g.resolution} m grid)",
             "value": fps, "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "strong" if sharded else "weak",
-            "vs_baseline": None, "dtype": "f32 grid / f64 index / i32 counts", "data": "synthetic",
+            "vs_baseline": None, "dtype": "i32 hit counts / f64 cell index / f32 log-odds", "data": "synthetic",
             "config": {"workload": f"BASELINE configs[{config - 1}]: {N}-point {a.cloud} cloud per GPU, "
                                    f"{g.nx}x{g.ny} @ {g.resolution} m grid, {len(bboxes)} bboxes + {len(poses)} poses, "
-                                   "bin (hit flags; counts: see with_hit_counts) + ray-march + bbox test + grid pass",
+                                   "bin (int32 hit counts) + ray-march + bbox test + grid pass",
                        "points": N, "cells": G, "parallelism": (f"points-sharded x{world} + RCCL reduce-scatter" if sharded else f"frame-per-gpu x{world}"),
                        "devices_visible": ndev},
             "mpoints_per_s": N_total * fps / 1e6,
@@ -291,32 +291,6 @@ def main():
                           "mcell_visits_per_s": (n_visits / (stages["ray_march"] * 1e-3) / 1e6) if stages["ray_march"] > 0 else None},
             "roofline": roof,
         }
-        # The production frame marks hit cells with byte flags (the update rule is binary per cell);
-        # the int32 hit counts of SURVEY X1 are produced on request.  Same workload with the counts
-        # computed every frame (atomics behind the LDS hit cache), reported next to the headline:
-        if not sharded and not a.no_hit_counts:
-            try:
-                os.environ["GV_HIT_COUNTS"] = "1"
-                hc = gvamd.GridVisionHIP(g.grid_x, g.grid_y, g.resolution, device=local_rank)
-                del os.environ["GV_HIT_COUNTS"]
-                hc.set_transforms(tfs["cam_lidar"], tfs["base_cam"], tfs["base_lidar"])
-                hc.upload_xyz(x, y, z)
-                hc.set_detections(flags, bboxes=bboxes, poses=poses)
-                kc = max(20, min(a.steps, 200))
-                for _ in range(10):
-                    hc.enqueue_frame()
-                hc.synchronize()
-                tc0 = time.perf_counter()
-                for _ in range(kc):
-                    hc.enqueue_frame()
-                hc.synchronize()
-                dtc = time.perf_counter() - tc0
-                hc.close()
-                out["with_hit_counts"] = {"value": kc / dtc, "unit": "frames/s", "ms_per_step": dtc / kc * 1e3, "steps": kc,
-                                          "note": "int32 hits[cell] += 1 per point (GV_HIT_COUNTS=1) instead of byte flags; same grid"}
-            except Exception as e:
-                os.environ.pop("GV_HIT_COUNTS", None)
-                print("with_hit_counts measurement failed:", e, file=sys.stderr)
         try:
             copy_gbps = measured_copy_rate(torch)
             out["frame_roofline"]["measured_copy_GBps"] = copy_gbps

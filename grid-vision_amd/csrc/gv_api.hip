@@ -1,5 +1,5 @@
 // gv_api.hip -- C ABI (include/gridvision_hip.h) over the gfx950 kernels.
-// One gv_context = one device + one stream + one resident grid.  No exception
+// One gv_context = one device + one resident grid + its HIP streams.  No exception
 // leaves this file; every entry point returns a gv_status.
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
@@ -16,33 +16,66 @@
 
 using namespace gv;
 
+namespace {
+
+// One of the two resident clouds: frames read the current one on stream A while the copy stream
+// fills the other (cloudCallback / timerCallback overlap, src/grid_vision_node.cpp:103-106,108-244).
+struct CloudSet {
+  float *x = nullptr, *y = nullptr, *z = nullptr;
+  size_t cap = 0;
+  uint8_t *raw = nullptr;       // PointCloud2 bytes before the de-interleave
+  size_t raw_cap = 0;
+  hipEvent_t ready = nullptr;   // copy stream: upload complete
+  hipEvent_t used = nullptr;    // stream A: last frame that reads this set has passed its points pass
+};
+
+// Per-frame detection inputs (bboxes, poses / network outputs) and what the device derives from them.
+// Sets 0/1 alternate between "read by the frames in flight" and "being uploaded"; set 2 belongs to the
+// standalone entry points of the reference surface, which therefore never disturb the frame's inputs.
+struct DetSet {
+  gv_bbox *bboxes = nullptr;
+  gv_lshape_pose *poses = nullptr;
+  float *orient = nullptr, *conf = nullptr, *dims = nullptr;
+  float4 *bbox_f = nullptr;                  // float thresholds of the bbox test
+  unsigned long long *tile_mask = nullptr;   // candidate masks per 16x16-pixel tile
+  size_t tile_mask_cap = 0;
+  int32_t cap = 0;
+  int32_t mask_words = 1;
+  int32_t nb = 0, n_poses = 0;
+  uint32_t flags = 0;
+  bool valid = false;           // a gv_frame_set_detections* call has filled this set
+  uint8_t *stage = nullptr;     // pinned host copy of the caller's arrays (free to reuse on return)
+  size_t stage_cap = 0;
+  hipEvent_t ready = nullptr, used = nullptr;
+};
+
+}  // namespace
+
 struct gv_context {
-  static constexpr int kSetsMax = 4;
+  static constexpr int kSets = 4;
   int device = 0;
-  hipStream_t stream = nullptr;
-  // frame pipelining: points/bitmaps of frame f+1 (stream) overlap sectors/grid pass of frame f (stream2)
-  hipStream_t stream2 = nullptr, stream3 = nullptr;   // B: sector ray stage, C: grid pass
-  hipStream_t stream4 = nullptr;                      // D: bbox test of the points pass when split off (GV_SPLIT_POINTS=1)
-  bool split_points = false;
-  bool rects_on_c = false;                            // GV_RECTS_ON_C=1: rectangle kernels on the grid-pass stream (lidar-like cloud -6 %, uniform +10 %)
-  hipStream_t stream2b = nullptr;                     // B': sector kernels of odd frames, so that one frame's sector
-                                                      // kernel fills the CUs its predecessor's tail leaves idle
-  int sector_streams = 1;                             // GV_SECTOR_STREAMS=2 alternates two sector streams: measured slower (75.9 vs 69.0 us)
-  unsigned long long *x_stats[kSetsMax]{};           // per-set (rays, visits) slots of the sector kernel
-  int last_stats_set = 0;
-  static constexpr int kSets = kSetsMax;                     // buffer sets the pipelined frames rotate through (n_sets in use)
+  // A: detections, partition, tile histogram of frame f+1 (and every non-frame entry point);
+  // B: sector ray stage of frame f;  C: grid pass of frame f;  copy: H2D of the next cloud / detections
+  hipStream_t stream = nullptr, stream2 = nullptr, stream3 = nullptr, stream_copy = nullptr;
   hipEvent_t ev_build[kSets]{}, ev_sec[kSets]{}, ev_fin[kSets]{};
-  std::vector<hipEvent_t> *trace = nullptr;         // diagnostic: timing events around every pipelined kernel (gv_debug_pipeline_trace)
-  int n_sets = 3;                                     // GV_PIPE_SETS (2..4): how far stream A may run ahead
-  // sets 1..: bitmaps, rectangles and miss grids of the frames in flight (set 0 = the primary buffers)
+  hipEvent_t ev_join[3]{};
+  int n_sets = 3;                 // GV_PIPE_SETS (2..4): buffer sets the pipelined frames rotate through
+  // per-set buffers of the frames in flight: end bitmaps, rectangles, miss grids, ray statistics
   uint32_t *x_hitN[kSets]{}, *x_clipN[kSets]{}, *x_hitT[kSets]{}, *x_clipT[kSets]{};
   Rect *x_rects[kSets]{};
   uint8_t *x_miss[kSets]{}, *x_missT[kSets]{};
-  bool three_streams = true;                         // GV_PIPELINE=2: grid pass on stream B (two streams)
+  bool miss_dirty[kSets]{};       // the set holds a kept frame's miss grids (GV_FRAME_KEEP_COUNTS)
+  unsigned long long *x_stats[kSets]{};
+  int last_set = 0;
   uint64_t frame_no = 0;
-  int since_drain = 0;       // pipelined frames enqueued since both streams were last idle
+  int since_drain = 0;            // pipelined frames enqueued since every stream was last idle
   bool pipe_busy = false;
-  bool no_pipeline = false;  // GV_PIPELINE=0
+  bool no_pipeline = false;       // GV_PIPELINE=0
+#ifdef GV_DIAG
+  std::vector<hipEvent_t> *trace = nullptr;   // timing events around every pipelined kernel (gv_debug_pipeline_trace)
+  unsigned long long *d_dbg = nullptr;        // GV_SECTOR_DBG=1: phase stamps of the sector kernel
+  int32_t env_ablate = 0;                     // GV_ABLATE
+#endif
   GridParams g{};
   gv_cam_params cam{};
   CamK camk{};
@@ -58,43 +91,51 @@ struct gv_context {
   float *log_odds = nullptr, *occupancy = nullptr;
   int8_t *occ_i8 = nullptr;
   // per-frame count grids
-  int32_t *hits = nullptr;
-  uint8_t *miss = nullptr, *clip_end = nullptr, *hit8 = nullptr;
+  int32_t *hits = nullptr;                  // tile path: every cell written by every BIN frame
+  uint8_t *clip_end = nullptr;              // generic path only
   uint32_t *ray_list = nullptr;
   uint32_t *ray_count = nullptr;            // [0] = number of list entries
-  unsigned long long *ray_stats = nullptr;  // [0] rays, [1] visits
-  int32_t *scratch_i32 = nullptr;           // G ints (miss read-back)
-  // sector/gather ray stage
-  uint8_t *missT = nullptr;                 // G bytes, [x][y]
-  uint32_t *hitN = nullptr, *clipN = nullptr, *hitT = nullptr, *clipT = nullptr;
+  int32_t *scratch_i32 = nullptr;           // G ints (miss read-back), also max(N) ints for id read-back
+  size_t scratch_cap = 0;
   int32_t nxw = 0, nyw = 0, nx_pad = 0, ny_pad = 0;
   bool tile_path = false;                   // nx % 4 == 0 and the grid fits the packed (a,b) fields
   bool force_simple = false;                // GV_RAY_IMPL=simple
   int env_reorder = 1;                      // GV_SECTOR_REORDER=0: workgroups in natural (octant, sector) order
-  int32_t last_log2s = 0, last_cap = 0;
-  unsigned long long *d_dbg = nullptr;      // GV_SECTOR_DBG=1: phase stamps of the sector kernel
-  size_t stat_slots = 1;                    // ray_stats slots written by the last frame
-  int32_t env_log2s_oct[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // GV_LOG2S_OCT="a,b,..." per octant index (experiments)
-  int32_t env_flat_k = 8;                   // GV_FLAT_K: exact-cell : marched-cell cost ratio (tools/flatk.sh: 8 is best on both clouds; 0 = always march)
-  int32_t env_log2s = 0, env_cap = 0, env_ablate = 0, env_log2m = 0;   // GV_LOG2S / GV_CAP / GV_ABLATE (experiments)
+  size_t stat_slots = 1;                    // ray statistics slots written by the last frame
+  int32_t env_log2s_oct[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // GV_LOG2S_OCT="a,b,..." per octant index (sweeps)
+  int32_t env_flat_k = 8;                   // GV_FLAT_K: exact-cell : marched-cell cost ratio (0 = always march)
+  int32_t env_log2s = 0, env_cap = 0, env_log2m = 0;     // GV_LOG2S / GV_CAP / GV_LOG2M (sweeps)
 
-  // resident cloud
-  float *cx = nullptr, *cy = nullptr, *cz = nullptr;
-  size_t n = 0, cap = 0;
+  // tile-path binning (gv_binning.hip)
+  int32_t tiles_x = 0, tiles_y = 0, n_tiles = 0;
+  uint16_t *bin_keys = nullptr, *bin_tab = nullptr;
+  size_t bin_keys_cap = 0, bin_tab_cap = 0;
+  uint32_t *bin_total[2] = {nullptr, nullptr};
+  uint32_t *bin_done = nullptr, *bin_scratch = nullptr;
+  size_t bin_slots = 0;
+  int bin_parity = 0;
+
+  // resident clouds
+  CloudSet cloud[2];
+  int cloud_cur = 0;
+  bool cloud_wait = false;                  // stream A has not yet waited for cloud[cloud_cur].ready
+  float *cx = nullptr, *cy = nullptr, *cz = nullptr;   // = cloud[cloud_cur]
+  size_t n = 0;
   float *tx = nullptr, *ty = nullptr, *tz = nullptr;   // transformed copy (A1 read-back)
   size_t tcap = 0;
-  uint8_t *raw = nullptr;
-  size_t raw_cap = 0;
-  int32_t *cell_idx = nullptr, *bbox_id = nullptr;
+  int32_t *cell_idx = nullptr;
+  int16_t *bbox_id = nullptr;
   size_t idx_cap = 0;
 
-  // detections of the current frame
-  gv_bbox *d_bboxes = nullptr;
-  gv_lshape_pose *d_poses = nullptr;
-  Rect *d_rects = nullptr;
-  float *d_orient = nullptr, *d_conf = nullptr, *d_dims = nullptr;
+  // detections
+  DetSet det[3];
+  int det_cur = 0;
+  bool det_wait = false;
+  int32_t bt_tiles_x = 1, bt_tiles_y = 1;   // 16x16-pixel tiles of the image
   VisionOut *d_vout = nullptr;
+  int32_t vout_cap = 0;
   double *d_pts = nullptr;
+  int32_t pts_cap = 0;
   // kNN depth / PCA pose scratch
   Cand2 *knn_partial = nullptr; size_t knn_partial_cap = 0;
   float *d_depths = nullptr, *d_knn_d2 = nullptr; size_t knn_out_cap = 0;
@@ -103,18 +144,9 @@ struct gv_context {
   float4 *d_planes = nullptr; unsigned *d_plane_counts = nullptr; size_t planes_cap = 0;
   uint8_t *d_ground = nullptr; size_t ground_cap = 0;
   std::vector<uint8_t> ground_mask;   // last gv_segment_ground_plane result (host copy)
-  float4 *d_bbox_f = nullptr;                // float thresholds of the bbox test
-  unsigned long long *d_tile_mask = nullptr; // candidate masks per 16x16-pixel tile
-  size_t tile_mask_cap = 0;
-  int32_t tiles_x = 0, tiles_y = 0, mask_words = 1;
-  int32_t det_cap = 0;
-  uint32_t frame_flags = 0;
-  int32_t nb = 0, n_poses = 0;
 
-  bool counts_dirty = false;   // hits/miss/clip_end hold a kept frame
-  bool frame_counts = false;   // the frame in flight used int32 hit counts (else byte flags)
-  bool force_counts = false;   // GV_HIT_COUNTS=1: always count (A/B measurement of the atomics path)
-  bool have_counts = false, have_cell_idx = false, have_bbox_id = false;
+  bool counts_dirty = false;   // generic path: hits/miss/clip_end hold a kept frame
+  bool have_hits = false, have_miss = false, have_cell_idx = false, have_bbox_id = false;
 
   // multi-GPU (one large frame sharded by points)
   ncclComm_t comm = nullptr;
@@ -163,60 +195,20 @@ int grow(gv_context *h, T *&p, size_t &cap, size_t need)
   return GV_OK;
 }
 
-int ensure_cloud(gv_context *h, size_t n)
+int drain(gv_context *h)
 {
-  if (n > h->cap) {
-    const size_t want = n + n / 8 + 1024;
-    for (float **p : {&h->cx, &h->cy, &h->cz}) {
-      if (*p) GV_HIP(hipFree(*p));
-      *p = nullptr;
-    }
-    h->cap = 0;
-    GV_HIP(hipMalloc(reinterpret_cast<void **>(&h->cx), want * sizeof(float)));
-    GV_HIP(hipMalloc(reinterpret_cast<void **>(&h->cy), want * sizeof(float)));
-    GV_HIP(hipMalloc(reinterpret_cast<void **>(&h->cz), want * sizeof(float)));
-    h->cap = want;
-  }
-  if (n > h->idx_cap) {
-    const size_t want = n + n / 8 + 1024;
-    for (int32_t **p : {&h->cell_idx, &h->bbox_id}) {
-      if (*p) GV_HIP(hipFree(*p));
-      *p = nullptr;
-    }
-    h->idx_cap = 0;
-    GV_HIP(hipMalloc(reinterpret_cast<void **>(&h->cell_idx), want * sizeof(int32_t)));
-    GV_HIP(hipMalloc(reinterpret_cast<void **>(&h->bbox_id), want * sizeof(int32_t)));
-    h->idx_cap = want;
-  }
+  GV_HIP(hipStreamSynchronize(h->stream_copy));
+  GV_HIP(hipStreamSynchronize(h->stream));
+  GV_HIP(hipStreamSynchronize(h->stream2));
+  GV_HIP(hipStreamSynchronize(h->stream3));
+  h->pipe_busy = false;
+  h->since_drain = 0;
+  h->cloud_wait = false;
+  h->det_wait = false;
   return GV_OK;
 }
 
-int ensure_det(gv_context *h, int32_t n)
-{
-  if (n <= h->det_cap) return GV_OK;
-  const int32_t want = std::max(n, 64);
-  auto re = [&](auto *&p, size_t bytes) -> int {
-    if (p) GV_HIP(hipFree(p));
-    p = nullptr;
-    GV_HIP(hipMalloc(reinterpret_cast<void **>(&p), bytes));
-    return GV_OK;
-  };
-  int rc;
-  if ((rc = re(h->d_bboxes, (size_t)want * sizeof(gv_bbox)))) return rc;
-  if ((rc = re(h->d_poses, (size_t)want * sizeof(gv_lshape_pose)))) return rc;
-  if ((rc = re(h->d_rects, (size_t)want * sizeof(Rect)))) return rc;
-  for (int k = 1; k < gv_context::kSets; ++k)
-    if ((rc = re(h->x_rects[k], (size_t)want * sizeof(Rect)))) return rc;
-  h->x_rects[0] = h->d_rects;
-  if ((rc = re(h->d_orient, (size_t)want * 4 * sizeof(float)))) return rc;
-  if ((rc = re(h->d_conf, (size_t)want * 2 * sizeof(float)))) return rc;
-  if ((rc = re(h->d_dims, (size_t)want * 3 * sizeof(float)))) return rc;
-  if ((rc = re(h->d_vout, (size_t)want * sizeof(VisionOut)))) return rc;
-  if ((rc = re(h->d_pts, (size_t)want * 3 * sizeof(double)))) return rc;
-  if ((rc = re(h->d_bbox_f, (size_t)want * sizeof(float4)))) return rc;
-  h->det_cap = want;
-  return GV_OK;
-}
+bool sector_path(const gv_context *h) { return h->tile_path && !h->force_simple; }
 
 int set_device_only(gv_context *h)
 {
@@ -224,19 +216,107 @@ int set_device_only(gv_context *h)
   return GV_OK;
 }
 
-// Every entry point except the pipelined gv_frame_enqueue starts from two idle streams.
+// Every entry point except the streaming ones (gv_frame_enqueue, gv_*_async, the uploads) starts from
+// idle streams: its work on stream A then sees every earlier frame and upload completed.
 int use_device(gv_context *h)
 {
   GV_HIP(hipSetDevice(h->device));
-  if (h->pipe_busy) {
-    GV_HIP(hipStreamSynchronize(h->stream));
-    GV_HIP(hipStreamSynchronize(h->stream2));
-    GV_HIP(hipStreamSynchronize(h->stream2b));
-    GV_HIP(hipStreamSynchronize(h->stream3));
-    GV_HIP(hipStreamSynchronize(h->stream4));
-    h->pipe_busy = false;
-    h->since_drain = 0;
+  if (h->pipe_busy || h->cloud_wait || h->det_wait) return drain(h);
+  return GV_OK;
+}
+
+// buffers whose size follows the cloud: per-point outputs and the binning scratch.  They live on
+// stream A only, so growing them needs the frames in flight to finish first (rare: the cloud grew).
+int ensure_point_buffers(gv_context *h, size_t n)
+{
+  const bool need_idx = n > h->idx_cap || !h->cell_idx;
+  const uint32_t chunk = bin_chunk_for(n);
+  const size_t n_wg = (n + chunk - 1) / chunk;
+  const size_t keys_need = n_wg * chunk + 2, tab_need = n_wg * ((size_t)h->n_tiles + 1) + 2;
+  const size_t slots_need = n / kBinSplitKeys + 1;
+  const bool need_bin = sector_path(h) && (keys_need > h->bin_keys_cap || tab_need > h->bin_tab_cap || slots_need > h->bin_slots);
+  if (!need_idx && !need_bin) return GV_OK;
+  int rc = drain(h);
+  if (rc) return rc;
+  if (need_idx) {
+    const size_t want = n + n / 8 + 1024;
+    if (h->cell_idx) GV_HIP(hipFree(h->cell_idx));
+    if (h->bbox_id) GV_HIP(hipFree(h->bbox_id));
+    h->cell_idx = nullptr;
+    h->bbox_id = nullptr;
+    h->idx_cap = 0;
+    GV_HIP(hipMalloc(reinterpret_cast<void **>(&h->cell_idx), want * sizeof(int32_t)));
+    GV_HIP(hipMalloc(reinterpret_cast<void **>(&h->bbox_id), want * sizeof(int16_t)));
+    h->idx_cap = want;
   }
+  if (need_bin) {
+    if ((rc = grow(h, h->bin_keys, h->bin_keys_cap, keys_need + keys_need / 8))) return rc;
+    if ((rc = grow(h, h->bin_tab, h->bin_tab_cap, tab_need + tab_need / 8))) return rc;
+    if (slots_need > h->bin_slots) {
+      const size_t want = slots_need + slots_need / 8;
+      if (h->bin_scratch) GV_HIP(hipFree(h->bin_scratch));
+      h->bin_scratch = nullptr;
+      h->bin_slots = 0;
+      GV_HIP(hipMalloc(reinterpret_cast<void **>(&h->bin_scratch), want * kBinSplitMax * ((size_t)kBinTileCells + 512) * sizeof(uint32_t)));
+      h->bin_slots = want;
+    }
+  }
+  return GV_OK;
+}
+
+int ensure_scratch_i32(gv_context *h, size_t n)
+{
+  if (n <= h->scratch_cap) return GV_OK;
+  return grow(h, h->scratch_i32, h->scratch_cap, n + n / 8);
+}
+
+int ensure_det(gv_context *h, DetSet &d, int32_t n)
+{
+  if (n <= d.cap) return GV_OK;
+  if (d.used) GV_HIP(hipEventSynchronize(d.used));     // frames that read this set are past it
+  if (d.ready) GV_HIP(hipEventSynchronize(d.ready));
+  const int32_t want = std::max(n + n / 4, 64);
+  auto re = [&](auto *&p, size_t bytes) -> int {
+    if (p) GV_HIP(hipFree(p));
+    p = nullptr;
+    GV_HIP(hipMalloc(reinterpret_cast<void **>(&p), bytes));
+    return GV_OK;
+  };
+  int rc;
+  d.cap = 0;
+  if ((rc = re(d.bboxes, (size_t)want * sizeof(gv_bbox)))) return rc;
+  if ((rc = re(d.poses, (size_t)want * sizeof(gv_lshape_pose)))) return rc;
+  if ((rc = re(d.orient, (size_t)want * 4 * sizeof(float)))) return rc;
+  if ((rc = re(d.conf, (size_t)want * 2 * sizeof(float)))) return rc;
+  if ((rc = re(d.dims, (size_t)want * 3 * sizeof(float)))) return rc;
+  if ((rc = re(d.bbox_f, (size_t)want * sizeof(float4)))) return rc;
+  const size_t nmask = (size_t)h->bt_tiles_x * h->bt_tiles_y * (size_t)((want + 63) / 64);
+  if ((rc = grow(h, d.tile_mask, d.tile_mask_cap, nmask))) return rc;
+  d.cap = want;
+  return GV_OK;
+}
+
+// rectangles (all pipeline sets), vision outputs and centre points follow the detection count; they
+// are written on stream A / C by the frames in flight, hence the drain
+int ensure_det_shared(gv_context *h, int32_t n)
+{
+  if (n <= h->vout_cap) return GV_OK;
+  int rc = drain(h);
+  if (rc) return rc;
+  const int32_t want = std::max(n + n / 4, 64);
+  auto re = [&](auto *&p, size_t bytes) -> int {
+    if (p) GV_HIP(hipFree(p));
+    p = nullptr;
+    GV_HIP(hipMalloc(reinterpret_cast<void **>(&p), bytes));
+    return GV_OK;
+  };
+  h->vout_cap = 0;
+  for (int k = 0; k < gv_context::kSets; ++k)
+    if ((rc = re(h->x_rects[k], (size_t)want * sizeof(Rect)))) return rc;
+  if ((rc = re(h->d_vout, (size_t)want * sizeof(VisionOut)))) return rc;
+  if ((rc = re(h->d_pts, (size_t)want * 3 * sizeof(double)))) return rc;
+  h->vout_cap = want;
+  h->pts_cap = want;
   return GV_OK;
 }
 
@@ -251,34 +331,98 @@ void refresh_origin(gv_context *h)
   h->org.cy = iy;
 }
 
+// generic path: the atomics-based count grids start every frame from zero
 int clear_counts(gv_context *h)
 {
   const size_t G = (size_t)h->g.G;
   GV_HIP(hipMemsetAsync(h->hits, 0, G * sizeof(int32_t), h->stream));
-  GV_HIP(hipMemsetAsync(h->miss, 0, G, h->stream));
+  GV_HIP(hipMemsetAsync(h->x_miss[0], 0, G, h->stream));
   GV_HIP(hipMemsetAsync(h->clip_end, 0, G, h->stream));
-  GV_HIP(hipMemsetAsync(h->hit8, 0, G, h->stream));
-  GV_HIP(hipMemsetAsync(h->missT, 0, G, h->stream));
   h->counts_dirty = false;
   return GV_OK;
 }
 
-// plain grid update (A7 / A8 / A10): rectangles already in d_rects
+BBoxTest bbox_test_of(const gv_context *h, const DetSet &d)
+{
+  BBoxTest t;
+  t.bbox_f = d.bbox_f;
+  t.tile_mask = d.tile_mask;
+  t.tiles_x = h->bt_tiles_x;
+  t.tiles_y = h->bt_tiles_y;
+  t.mask_words = d.mask_words;
+  return t;
+}
+
+// Upload the small per-frame arrays into detection set `d` on stream `s` and derive the bbox-test
+// tables there.  The caller's arrays are copied into the set's pinned staging first, so they are free
+// on return and the H2D copies are asynchronous.
+int upload_det(gv_context *h, DetSet &d, const gv_bbox *bboxes, int32_t nb, const gv_lshape_pose *poses,
+               int32_t n_poses, const float *orient, const float *conf, const float *dims, hipStream_t s)
+{
+  int rc = ensure_det(h, d, std::max(nb, n_poses));
+  if (rc) return rc;
+  if ((rc = ensure_det_shared(h, std::max(nb, n_poses)))) return rc;
+  const size_t b_bytes = (size_t)nb * sizeof(gv_bbox), p_bytes = (size_t)n_poses * sizeof(gv_lshape_pose);
+  const size_t o_bytes = orient ? (size_t)nb * 4 * sizeof(float) : 0, c_bytes = conf ? (size_t)nb * 2 * sizeof(float) : 0;
+  const size_t d_bytes = dims ? (size_t)nb * 3 * sizeof(float) : 0;
+  const size_t total = b_bytes + p_bytes + o_bytes + c_bytes + d_bytes;
+  if (d.ready) GV_HIP(hipEventSynchronize(d.ready));   // the staging's previous copy has left it
+  if (total > d.stage_cap) {
+    if (d.stage) GV_HIP(hipHostFree(d.stage));
+    d.stage = nullptr;
+    d.stage_cap = 0;
+    const size_t want = total + total / 2 + 4096;
+    GV_HIP(hipHostMalloc(reinterpret_cast<void **>(&d.stage), want, hipHostMallocDefault));
+    d.stage_cap = want;
+  }
+  uint8_t *q = d.stage;
+  auto put = [&](void *dev, const void *src, size_t bytes) -> int {
+    if (!bytes) return GV_OK;
+    std::memcpy(q, src, bytes);
+    GV_HIP(hipMemcpyAsync(dev, q, bytes, hipMemcpyHostToDevice, s));
+    q += bytes;
+    return GV_OK;
+  };
+  if ((rc = put(d.bboxes, bboxes, b_bytes))) return rc;
+  if ((rc = put(d.poses, poses, p_bytes))) return rc;
+  if ((rc = put(d.orient, orient, o_bytes))) return rc;
+  if ((rc = put(d.conf, conf, c_bytes))) return rc;
+  if ((rc = put(d.dims, dims, d_bytes))) return rc;
+  d.mask_words = std::max(1, (nb + 63) / 64);
+  launch_bbox_prepare(d.bboxes, nb, h->bt_tiles_x, h->bt_tiles_y, d.mask_words, d.bbox_f, d.tile_mask, s);
+  GV_HIP(hipGetLastError());
+  d.nb = nb;
+  d.n_poses = n_poses;
+  d.valid = true;
+  return GV_OK;
+}
+
+// bboxes only, synchronously, into the standalone set (extractCloudPerBBox and friends)
+int upload_scratch_bboxes(gv_context *h, const gv_bbox *b, int32_t nb)
+{
+  DetSet &d = h->det[2];
+  int rc = upload_det(h, d, b, nb, nullptr, 0, nullptr, nullptr, nullptr, h->stream);
+  if (rc) return rc;
+  GV_HIP(hipEventRecord(d.ready, h->stream));
+  return GV_OK;
+}
+
+// plain grid update (A7 / A8 / A10): rectangles already in x_rects[0]
 int enqueue_plain_update(gv_context *h, int32_t n_rects)
 {
-  if (h->tile_path) {
+  if (sector_path(h)) {
     FinalizeTileArgs t{};
     t.g = h->g;
     t.log_odds = h->log_odds;
     t.occupancy = h->occupancy;
     t.occ_i8 = h->occ_i8;
-    t.rects = h->d_rects;
+    t.rects = h->x_rects[0];
     t.n_rects = n_rects;
-    t.hitN = h->hitN;
+    t.hitN = h->x_hitN[0];
     t.nxw = h->nxw;
     t.ny_pad = h->ny_pad;
-    t.missN = h->miss;
-    t.missT = h->missT;
+    t.missN = h->x_miss[0];
+    t.missT = h->x_missT[0];
     t.counts = false;
     t.zero = false;
     t.use_missT = false;
@@ -293,7 +437,7 @@ int enqueue_plain_update(gv_context *h, int32_t n_rects)
   f.log_odds = h->log_odds;
   f.occupancy = h->occupancy;
   f.occ_i8 = h->occ_i8;
-  f.rects = h->d_rects;
+  f.rects = h->x_rects[0];
   f.n_rects = n_rects;
   f.hits = nullptr;
   f.miss = nullptr;
@@ -308,8 +452,8 @@ int enqueue_plain_update(gv_context *h, int32_t n_rects)
 
 int sharded_tail(gv_context *h, int32_t n_rects);
 
-// sector-kernel launch parameters for the resident cloud and grid (set-0 bitmaps by default)
-int fill_sector_args(gv_context *h, SectorArgs &sa)
+// sector-kernel launch parameters for the resident cloud and grid, buffer set p
+int fill_sector_args(gv_context *h, SectorArgs &sa, int p)
 {
   sa.g = h->g;
   sa.org = h->org;
@@ -332,7 +476,6 @@ int fill_sector_args(gv_context *h, SectorArgs &sa)
   // 1024 workgroups, 84 -> 76 us pipelined.  Wider wedges (S = 16 for 340 columns) lose again.
   const double dens = std::min((double)h->n, (double)h->g.G) / (double)h->g.G;
   double est_max = 0.0;
-  int log2s_max = 0;
   for (int o = 0; o < 8; ++o) {
     int l2 = 3;   // the gap-sector logic wants S >= 8
     while ((16 << l2) < len[o]) ++l2;
@@ -345,12 +488,15 @@ int fill_sector_args(gv_context *h, SectorArgs &sa)
     if (h->env_log2s_oct[o] > 0) { l2 = h->env_log2s_oct[o]; est = 1.5 * dens * (double)len[o] * (double)len[o] / (double)(2 << l2); }
     sa.log2s_oct[o] = (uint8_t)l2;
     est_max = std::max(est_max, est);
-    log2s_max = std::max(log2s_max, l2);
   }
   sa.cap = h->env_cap > 0 ? std::max(2048, h->env_cap) : ((est_max <= 1700.0 && h->env_log2s <= 0) ? 2048 : 4096);
+  sa.ablate = 0;
+  sa.dbg = nullptr;
+#ifdef GV_DIAG
   sa.ablate = h->env_ablate;
-  sa.flat_k = h->env_flat_k;
   sa.dbg = h->d_dbg;
+#endif
+  sa.flat_k = h->env_flat_k;
   sa.log2m = h->env_log2m > 0 ? h->env_log2m : 9;
   sa.marks_words = (imax + 3) & ~1;   // one word per wedge column, 0..imax
   std::stable_sort(ord, ord + 8, [&](int a, int b) { return len[a] > len[b]; });
@@ -364,205 +510,87 @@ int fill_sector_args(gv_context *h, SectorArgs &sa)
   }
   if (base > kMaxStatSlots || base > 65535u) { h->err = "too many sector workgroups"; return GV_ERR_BAD_ARG; }
   sa.wg_base[8] = (uint16_t)base;
-  sa.hitN = h->hitN; sa.clipN = h->clipN; sa.hitT = h->hitT; sa.clipT = h->clipT;
+  sa.hitN = h->x_hitN[p]; sa.clipN = h->x_clipN[p]; sa.hitT = h->x_hitT[p]; sa.clipT = h->x_clipT[p];
   sa.nxw = h->nxw; sa.nyw = h->nyw; sa.nx_pad = h->nx_pad; sa.ny_pad = h->ny_pad;
-  sa.missN = h->miss;
-  sa.missT = h->missT;
-  sa.stats = h->ray_stats;
-  h->last_stats_set = 0;
-  h->last_log2s = log2s_max;
-  h->last_cap = sa.cap;
+  sa.missN = h->x_miss[p];
+  sa.missT = h->x_missT[p];
+  sa.stats = h->x_stats[p];
   h->stat_slots = (size_t)sa.wg_base[8];
   return GV_OK;
 }
 
-
-int enqueue_frame(gv_context *h, bool stage_events, bool sharded = false)
+// poses / network outputs of detection set D -> index rectangles on stream s
+int32_t enqueue_rects(gv_context *h, const DetSet &D, Rect *rects, hipStream_t s)
 {
-  const uint32_t fl = h->frame_flags;
+  const bool vision = D.flags & GV_FRAME_VISION_ORIENT;
+  if (vision && D.nb > 0) {
+    launch_vision(D.orient, D.conf, D.dims, D.bboxes, D.nb, h->cam, h->d_vout, D.poses, s);
+    launch_rects_from_poses(D.poses, D.nb, h->g, true, h->x_bc, rects, s);
+    return D.nb;
+  }
+  if (!vision && D.n_poses > 0) {
+    launch_rects_from_poses(D.poses, D.n_poses, h->g, false, h->x_bc, rects, s);
+    return D.n_poses;
+  }
+  return 0;
+}
+
+int check_frame_flags(const gv_context *h, uint32_t fl)
+{
   const bool do_bin = fl & GV_FRAME_BIN, do_ray = fl & GV_FRAME_RAYMARCH, do_bbox = fl & GV_FRAME_BBOX_TEST;
-  const bool keep_cell = fl & GV_FRAME_KEEP_CELL_IDX, keep_counts = fl & GV_FRAME_KEEP_COUNTS;
-  const bool vision = fl & GV_FRAME_VISION_ORIENT;
   if (do_ray && !do_bin) return GV_ERR_BAD_ARG;
-  if (sharded && (!do_bin || !h->tile_path || h->force_simple || !h->comm)) return GV_ERR_STATE;
   if (do_bin && !h->has_bl) return GV_ERR_TF;
   if (do_bbox && !h->has_cl) return GV_ERR_TF;
-  if (vision && !h->has_bc) return GV_ERR_TF;
-  if (h->counts_dirty) { int rc = clear_counts(h); if (rc) return rc; }
-  if (stage_events) GV_HIP(hipEventRecord(h->ev[0], h->stream));
-  // int32 hit counts only where someone reads them (KEEP_COUNTS getter, generic ray path);
-  // otherwise points mark byte flags (no atomics)
-  const bool sectors = h->tile_path && !h->force_simple;
-  const bool counts = keep_counts || !sectors || h->force_counts;
-  h->frame_counts = counts;
-
-  // --- detections -> rectangles
-  int32_t n_rects = 0;
-  if (vision && h->nb > 0) {
-    launch_vision(h->d_orient, h->d_conf, h->d_dims, h->d_bboxes, h->nb, h->cam, h->d_vout, h->d_poses, h->stream);
-    launch_rects_from_poses(h->d_poses, h->nb, h->g, true, h->x_bc, h->d_rects, h->stream);
-    n_rects = h->nb;
-  } else if (h->n_poses > 0) {
-    launch_rects_from_poses(h->d_poses, h->n_poses, h->g, false, h->x_bc, h->d_rects, h->stream);
-    n_rects = h->n_poses;
-  }
-  if (stage_events) GV_HIP(hipEventRecord(h->ev[kStageDetections + 1], h->stream));
-
-  // --- points pass
-  if (do_bin || do_bbox) {
-    PointsArgs a{};
-    a.x = h->cx; a.y = h->cy; a.z = h->cz;
-    a.n = (uint32_t)h->n;
-    a.g = h->g;
-    a.m_base = h->m_base;
-    a.m_cam = h->m_cam;
-    a.cam = h->camk;
-    a.org = h->org;
-    a.bboxes = h->d_bboxes;
-    a.nb = h->nb;
-    a.bbox_f = h->d_bbox_f;
-    a.tile_mask = h->d_tile_mask;
-    a.tiles_x = h->tiles_x; a.tiles_y = h->tiles_y; a.mask_words = h->mask_words;
-    a.hits = h->hits;
-    a.hit8 = h->hit8;
-    a.clip_end = h->clip_end;
-    a.cell_idx = keep_cell ? h->cell_idx : nullptr;
-    a.bbox_id = h->bbox_id;
-    a.do_bin = do_bin; a.do_ray = do_ray; a.do_bbox = do_bbox;
-    a.counts = counts;
-    launch_points(a, h->stream);
-  }
-  if (stage_events) GV_HIP(hipEventRecord(h->ev[kStagePoints + 1], h->stream));
-
-  if (sectors) {
-    // --- end bitmaps (both orientations), sector gather, tile grid pass
-    if (do_bin) {
-      BitmapArgs b{};
-      b.nx = h->g.nx; b.ny = h->g.ny;
-      b.hits = h->hits; b.clip_end = h->clip_end;
-      b.hit8 = counts ? nullptr : h->hit8;
-      b.hitN = h->hitN; b.clipN = h->clipN; b.hitT = h->hitT; b.clipT = h->clipT;
-      b.nxw = h->nxw; b.nyw = h->nyw; b.nx_pad = h->nx_pad; b.ny_pad = h->ny_pad;
-      b.zero_hits = !keep_counts && !sharded;   // the sharded path reduces the counts first
-      launch_build_bitmaps(b, h->stream);
-    }
-    if (stage_events) GV_HIP(hipEventRecord(h->ev[kStageRayCompact + 1], h->stream));
-    if (do_ray && h->org.valid) {
-      SectorArgs sa{};
-      { int rc2 = fill_sector_args(h, sa); if (rc2) return rc2; }
-      launch_ray_sectors(sa, h->stream);
-    }
-    if (stage_events) GV_HIP(hipEventRecord(h->ev[kStageRayMarch + 1], h->stream));
-    if (sharded) return sharded_tail(h, n_rects);
-    FinalizeTileArgs t{};
-    t.g = h->g;
-    t.log_odds = h->log_odds;
-    t.occupancy = h->occupancy;
-    t.occ_i8 = h->occ_i8;
-    t.rects = h->d_rects;
-    t.n_rects = n_rects;
-    t.hitN = h->hitN;
-    t.nxw = h->nxw;
-    t.ny_pad = h->ny_pad;
-    t.missN = h->miss;
-    t.missT = h->missT;
-    t.counts = do_bin;
-    t.zero = do_bin && !keep_counts;
-    t.use_missT = true;
-    t.y_begin = 0;
-    t.y_end = h->g.ny;
-    launch_finalize_tiles(t, h->stream);
-    if (stage_events) GV_HIP(hipEventRecord(h->ev[kStageFinalize + 1], h->stream));
-    GV_HIP(hipGetLastError());
-  } else {
-  // --- ray march (generic path: any grid shape)
-  if (do_ray && h->org.valid) {
-    GV_HIP(hipMemsetAsync(h->ray_count, 0, sizeof(uint32_t), h->stream));
-    GV_HIP(hipMemsetAsync(h->ray_stats, 0, 2 * sizeof(unsigned long long), h->stream));
-    h->stat_slots = 1;
-    h->last_stats_set = 0;
-    launch_ray_compact(h->hits, h->clip_end, h->g, h->ray_list, h->ray_count, h->stream);
-    if (stage_events) GV_HIP(hipEventRecord(h->ev[kStageRayCompact + 1], h->stream));
-    launch_ray_march(h->ray_list, h->ray_count, h->g, h->org, h->miss, h->ray_stats, h->stream);
-    if (stage_events) GV_HIP(hipEventRecord(h->ev[kStageRayMarch + 1], h->stream));
-  } else if (stage_events) {
-    GV_HIP(hipEventRecord(h->ev[kStageRayCompact + 1], h->stream));
-    GV_HIP(hipEventRecord(h->ev[kStageRayMarch + 1], h->stream));
-  }
-
-  // --- one grid pass
-  FinalizeArgs f{};
-  f.g = h->g;
-  f.log_odds = h->log_odds;
-  f.occupancy = h->occupancy;
-  f.occ_i8 = h->occ_i8;
-  f.rects = h->d_rects;
-  f.n_rects = n_rects;
-  f.hits = do_bin ? h->hits : nullptr;
-  f.miss = h->miss;
-  f.clip_end = h->clip_end;
-  f.zero_counts = do_bin && !keep_counts;
-  f.cell_begin = 0;
-  f.cell_end = h->g.G;
-  launch_finalize(f, h->stream);
-  if (stage_events) GV_HIP(hipEventRecord(h->ev[kStageFinalize + 1], h->stream));
-  GV_HIP(hipGetLastError());
-  }
-
-  h->counts_dirty = do_bin && keep_counts;
-  h->have_counts = do_bin && keep_counts;
-  h->have_cell_idx = do_bin && keep_cell;
-  h->have_bbox_id = do_bbox;
+  if ((fl & GV_FRAME_VISION_ORIENT) && !h->has_bc) return GV_ERR_TF;
   return GV_OK;
 }
 
-// Pipelined frame (production path): stream A = rectangles, points pass, end bitmaps of frame f;
-// stream B = sector ray stage + grid pass of frame f.  A may run up to two frames ahead of B:
-// the end bitmaps and rectangles are double buffered (set f & 1), everything else is either
-// private to one stream (hits/clip_end: A; miss grids, grid layers: B) or ordered by events.
-int enqueue_frame_pipelined(gv_context *h)
+// The tile-path frame.  pipelined: stream A = rectangles, partition, tile histogram + end bitmaps of
+// frame f; stream B = sector ray stage; stream C = grid pass, over n_sets rotating buffer sets, so that A
+// runs up to n_sets frames ahead.  Serial (GV_PIPELINE=0, stage timing, the sharded frame): the same
+// launches on stream A alone, buffer set 0.
+int enqueue_frame_tiles(gv_context *h, bool pipelined, bool stage_events, bool sharded = false)
 {
-  auto mark = [&](hipStream_t st) {   // diagnostic build-up of a device timeline; null in production
+  DetSet &D = h->det[h->det_cur];
+  const uint32_t fl = D.flags;
+  const bool do_bin = fl & GV_FRAME_BIN, do_ray = fl & GV_FRAME_RAYMARCH, do_bbox = fl & GV_FRAME_BBOX_TEST;
+  const bool keep_cell = fl & GV_FRAME_KEEP_CELL_IDX, keep_counts = fl & GV_FRAME_KEEP_COUNTS;
+  int rc = check_frame_flags(h, fl);
+  if (rc) return rc;
+  if (sharded && (!do_bin || !h->comm)) return GV_ERR_STATE;
+  const int p = pipelined ? (int)(h->frame_no % (unsigned)h->n_sets) : 0;
+  hipStream_t sA = h->stream, sB = pipelined ? h->stream2 : sA, sC = pipelined ? h->stream3 : sA;
+  CloudSet &CS = h->cloud[h->cloud_cur];
+#ifdef GV_DIAG
+  auto mark = [&](hipStream_t st) {   // device timeline of the pipelined frame (gv_debug_pipeline_trace)
     if (!h->trace) return;
     hipEvent_t e;
     if (hipEventCreate(&e) != hipSuccess) return;
     (void)hipEventRecord(e, st);
     h->trace->push_back(e);
   };
+#else
+  auto mark = [](hipStream_t) {};
+#endif
+  const bool set_reused = pipelined && h->since_drain >= h->n_sets;
+  if (set_reused) GV_HIP(hipStreamWaitEvent(sA, h->ev_fin[p], 0));   // set p (bitmaps, rectangles) is free again
+  if (h->cloud_wait) { GV_HIP(hipStreamWaitEvent(sA, CS.ready, 0)); h->cloud_wait = false; }
+  if (h->det_wait) { GV_HIP(hipStreamWaitEvent(sA, D.ready, 0)); h->det_wait = false; }
+  if (stage_events) GV_HIP(hipEventRecord(h->ev[0], sA));
 
-  const uint32_t fl = h->frame_flags;
-  const bool do_bin = fl & GV_FRAME_BIN, do_ray = fl & GV_FRAME_RAYMARCH, do_bbox = fl & GV_FRAME_BBOX_TEST;
-  const bool vision = fl & GV_FRAME_VISION_ORIENT;
-  if (do_ray && !do_bin) return GV_ERR_BAD_ARG;
-  if (do_bin && !h->has_bl) return GV_ERR_TF;
-  if (do_bbox && !h->has_cl) return GV_ERR_TF;
-  if (vision && !h->has_bc) return GV_ERR_TF;
-  if (h->counts_dirty) { int rc = clear_counts(h); if (rc) return rc; }
-  const int p = (int)(h->frame_no % (unsigned)h->n_sets);
-  hipStream_t sA = h->stream, sB = (h->sector_streams > 1 && (h->frame_no & 1)) ? h->stream2b : h->stream2;
-  uint32_t *hitN = h->x_hitN[p], *clipN = h->x_clipN[p], *hitT = h->x_hitT[p], *clipT = h->x_clipT[p];
+  // --- detections -> rectangles
   Rect *rects = h->x_rects[p];
-  if (h->since_drain >= h->n_sets) GV_HIP(hipStreamWaitEvent(sA, h->ev_fin[p], 0));   // set p is free again
+  mark(sA);
+  const int32_t n_rects = enqueue_rects(h, D, rects, sA);
+  mark(sA);
+  if (stage_events) GV_HIP(hipEventRecord(h->ev[kStageDetections + 1], sA));
 
-  // the detection -> rectangle kernels are tiny and only the grid pass reads their output: they run on
-  // the grid-pass stream right before it (same-stream order, no event), off the stream the sector
-  // kernel waits for
-  const bool rects_on_c = h->three_streams && h->rects_on_c;
-  hipStream_t sR = rects_on_c ? h->stream3 : sA;
-  int32_t n_rects = (vision && h->nb > 0) ? h->nb : ((!vision || h->nb <= 0) && h->n_poses > 0 ? h->n_poses : 0);
-  auto launch_rects = [&]() {
-    if (vision && h->nb > 0) {
-      launch_vision(h->d_orient, h->d_conf, h->d_dims, h->d_bboxes, h->nb, h->cam, h->d_vout, h->d_poses, sR);
-      launch_rects_from_poses(h->d_poses, h->nb, h->g, true, h->x_bc, rects, sR);
-    } else if (h->n_poses > 0) {
-      mark(sR);
-      launch_rects_from_poses(h->d_poses, h->n_poses, h->g, false, h->x_bc, rects, sR);
-      mark(sR);
-    }
-  };
-  if (!rects_on_c) launch_rects();
-  if (do_bin || do_bbox) {
-    PointsArgs a{};
+  // --- points: partition by tile (+ ray ends, bbox test)
+  const uint32_t chunk = bin_chunk_for(h->n);
+  const uint32_t n_wg = (uint32_t)((h->n + chunk - 1) / chunk);
+  mark(sA);
+  if (do_bin) {
+    BinArgs a{};
     a.x = h->cx; a.y = h->cy; a.z = h->cz;
     a.n = (uint32_t)h->n;
     a.g = h->g;
@@ -570,66 +598,87 @@ int enqueue_frame_pipelined(gv_context *h)
     a.m_cam = h->m_cam;
     a.cam = h->camk;
     a.org = h->org;
-    a.bboxes = h->d_bboxes;
-    a.nb = h->nb;
-    a.bbox_f = h->d_bbox_f;
-    a.tile_mask = h->d_tile_mask;
-    a.tiles_x = h->tiles_x; a.tiles_y = h->tiles_y; a.mask_words = h->mask_words;
-    a.hits = h->hits;
-    a.hit8 = h->hit8;
-    a.clip_end = h->clip_end;
-    a.cell_idx = nullptr;
+    a.bt = bbox_test_of(h, D);
     a.bbox_id = h->bbox_id;
-    a.do_bin = do_bin; a.do_ray = do_ray; a.do_bbox = do_bbox;
-    a.counts = h->force_counts;
-    mark(sA);
-    if (h->split_points && do_bin && do_bbox) {
-      // binning (what the bitmaps wait for) on stream A, the bbox test on its own stream: two lighter
-      // kernels (46 and 30 VGPRs, no SGPR spills) instead of one fused pass over the cloud
-      PointsArgs ab = a, ax = a;
-      ab.do_bbox = false;
-      ax.do_bin = false; ax.do_ray = false; ax.counts = false;
-      launch_points(ab, sA);
-      launch_points(ax, h->stream4);
-    } else {
-      launch_points(a, sA);
-    }
-    mark(sA);
+    a.cell_idx = keep_cell ? h->cell_idx : nullptr;
+    a.do_ray = do_ray;
+    a.do_bbox = do_bbox;
+    a.chunk = chunk;
+    a.n_wg = n_wg;
+    a.tiles_x = h->tiles_x; a.tiles_y = h->tiles_y; a.n_tiles = h->n_tiles;
+    a.keys = h->bin_keys;
+    a.tab = h->bin_tab;
+    a.tile_total = h->bin_total[h->bin_parity];
+    launch_bin_partition(a, sA);
+  } else if (do_bbox) {
+    PointsArgs a{};
+    a.x = h->cx; a.y = h->cy; a.z = h->cz;
+    a.n = (uint32_t)h->n;
+    a.g = h->g;
+    a.m_cam = h->m_cam;
+    a.cam = h->camk;
+    a.bt = bbox_test_of(h, D);
+    a.bbox_id = h->bbox_id;
+    a.do_bbox = true;
+    launch_points(a, sA);
   }
+  mark(sA);
+  GV_HIP(hipEventRecord(CS.used, sA));   // the other cloud / detection set may be refilled from here on
+  GV_HIP(hipEventRecord(D.used, sA));
+  if (stage_events) GV_HIP(hipEventRecord(h->ev[kStagePoints + 1], sA));
+
+  // --- tile histogram: hits[] + the four end bitmaps of set p
+  mark(sA);
   if (do_bin) {
-    BitmapArgs b{};
-    b.nx = h->g.nx; b.ny = h->g.ny;
-    b.hits = h->hits; b.clip_end = h->clip_end;
-    b.hit8 = h->force_counts ? nullptr : h->hit8;
-    b.hitN = hitN; b.clipN = clipN; b.hitT = hitT; b.clipT = clipT;
-    b.nxw = h->nxw; b.nyw = h->nyw; b.nx_pad = h->nx_pad; b.ny_pad = h->ny_pad;
-    b.zero_hits = true;
-    mark(sA);
-    launch_build_bitmaps(b, sA);
-    mark(sA);
+    BinTileArgs t{};
+    t.nx = h->g.nx; t.ny = h->g.ny;
+    t.tiles_x = h->tiles_x; t.tiles_y = h->tiles_y; t.n_tiles = h->n_tiles;
+    t.n_wg = n_wg;
+    t.chunk = chunk;
+    t.keys = h->bin_keys;
+    t.tab = h->bin_tab;
+    t.tile_total = h->bin_total[h->bin_parity];
+    t.tile_total_next = h->bin_total[h->bin_parity ^ 1];
+    t.done = h->bin_done;
+    t.scratch = h->bin_scratch;
+    t.split_keys = kBinSplitKeys;
+    t.max_slots = (uint32_t)h->bin_slots;
+    t.hits = h->hits;
+    t.hitN = h->x_hitN[p]; t.clipN = h->x_clipN[p]; t.hitT = h->x_hitT[p]; t.clipT = h->x_clipT[p];
+    t.nxw = h->nxw; t.nyw = h->nyw; t.nx_pad = h->nx_pad; t.ny_pad = h->ny_pad;
+    launch_bin_tiles(t, (uint32_t)(h->n / kBinSplitKeys), sA);
+    h->bin_parity ^= 1;
   }
-  GV_HIP(hipEventRecord(h->ev_build[p], sA));
-  GV_HIP(hipStreamWaitEvent(sB, h->ev_build[p], 0));
-  // the grid pass runs on its own stream: HBM-bound, it overlaps the issue-bound sector kernel of the
-  // next frame; the miss grids alternate with the frame parity like the bitmaps do
-  hipStream_t sC = h->three_streams ? h->stream3 : sB;   // (two-stream mode runs with one sector stream)
-  uint8_t *missN = h->x_miss[p], *missT = h->x_missT[p];
-  if ((h->three_streams || h->sector_streams > 1) && h->since_drain >= h->n_sets) GV_HIP(hipStreamWaitEvent(sB, h->ev_fin[p], 0));   // miss set p cleared by its last reader
+  mark(sA);
+  if (stage_events) GV_HIP(hipEventRecord(h->ev[kStageRayCompact + 1], sA));
+  if (pipelined) {
+    GV_HIP(hipEventRecord(h->ev_build[p], sA));
+    GV_HIP(hipStreamWaitEvent(sB, h->ev_build[p], 0));
+    if (set_reused) GV_HIP(hipStreamWaitEvent(sB, h->ev_fin[p], 0));   // miss set p cleared by its last reader
+  }
+
+  // --- free-space ray stage
+  if (h->miss_dirty[p]) {   // a kept frame (GV_FRAME_KEEP_COUNTS) left its miss grids in this set
+    GV_HIP(hipMemsetAsync(h->x_miss[p], 0, (size_t)h->g.G, sB));
+    GV_HIP(hipMemsetAsync(h->x_missT[p], 0, (size_t)h->g.G, sB));
+    h->miss_dirty[p] = false;
+  }
+  mark(sB);
   if (do_ray && h->org.valid) {
     SectorArgs sa{};
-    int rc = fill_sector_args(h, sa);
-    if (rc) return rc;
-    sa.hitN = hitN; sa.clipN = clipN; sa.hitT = hitT; sa.clipT = clipT;
-    sa.missN = missN; sa.missT = missT;
-    mark(sB);
+    if ((rc = fill_sector_args(h, sa, p))) return rc;
     launch_ray_sectors(sa, sB);
-    mark(sB);
   }
-  if (rects_on_c) launch_rects();   // before the wait: they do not depend on the sector kernel
-  if (h->three_streams) {
+  mark(sB);
+  if (stage_events) GV_HIP(hipEventRecord(h->ev[kStageRayMarch + 1], sB));
+  h->last_set = p;
+  if (sharded) return sharded_tail(h, n_rects);
+  if (pipelined) {
     GV_HIP(hipEventRecord(h->ev_sec[p], sB));
     GV_HIP(hipStreamWaitEvent(sC, h->ev_sec[p], 0));
   }
+
+  // --- grid pass
   FinalizeTileArgs t{};
   t.g = h->g;
   t.log_odds = h->log_odds;
@@ -637,27 +686,100 @@ int enqueue_frame_pipelined(gv_context *h)
   t.occ_i8 = h->occ_i8;
   t.rects = rects;
   t.n_rects = n_rects;
-  t.hitN = hitN;
+  t.hitN = h->x_hitN[p];
   t.nxw = h->nxw;
   t.ny_pad = h->ny_pad;
-  t.missN = missN;
-  t.missT = missT;
+  t.missN = h->x_miss[p];
+  t.missT = h->x_missT[p];
   t.counts = do_bin;
-  t.zero = do_bin;
+  t.zero = do_bin && !keep_counts;
   t.use_missT = true;
   t.y_begin = 0;
   t.y_end = h->g.ny;
   mark(sC);
   launch_finalize_tiles(t, sC);
   mark(sC);
-  GV_HIP(hipEventRecord(h->ev_fin[p], sC));
+  if (do_bin && keep_counts) h->miss_dirty[p] = true;
+  if (stage_events) GV_HIP(hipEventRecord(h->ev[kStageFinalize + 1], sC));
+  if (pipelined) GV_HIP(hipEventRecord(h->ev_fin[p], sC));
   GV_HIP(hipGetLastError());
-  h->frame_no++;
-  if (h->since_drain < h->n_sets) h->since_drain++;
-  h->pipe_busy = true;
-  h->counts_dirty = false;
-  h->have_counts = false;
-  h->have_cell_idx = false;
+  if (pipelined) {
+    h->frame_no++;
+    if (h->since_drain < h->n_sets) h->since_drain++;
+    h->pipe_busy = true;
+  }
+  h->have_hits = do_bin;
+  h->have_miss = do_bin && keep_counts;
+  h->have_cell_idx = do_bin && keep_cell;
+  h->have_bbox_id = do_bbox;
+  return GV_OK;
+}
+
+// Generic frame: any grid shape (nx % 4 != 0, more than 8000 cells per side, GV_RAY_IMPL=simple).
+// One stream; atomics-based count grids; literal per-ray march.
+int enqueue_frame_generic(gv_context *h, bool stage_events)
+{
+  DetSet &D = h->det[h->det_cur];
+  const uint32_t fl = D.flags;
+  const bool do_bin = fl & GV_FRAME_BIN, do_ray = fl & GV_FRAME_RAYMARCH, do_bbox = fl & GV_FRAME_BBOX_TEST;
+  const bool keep_cell = fl & GV_FRAME_KEEP_CELL_IDX, keep_counts = fl & GV_FRAME_KEEP_COUNTS;
+  int rc = check_frame_flags(h, fl);
+  if (rc) return rc;
+  if (h->counts_dirty && (rc = clear_counts(h))) return rc;
+  hipStream_t s = h->stream;
+  if (stage_events) GV_HIP(hipEventRecord(h->ev[0], s));
+  const int32_t n_rects = enqueue_rects(h, D, h->x_rects[0], s);
+  if (stage_events) GV_HIP(hipEventRecord(h->ev[kStageDetections + 1], s));
+  if (do_bin || do_bbox) {
+    PointsArgs a{};
+    a.x = h->cx; a.y = h->cy; a.z = h->cz;
+    a.n = (uint32_t)h->n;
+    a.g = h->g;
+    a.m_base = h->m_base;
+    a.m_cam = h->m_cam;
+    a.cam = h->camk;
+    a.org = h->org;
+    a.bt = bbox_test_of(h, D);
+    a.hits = h->hits;
+    a.clip_end = h->clip_end;
+    a.cell_idx = keep_cell ? h->cell_idx : nullptr;
+    a.bbox_id = h->bbox_id;
+    a.do_bin = do_bin; a.do_ray = do_ray; a.do_bbox = do_bbox;
+    launch_points(a, s);
+  }
+  if (stage_events) GV_HIP(hipEventRecord(h->ev[kStagePoints + 1], s));
+  if (do_ray && h->org.valid) {
+    GV_HIP(hipMemsetAsync(h->ray_count, 0, sizeof(uint32_t), s));
+    GV_HIP(hipMemsetAsync(h->x_stats[0], 0, 2 * sizeof(unsigned long long), s));
+    h->stat_slots = 1;
+    launch_ray_compact(h->hits, h->clip_end, h->g, h->ray_list, h->ray_count, s);
+    if (stage_events) GV_HIP(hipEventRecord(h->ev[kStageRayCompact + 1], s));
+    launch_ray_march(h->ray_list, h->ray_count, h->g, h->org, h->x_miss[0], h->x_stats[0], s);
+    if (stage_events) GV_HIP(hipEventRecord(h->ev[kStageRayMarch + 1], s));
+  } else if (stage_events) {
+    GV_HIP(hipEventRecord(h->ev[kStageRayCompact + 1], s));
+    GV_HIP(hipEventRecord(h->ev[kStageRayMarch + 1], s));
+  }
+  FinalizeArgs f{};
+  f.g = h->g;
+  f.log_odds = h->log_odds;
+  f.occupancy = h->occupancy;
+  f.occ_i8 = h->occ_i8;
+  f.rects = h->x_rects[0];
+  f.n_rects = n_rects;
+  f.hits = do_bin ? h->hits : nullptr;
+  f.miss = h->x_miss[0];
+  f.clip_end = h->clip_end;
+  f.zero_counts = do_bin && !keep_counts;
+  f.cell_begin = 0;
+  f.cell_end = h->g.G;
+  launch_finalize(f, s);
+  if (stage_events) GV_HIP(hipEventRecord(h->ev[kStageFinalize + 1], s));
+  GV_HIP(hipGetLastError());
+  h->last_set = 0;
+  h->counts_dirty = do_bin && keep_counts;
+  h->have_hits = h->have_miss = do_bin && keep_counts;
+  h->have_cell_idx = do_bin && keep_cell;
   h->have_bbox_id = do_bbox;
   return GV_OK;
 }
@@ -687,35 +809,32 @@ int sharded_tail(gv_context *h, int32_t n_rects)
 {
   const int nx = h->g.nx, ny = h->g.ny;
   const size_t G = (size_t)h->g.G;
-  launch_merge_miss(h->miss, h->missT, nx, ny, h->stream);   // miss = N | T^T, missT cleared
+  uint8_t *miss = h->x_miss[0], *missT = h->x_missT[0];
+  launch_merge_miss(miss, missT, nx, ny, h->stream);   // miss = N | T^T, missT cleared
   GV_HIP(hipGetLastError());
   int32_t y0, y1;
   band_rows(h, h->rank, y0, y1);
-  const bool counts = h->frame_counts;   // int32 sums only when the caller keeps the counts; else byte flags, max
   if (ny % h->world == 0) {
     const size_t cnt = G / (size_t)h->world;
-    if (counts) GV_NCCL(ncclReduceScatter(h->hits, h->hits + (size_t)h->rank * cnt, cnt, ncclInt32, ncclSum, h->comm, h->stream));
-    else GV_NCCL(ncclReduceScatter(h->hit8, h->hit8 + (size_t)h->rank * cnt, cnt, ncclUint8, ncclMax, h->comm, h->stream));
-    GV_NCCL(ncclReduceScatter(h->miss, h->miss + (size_t)h->rank * cnt, cnt, ncclUint8, ncclMax, h->comm, h->stream));
+    GV_NCCL(ncclReduceScatter(h->hits, h->hits + (size_t)h->rank * cnt, cnt, ncclInt32, ncclSum, h->comm, h->stream));
+    GV_NCCL(ncclReduceScatter(miss, miss + (size_t)h->rank * cnt, cnt, ncclUint8, ncclMax, h->comm, h->stream));
   } else {   // bands are not equal sized: reduce everything everywhere
-    if (counts) GV_NCCL(ncclAllReduce(h->hits, h->hits, G, ncclInt32, ncclSum, h->comm, h->stream));
-    else GV_NCCL(ncclAllReduce(h->hit8, h->hit8, G, ncclUint8, ncclMax, h->comm, h->stream));
-    GV_NCCL(ncclAllReduce(h->miss, h->miss, G, ncclUint8, ncclMax, h->comm, h->stream));
+    GV_NCCL(ncclAllReduce(h->hits, h->hits, G, ncclInt32, ncclSum, h->comm, h->stream));
+    GV_NCCL(ncclAllReduce(miss, miss, G, ncclUint8, ncclMax, h->comm, h->stream));
   }
-  if (counts) launch_band_hit_bitmap(h->hits, nx, h->ny_pad, y0, y1, h->hitN, h->stream);
-  else launch_band_hit_bitmap8(h->hit8, nx, h->ny_pad, y0, y1, h->hitN, h->stream);
+  launch_band_hit_bitmap(h->hits, nx, h->ny_pad, y0, y1, h->x_hitN[0], h->stream);
   FinalizeTileArgs t{};
   t.g = h->g;
   t.log_odds = h->log_odds;
   t.occupancy = h->occupancy;
   t.occ_i8 = h->occ_i8;
-  t.rects = h->d_rects;
+  t.rects = h->x_rects[0];
   t.n_rects = n_rects;
-  t.hitN = h->hitN;
+  t.hitN = h->x_hitN[0];
   t.nxw = h->nxw;
   t.ny_pad = h->ny_pad;
-  t.missN = h->miss;
-  t.missT = h->missT;
+  t.missN = miss;
+  t.missT = missT;
   t.counts = true;
   t.zero = false;
   t.use_missT = false;
@@ -723,62 +842,29 @@ int sharded_tail(gv_context *h, int32_t n_rects)
   t.y_end = y1;
   launch_finalize_tiles(t, h->stream);
   GV_HIP(hipGetLastError());
-  if (counts) GV_HIP(hipMemsetAsync(h->hits, 0, G * sizeof(int32_t), h->stream));
-  else GV_HIP(hipMemsetAsync(h->hit8, 0, G, h->stream));
-  GV_HIP(hipMemsetAsync(h->miss, 0, G, h->stream));
+  GV_HIP(hipMemsetAsync(miss, 0, G, h->stream));
   // packed bands to everyone: band r sits at data[G - e_r, G - b_r) (toOccupancyGrid order)
-  GV_NCCL(ncclGroupStart());
-  for (int r = 0; r < h->world; ++r) {
+  ncclResult_t gr = ncclGroupStart(), first_err = ncclSuccess;
+  if (gr != ncclSuccess) first_err = gr;
+  for (int r = 0; r < h->world && first_err == ncclSuccess; ++r) {
     int32_t r0, r1;
     band_rows(h, r, r0, r1);
     const size_t b = (size_t)r0 * nx, e = (size_t)r1 * nx;
-    if (e > b) GV_NCCL(ncclBroadcast(h->occ_i8 + (G - e), h->occ_i8 + (G - e), e - b, ncclInt8, r, h->comm, h->stream));
+    if (e > b) {
+      const ncclResult_t br = ncclBroadcast(h->occ_i8 + (G - e), h->occ_i8 + (G - e), e - b, ncclInt8, r, h->comm, h->stream);
+      if (br != ncclSuccess) first_err = br;
+    }
   }
-  GV_NCCL(ncclGroupEnd());
-  h->counts_dirty = false;
-  h->have_counts = false;
+  gr = ncclGroupEnd();   // always closed, also on the error path
+  if (first_err == ncclSuccess && gr != ncclSuccess) first_err = gr;
+  if (first_err != ncclSuccess) {
+    h->err = std::string("sharded band exchange -> ") + ncclGetErrorString(first_err);
+    return GV_ERR_RCCL;
+  }
+  h->have_hits = false;     // hits[] holds this rank's band of the sum only
+  h->have_miss = false;
   h->have_cell_idx = false;
-  h->have_bbox_id = (h->frame_flags & GV_FRAME_BBOX_TEST) != 0;
-  return GV_OK;
-}
-
-int upload_bboxes(gv_context *h, const gv_bbox *b, int32_t nb)
-{
-  int rc = ensure_det(h, nb);
-  if (rc) return rc;
-  // float thresholds + tile candidate masks for the first-match test (extractCloudPerBBox)
-  h->tiles_x = (h->cam.orig_w + 15) / 16;
-  h->tiles_y = (h->cam.orig_h + 15) / 16;
-  if (h->tiles_x < 1) h->tiles_x = 1;
-  if (h->tiles_y < 1) h->tiles_y = 1;
-  h->mask_words = std::max(1, (nb + 63) / 64);
-  const size_t nmask = (size_t)h->tiles_x * h->tiles_y * h->mask_words;
-  if ((rc = grow(h, h->d_tile_mask, h->tile_mask_cap, nmask))) return rc;
-  std::vector<float4> bf((size_t)std::max(nb, 1));
-  std::vector<unsigned long long> masks(nmask, 0ull);
-  for (int32_t i = 0; i < nb; ++i) {
-    float4 f;
-    f.x = host::ceil_to_float(b[i].x_min);
-    f.y = host::ceil_to_float(b[i].y_min);
-    f.z = host::floor_to_float(b[i].x_max);
-    f.w = host::floor_to_float(b[i].y_max);
-    bf[i] = f;
-    if (!(f.x <= f.z && f.y <= f.w)) continue;   // empty or NaN box never matches
-    // tiles whose pixel range [16t, 16t+16) can contain a u in [f.x, f.z]
-    int tx0 = (int)std::floor(std::max(f.x, 0.0f) / 16.0f), tx1 = (int)std::floor(std::min(f.z, 16.0f * h->tiles_x - 1.0f) / 16.0f);
-    int ty0 = (int)std::floor(std::max(f.y, 0.0f) / 16.0f), ty1 = (int)std::floor(std::min(f.w, 16.0f * h->tiles_y - 1.0f) / 16.0f);
-    tx0 = std::max(tx0, 0); ty0 = std::max(ty0, 0);
-    tx1 = std::min(tx1, h->tiles_x - 1); ty1 = std::min(ty1, h->tiles_y - 1);
-    for (int ty = ty0; ty <= ty1; ++ty)
-      for (int tx = tx0; tx <= tx1; ++tx)
-        masks[((size_t)ty * h->tiles_x + tx) * h->mask_words + (i >> 6)] |= 1ull << (i & 63);
-  }
-  if (nb > 0) {
-    GV_HIP(hipMemcpyAsync(h->d_bboxes, b, (size_t)nb * sizeof(gv_bbox), hipMemcpyHostToDevice, h->stream));
-    GV_HIP(hipMemcpyAsync(h->d_bbox_f, bf.data(), (size_t)nb * sizeof(float4), hipMemcpyHostToDevice, h->stream));
-  }
-  GV_HIP(hipMemcpyAsync(h->d_tile_mask, masks.data(), nmask * sizeof(unsigned long long), hipMemcpyHostToDevice, h->stream));
-  GV_HIP(hipStreamSynchronize(h->stream));   // bf / masks are stack-owned
+  h->have_bbox_id = (h->det[h->det_cur].flags & GV_FRAME_BBOX_TEST) != 0;
   return GV_OK;
 }
 
@@ -786,7 +872,7 @@ int upload_bboxes(gv_context *h, const gv_bbox *b, int32_t nb)
 
 extern "C" {
 
-int gv_abi_version(void) { return 1; }
+int gv_abi_version(void) { return 2; }
 
 int gv_create(gv_handle *out, uint8_t grid_x, uint8_t grid_y, double resolution, const gv_cam_params *cam,
               int device_id)
@@ -824,6 +910,8 @@ int gv_create(gv_handle *out, uint8_t grid_x, uint8_t grid_y, double resolution,
   for (int i = 0; i < 9; ++i) h->camk.k[i] = h->K[i];
   h->camk.W = cam->orig_w;
   h->camk.H = cam->orig_h;
+  h->bt_tiles_x = std::max(1, (cam->orig_w + 15) / 16);
+  h->bt_tiles_y = std::max(1, (cam->orig_h + 15) / 16);
 
   auto fail = [&](int code) { gv_destroy(h); return code; };
 #define GV_C(call)                                           \
@@ -831,81 +919,40 @@ int gv_create(gv_handle *out, uint8_t grid_x, uint8_t grid_y, double resolution,
     if ((call) != hipSuccess) return fail(GV_ERR_HIP);       \
   } while (0)
   GV_C(hipSetDevice(h->device));
-  {
-    // GV_PRIO (experiment): 1 = stream A (points/bitmaps) high priority, 2 = stream B high priority
-    int lo = 0, hi = 0;
-    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-    const char *pe = std::getenv("GV_PRIO");
-    const int mode = pe ? std::atoi(pe) : 0;
-    GV_C(hipStreamCreateWithPriority(&h->stream, hipStreamNonBlocking, mode == 1 ? hi : (mode == 2 ? lo : 0)));
-    GV_C(hipStreamCreateWithPriority(&h->stream2, hipStreamNonBlocking, mode == 2 ? hi : (mode == 1 ? lo : 0)));
-    GV_C(hipStreamCreateWithPriority(&h->stream3, hipStreamNonBlocking, mode == 3 ? hi : 0));
-    GV_C(hipStreamCreateWithPriority(&h->stream4, hipStreamNonBlocking, 0));
-    GV_C(hipStreamCreateWithPriority(&h->stream2b, hipStreamNonBlocking, mode == 2 ? hi : (mode == 1 ? lo : 0)));
-  }
+  GV_C(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+  GV_C(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
+  GV_C(hipStreamCreateWithFlags(&h->stream3, hipStreamNonBlocking));
+  GV_C(hipStreamCreateWithFlags(&h->stream_copy, hipStreamNonBlocking));
   for (int i = 0; i < gv_context::kSets; ++i) {
     GV_C(hipEventCreateWithFlags(&h->ev_build[i], hipEventDisableTiming));
     GV_C(hipEventCreateWithFlags(&h->ev_fin[i], hipEventDisableTiming));
     GV_C(hipEventCreateWithFlags(&h->ev_sec[i], hipEventDisableTiming));
+  }
+  for (auto &e : h->ev_join) GV_C(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  for (auto &c : h->cloud) {
+    GV_C(hipEventCreateWithFlags(&c.ready, hipEventDisableTiming));
+    GV_C(hipEventCreateWithFlags(&c.used, hipEventDisableTiming));
+  }
+  for (auto &d : h->det) {
+    GV_C(hipEventCreateWithFlags(&d.ready, hipEventDisableTiming));
+    GV_C(hipEventCreateWithFlags(&d.used, hipEventDisableTiming));
   }
   const size_t G = (size_t)g.G;
   GV_C(hipMalloc(reinterpret_cast<void **>(&h->log_odds), G * sizeof(float)));
   GV_C(hipMalloc(reinterpret_cast<void **>(&h->occupancy), G * sizeof(float)));
   GV_C(hipMalloc(reinterpret_cast<void **>(&h->occ_i8), G));
   GV_C(hipMalloc(reinterpret_cast<void **>(&h->hits), G * sizeof(int32_t)));
-  GV_C(hipMalloc(reinterpret_cast<void **>(&h->miss), G + 16));
-  GV_C(hipMalloc(reinterpret_cast<void **>(&h->clip_end), G + 16));
-  GV_C(hipMalloc(reinterpret_cast<void **>(&h->hit8), G + 16));
-  GV_C(hipMalloc(reinterpret_cast<void **>(&h->ray_list), G * sizeof(uint32_t)));
+  GV_C(hipMemsetAsync(h->hits, 0, G * sizeof(int32_t), h->stream));
   GV_C(hipMalloc(reinterpret_cast<void **>(&h->ray_count), 4 * sizeof(uint32_t)));
-  GV_C(hipMalloc(reinterpret_cast<void **>(&h->ray_stats), kMaxStatSlots * 2 * sizeof(unsigned long long)));
+  GV_C(hipMemsetAsync(h->ray_count, 0, 4 * sizeof(uint32_t), h->stream));
   GV_C(hipMalloc(reinterpret_cast<void **>(&h->scratch_i32), G * sizeof(int32_t)));
-  GV_C(hipMalloc(reinterpret_cast<void **>(&h->missT), G + 16));
-  h->x_miss[0] = h->miss;
-  h->x_missT[0] = h->missT;
-  for (int k = 1; k < gv_context::kSets; ++k) {
-    GV_C(hipMalloc(reinterpret_cast<void **>(&h->x_miss[k]), G + 16));
-    GV_C(hipMalloc(reinterpret_cast<void **>(&h->x_missT[k]), G + 16));
-    GV_C(hipMemsetAsync(h->x_miss[k], 0, G + 16, h->stream));
-    GV_C(hipMemsetAsync(h->x_missT[k], 0, G + 16, h->stream));
-  }
-  h->nxw = 2 * ((g.nx + 63) / 64);
-  h->nyw = 2 * ((g.ny + 63) / 64);
-  h->nx_pad = 64 * ((g.nx + 63) / 64);
-  h->ny_pad = 64 * ((g.ny + 63) / 64);
-  {
-    const size_t nN = (size_t)h->ny_pad * h->nxw + 4, nT = (size_t)h->nx_pad * h->nyw + 4;
-    GV_C(hipMalloc(reinterpret_cast<void **>(&h->hitN), nN * sizeof(uint32_t)));
-    GV_C(hipMalloc(reinterpret_cast<void **>(&h->clipN), nN * sizeof(uint32_t)));
-    GV_C(hipMalloc(reinterpret_cast<void **>(&h->hitT), nT * sizeof(uint32_t)));
-    GV_C(hipMalloc(reinterpret_cast<void **>(&h->clipT), nT * sizeof(uint32_t)));
-    GV_C(hipMemsetAsync(h->hitN, 0, nN * sizeof(uint32_t), h->stream));
-    GV_C(hipMemsetAsync(h->clipN, 0, nN * sizeof(uint32_t), h->stream));
-    GV_C(hipMemsetAsync(h->hitT, 0, nT * sizeof(uint32_t), h->stream));
-    GV_C(hipMemsetAsync(h->clipT, 0, nT * sizeof(uint32_t), h->stream));
-    h->x_hitN[0] = h->hitN; h->x_clipN[0] = h->clipN; h->x_hitT[0] = h->hitT; h->x_clipT[0] = h->clipT;
-    for (int k = 1; k < gv_context::kSets; ++k) {
-      GV_C(hipMalloc(reinterpret_cast<void **>(&h->x_hitN[k]), nN * sizeof(uint32_t)));
-      GV_C(hipMalloc(reinterpret_cast<void **>(&h->x_clipN[k]), nN * sizeof(uint32_t)));
-      GV_C(hipMalloc(reinterpret_cast<void **>(&h->x_hitT[k]), nT * sizeof(uint32_t)));
-      GV_C(hipMalloc(reinterpret_cast<void **>(&h->x_clipT[k]), nT * sizeof(uint32_t)));
-      GV_C(hipMemsetAsync(h->x_hitN[k], 0, nN * sizeof(uint32_t), h->stream));
-      GV_C(hipMemsetAsync(h->x_clipN[k], 0, nN * sizeof(uint32_t), h->stream));
-      GV_C(hipMemsetAsync(h->x_hitT[k], 0, nT * sizeof(uint32_t), h->stream));
-      GV_C(hipMemsetAsync(h->x_clipT[k], 0, nT * sizeof(uint32_t), h->stream));
-    }
-  }
+  h->scratch_cap = G;
   // packed (a,b) fields hold 13 bits each; vector stores need nx % 4 == 0
   h->tile_path = (g.nx % 4 == 0) && g.nx <= 8000 && g.ny <= 8000;
   {
     const char *impl = std::getenv("GV_RAY_IMPL");
     h->force_simple = impl && std::strcmp(impl, "simple") == 0;
-    if (const char *e = std::getenv("GV_PIPELINE")) { h->no_pipeline = std::atoi(e) == 0; h->three_streams = std::atoi(e) != 2; }
-    if (const char *e = std::getenv("GV_HIT_COUNTS")) h->force_counts = std::atoi(e) != 0;
-    if (const char *e = std::getenv("GV_RECTS_ON_C")) h->rects_on_c = std::atoi(e) != 0;
-    if (const char *e = std::getenv("GV_SPLIT_POINTS")) h->split_points = std::atoi(e) != 0;
-    if (const char *e = std::getenv("GV_SECTOR_STREAMS")) h->sector_streams = std::max(1, std::min(2, std::atoi(e)));
-    if (!h->three_streams) h->sector_streams = 1;
+    if (const char *e = std::getenv("GV_PIPELINE")) h->no_pipeline = std::atoi(e) == 0;
     if (const char *e = std::getenv("GV_PIPE_SETS")) h->n_sets = std::min(gv_context::kSets, std::max(2, std::atoi(e)));
     if (const char *e = std::getenv("GV_LOG2S")) h->env_log2s = std::atoi(e);
     if (const char *e = std::getenv("GV_LOG2S_OCT")) {
@@ -918,27 +965,66 @@ int gv_create(gv_handle *out, uint8_t grid_x, uint8_t grid_y, double resolution,
     }
     if (const char *e = std::getenv("GV_SECTOR_REORDER")) h->env_reorder = std::atoi(e) != 0;
     if (const char *e = std::getenv("GV_CAP")) h->env_cap = std::atoi(e);
-    if (const char *e = std::getenv("GV_ABLATE")) h->env_ablate = std::atoi(e);
     if (const char *e = std::getenv("GV_FLAT_K")) h->env_flat_k = std::max(0, std::atoi(e));
+    if (const char *e = std::getenv("GV_LOG2M")) h->env_log2m = std::min(9, std::max(4, std::atoi(e)));
+#ifdef GV_DIAG
+    if (const char *e = std::getenv("GV_ABLATE")) h->env_ablate = std::atoi(e);
     if (const char *e = std::getenv("GV_SECTOR_DBG")) {
       if (std::atoi(e) > 0) {
         GV_C(hipMalloc(reinterpret_cast<void **>(&h->d_dbg), kMaxStatSlots * 16 * sizeof(unsigned long long)));
         GV_C(hipMemsetAsync(h->d_dbg, 0, kMaxStatSlots * 16 * sizeof(unsigned long long), h->stream));
       }
     }
-    if (const char *e = std::getenv("GV_LOG2M")) h->env_log2m = std::min(9, std::max(4, std::atoi(e)));
+#endif
   }
-  for (auto &e : h->ev) GV_C(hipEventCreate(&e));
-  GV_C(hipMemsetAsync(h->ray_count, 0, 4 * sizeof(uint32_t), h->stream));
-  GV_C(hipMemsetAsync(h->ray_stats, 0, kMaxStatSlots * 2 * sizeof(unsigned long long), h->stream));
-  h->x_stats[0] = h->ray_stats;
-  for (int k = 1; k < gv_context::kSets; ++k) {
+  const bool sectors = h->tile_path && !h->force_simple;
+  const int nsets_alloc = sectors ? gv_context::kSets : 1;
+  for (int k = 0; k < nsets_alloc; ++k) {
+    GV_C(hipMalloc(reinterpret_cast<void **>(&h->x_miss[k]), G + 16));
+    GV_C(hipMemsetAsync(h->x_miss[k], 0, G + 16, h->stream));
     GV_C(hipMalloc(reinterpret_cast<void **>(&h->x_stats[k]), kMaxStatSlots * 2 * sizeof(unsigned long long)));
     GV_C(hipMemsetAsync(h->x_stats[k], 0, kMaxStatSlots * 2 * sizeof(unsigned long long), h->stream));
   }
+  // end bitmaps: padded to whole binning tiles, so that every word belongs to exactly one tile
+  h->nx_pad = kBinTile * ((g.nx + kBinTile - 1) / kBinTile);
+  h->ny_pad = kBinTile * ((g.ny + kBinTile - 1) / kBinTile);
+  h->nxw = h->nx_pad / 32;
+  h->nyw = h->ny_pad / 32;
+  h->tiles_x = h->nx_pad / kBinTile;
+  h->tiles_y = h->ny_pad / kBinTile;
+  h->n_tiles = h->tiles_x * h->tiles_y;
+  if (sectors) {
+    const size_t nN = (size_t)h->ny_pad * h->nxw + 4, nT = (size_t)h->nx_pad * h->nyw + 4;
+    for (int k = 0; k < gv_context::kSets; ++k) {
+      GV_C(hipMalloc(reinterpret_cast<void **>(&h->x_missT[k]), G + 16));
+      GV_C(hipMemsetAsync(h->x_missT[k], 0, G + 16, h->stream));
+      GV_C(hipMalloc(reinterpret_cast<void **>(&h->x_hitN[k]), nN * sizeof(uint32_t)));
+      GV_C(hipMalloc(reinterpret_cast<void **>(&h->x_clipN[k]), nN * sizeof(uint32_t)));
+      GV_C(hipMalloc(reinterpret_cast<void **>(&h->x_hitT[k]), nT * sizeof(uint32_t)));
+      GV_C(hipMalloc(reinterpret_cast<void **>(&h->x_clipT[k]), nT * sizeof(uint32_t)));
+      GV_C(hipMemsetAsync(h->x_hitN[k], 0, nN * sizeof(uint32_t), h->stream));
+      GV_C(hipMemsetAsync(h->x_clipN[k], 0, nN * sizeof(uint32_t), h->stream));
+      GV_C(hipMemsetAsync(h->x_hitT[k], 0, nT * sizeof(uint32_t), h->stream));
+      GV_C(hipMemsetAsync(h->x_clipT[k], 0, nT * sizeof(uint32_t), h->stream));
+    }
+    for (int k = 0; k < 2; ++k) {
+      GV_C(hipMalloc(reinterpret_cast<void **>(&h->bin_total[k]), (size_t)h->n_tiles * sizeof(uint32_t)));
+      GV_C(hipMemsetAsync(h->bin_total[k], 0, (size_t)h->n_tiles * sizeof(uint32_t), h->stream));
+    }
+    GV_C(hipMalloc(reinterpret_cast<void **>(&h->bin_done), (size_t)h->n_tiles * sizeof(uint32_t)));
+    GV_C(hipMemsetAsync(h->bin_done, 0, (size_t)h->n_tiles * sizeof(uint32_t), h->stream));
+  } else {
+    // generic path: byte flags of clipped ray ends + the compacted ray list
+    GV_C(hipMalloc(reinterpret_cast<void **>(&h->clip_end), G + 16));
+    GV_C(hipMemsetAsync(h->clip_end, 0, G + 16, h->stream));
+    GV_C(hipMalloc(reinterpret_cast<void **>(&h->ray_list), G * sizeof(uint32_t)));
+  }
+  for (auto &e : h->ev) GV_C(hipEventCreate(&e));
 #undef GV_C
-  if (ensure_det(h, 64) != GV_OK) return fail(GV_ERR_HIP);
-  if (clear_counts(h) != GV_OK) return fail(GV_ERR_HIP);
+  if (ensure_det_shared(h, 64) != GV_OK) return fail(GV_ERR_HIP);
+  for (auto &d : h->det)
+    if (ensure_det(h, d, 64) != GV_OK) return fail(GV_ERR_HIP);
+  if (ensure_point_buffers(h, 0) != GV_OK) return fail(GV_ERR_HIP);
   *out = h;
   int rc = gv_reset(h);
   if (rc != GV_OK) { *out = nullptr; return fail(rc); }
@@ -950,36 +1036,48 @@ int gv_destroy(gv_handle h)
 {
   if (!h) return GV_ERR_BAD_ARG;
   (void)hipSetDevice(h->device);
-  if (h->stream) (void)hipStreamSynchronize(h->stream);
-  if (h->stream2) (void)hipStreamSynchronize(h->stream2);
-  if (h->stream3) (void)hipStreamSynchronize(h->stream3);
-  if (h->stream2b) (void)hipStreamSynchronize(h->stream2b);
-  if (h->stream4) (void)hipStreamSynchronize(h->stream4);
+  for (hipStream_t s : {h->stream_copy, h->stream, h->stream2, h->stream3})
+    if (s) (void)hipStreamSynchronize(s);
   if (h->comm) { ncclCommDestroy(h->comm); h->comm = nullptr; }
-  void *bufs[] = {h->log_odds, h->occupancy, h->occ_i8, h->hits, h->miss, h->clip_end, h->hit8, h->ray_list, h->ray_count,
-                  h->ray_stats, h->scratch_i32, h->d_dbg, h->missT, h->hitN, h->clipN, h->hitT, h->clipT, h->cx, h->cy, h->cz, h->tx, h->ty, h->tz, h->raw, h->cell_idx,
-                  h->bbox_id, h->d_bboxes, h->d_poses, h->d_rects, h->d_orient, h->d_conf, h->d_dims, h->d_vout,
-                  h->d_pts, h->d_bbox_f, h->d_tile_mask, h->knn_partial, h->d_depths, h->d_knn_d2, h->d_idx, h->d_segof,
-                  h->d_segstart, h->gx, h->gy, h->gz, h->d_keep, h->d_planes, h->d_plane_counts, h->d_ground};
+  void *bufs[] = {h->log_odds, h->occupancy, h->occ_i8, h->hits, h->clip_end, h->ray_list, h->ray_count, h->scratch_i32,
+                  h->bin_keys, h->bin_tab, h->bin_total[0], h->bin_total[1], h->bin_done, h->bin_scratch,
+                  h->tx, h->ty, h->tz, h->cell_idx, h->bbox_id, h->d_vout, h->d_pts, h->knn_partial, h->d_depths,
+                  h->d_knn_d2, h->d_idx, h->d_segof, h->d_segstart, h->gx, h->gy, h->gz, h->d_keep, h->d_planes,
+                  h->d_plane_counts, h->d_ground};
   for (void *p : bufs)
     if (p) (void)hipFree(p);
-  for (int k = 1; k < gv_context::kSets; ++k) {
+#ifdef GV_DIAG
+  if (h->d_dbg) (void)hipFree(h->d_dbg);
+#endif
+  for (int k = 0; k < gv_context::kSets; ++k) {
     void *xs[] = {h->x_hitN[k], h->x_clipN[k], h->x_hitT[k], h->x_clipT[k], h->x_rects[k], h->x_miss[k], h->x_missT[k], h->x_stats[k]};
     for (void *p : xs)
       if (p) (void)hipFree(p);
   }
+  for (auto &c : h->cloud) {
+    for (void *p : {(void *)c.x, (void *)c.y, (void *)c.z, (void *)c.raw})
+      if (p) (void)hipFree(p);
+    if (c.ready) (void)hipEventDestroy(c.ready);
+    if (c.used) (void)hipEventDestroy(c.used);
+  }
+  for (auto &d : h->det) {
+    for (void *p : {(void *)d.bboxes, (void *)d.poses, (void *)d.orient, (void *)d.conf, (void *)d.dims, (void *)d.bbox_f, (void *)d.tile_mask})
+      if (p) (void)hipFree(p);
+    if (d.stage) (void)hipHostFree(d.stage);
+    if (d.ready) (void)hipEventDestroy(d.ready);
+    if (d.used) (void)hipEventDestroy(d.used);
+  }
   for (auto &e : h->ev)
+    if (e) (void)hipEventDestroy(e);
+  for (auto &e : h->ev_join)
     if (e) (void)hipEventDestroy(e);
   for (int i = 0; i < gv_context::kSets; ++i) {
     if (h->ev_build[i]) (void)hipEventDestroy(h->ev_build[i]);
     if (h->ev_fin[i]) (void)hipEventDestroy(h->ev_fin[i]);
     if (h->ev_sec[i]) (void)hipEventDestroy(h->ev_sec[i]);
   }
-  if (h->stream3) (void)hipStreamDestroy(h->stream3);
-  if (h->stream2b) (void)hipStreamDestroy(h->stream2b);
-  if (h->stream4) (void)hipStreamDestroy(h->stream4);
-  if (h->stream2) (void)hipStreamDestroy(h->stream2);
-  if (h->stream) (void)hipStreamDestroy(h->stream);
+  for (hipStream_t s : {h->stream3, h->stream2, h->stream_copy, h->stream})
+    if (s) (void)hipStreamDestroy(s);
   delete h;
   return GV_OK;
 }
@@ -1024,22 +1122,146 @@ int gv_set_transforms(gv_handle h, const gv_transform *cl, const gv_transform *b
   GV_CATCH
 }
 
+/* ------------------------------------------------------------------ ingest -- */
+int gv_host_alloc(void **ptr, size_t bytes)
+{
+  if (!ptr || !bytes) return GV_ERR_BAD_ARG;
+  *ptr = nullptr;
+  return hipHostMalloc(ptr, bytes, hipHostMallocDefault) == hipSuccess ? GV_OK : GV_ERR_HIP;
+}
+
+int gv_host_free(void *ptr)
+{
+  if (!ptr) return GV_OK;
+  return hipHostFree(ptr) == hipSuccess ? GV_OK : GV_ERR_HIP;
+}
+
+}  // extern "C"
+
+namespace {
+
+// The cloud set that is NOT being read by the frames in flight, grown to n points, with the copy
+// stream ordered after the last frame that read it.
+int begin_cloud_upload(gv_context *h, size_t n, int &target)
+{
+  int rc = set_device_only(h);
+  if (rc) return rc;
+  if ((rc = ensure_point_buffers(h, n))) return rc;
+  target = h->cloud_cur ^ 1;
+  CloudSet &c = h->cloud[target];
+  if (n > c.cap) {
+    GV_HIP(hipEventSynchronize(c.used));
+    GV_HIP(hipEventSynchronize(c.ready));
+    for (float **p : {&c.x, &c.y, &c.z}) {
+      if (*p) GV_HIP(hipFree(*p));
+      *p = nullptr;
+    }
+    c.cap = 0;
+    const size_t want = n + n / 8 + 1024;
+    GV_HIP(hipMalloc(reinterpret_cast<void **>(&c.x), want * sizeof(float)));
+    GV_HIP(hipMalloc(reinterpret_cast<void **>(&c.y), want * sizeof(float)));
+    GV_HIP(hipMalloc(reinterpret_cast<void **>(&c.z), want * sizeof(float)));
+    c.cap = want;
+  }
+  GV_HIP(hipStreamWaitEvent(h->stream_copy, c.used, 0));
+  return GV_OK;
+}
+
+int end_cloud_upload(gv_context *h, int target, size_t n)
+{
+  CloudSet &c = h->cloud[target];
+  GV_HIP(hipEventRecord(c.ready, h->stream_copy));
+  h->cloud_cur = target;
+  h->cx = c.x; h->cy = c.y; h->cz = c.z;
+  h->n = n;
+  h->cloud_wait = true;
+  h->have_cell_idx = h->have_bbox_id = false;
+  return GV_OK;
+}
+
+int upload_xyz(gv_context *h, const float *x, const float *y, const float *z, size_t n, bool wait)
+{
+  int target = 0;
+  int rc = begin_cloud_upload(h, n, target);
+  if (rc) return rc;
+  CloudSet &c = h->cloud[target];
+  if (n) {
+    GV_HIP(hipMemcpyAsync(c.x, x, n * sizeof(float), hipMemcpyHostToDevice, h->stream_copy));
+    GV_HIP(hipMemcpyAsync(c.y, y, n * sizeof(float), hipMemcpyHostToDevice, h->stream_copy));
+    GV_HIP(hipMemcpyAsync(c.z, z, n * sizeof(float), hipMemcpyHostToDevice, h->stream_copy));
+  }
+  if ((rc = end_cloud_upload(h, target, n))) return rc;
+  if (wait) GV_HIP(hipEventSynchronize(c.ready));
+  return GV_OK;
+}
+
+int upload_pc2(gv_context *h, const uint8_t *data, size_t n, uint32_t point_step, uint32_t off_x, uint32_t off_y,
+               uint32_t off_z, bool wait)
+{
+  int target = 0;
+  int rc = begin_cloud_upload(h, n, target);
+  if (rc) return rc;
+  CloudSet &c = h->cloud[target];
+  const size_t bytes = n * (size_t)point_step;
+  if (bytes + 16 > c.raw_cap) {
+    GV_HIP(hipEventSynchronize(c.ready));   // the previous de-interleave out of this buffer is done
+    if ((rc = grow(h, c.raw, c.raw_cap, bytes + bytes / 8 + 16))) return rc;
+  }
+  if (n) {
+    GV_HIP(hipMemcpyAsync(c.raw, data, bytes, hipMemcpyHostToDevice, h->stream_copy));
+    launch_deinterleave(c.raw, (uint32_t)n, point_step, off_x, off_y, off_z, c.x, c.y, c.z, h->stream_copy);
+    GV_HIP(hipGetLastError());
+  }
+  if ((rc = end_cloud_upload(h, target, n))) return rc;
+  if (wait) GV_HIP(hipEventSynchronize(c.ready));
+  return GV_OK;
+}
+
+int set_detections(gv_context *h, const gv_frame_desc *d, bool wait)
+{
+  if (!h || !d) return GV_ERR_BAD_ARG;
+  if (d->n_bboxes < 0 || d->n_poses < 0) return GV_ERR_BAD_ARG;
+  if (d->n_bboxes && !d->bboxes) return GV_ERR_BAD_ARG;
+  const bool vision = d->flags & GV_FRAME_VISION_ORIENT;
+  if (vision && d->n_bboxes && (!d->orient || !d->conf || !d->dims)) return GV_ERR_BAD_ARG;
+  if (!vision && d->n_poses && !d->poses) return GV_ERR_BAD_ARG;
+  int rc = set_device_only(h);
+  if (rc) return rc;
+  const int target = h->det_cur ^ 1;
+  DetSet &D = h->det[target];
+  // shared rectangle / vision buffers may have to grow (drains); do it before ordering the copy stream
+  if ((rc = ensure_det_shared(h, std::max(d->n_bboxes, d->n_poses)))) return rc;
+  if ((rc = ensure_det(h, D, std::max(d->n_bboxes, d->n_poses)))) return rc;
+  GV_HIP(hipStreamWaitEvent(h->stream_copy, D.used, 0));   // frames that read this set are past their points pass
+  const bool net = vision && d->n_bboxes;
+  if ((rc = upload_det(h, D, d->bboxes, d->n_bboxes, vision ? nullptr : d->poses, vision ? 0 : d->n_poses,
+                       net ? d->orient : nullptr, net ? d->conf : nullptr, net ? d->dims : nullptr, h->stream_copy)))
+    return rc;
+  D.flags = d->flags;
+  GV_HIP(hipEventRecord(D.ready, h->stream_copy));
+  h->det_cur = target;
+  h->det_wait = true;
+  if (wait) GV_HIP(hipEventSynchronize(D.ready));
+  return GV_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
 int gv_cloud_upload_xyz(gv_handle h, const float *x, const float *y, const float *z, size_t n)
 {
   if (!h || (n && (!x || !y || !z)) || n > 0x7fffffffu) return GV_ERR_BAD_ARG;
   GV_TRY
-  int rc = use_device(h);
-  if (rc) return rc;
-  if ((rc = ensure_cloud(h, n))) return rc;
-  if (n) {
-    GV_HIP(hipMemcpyAsync(h->cx, x, n * sizeof(float), hipMemcpyHostToDevice, h->stream));
-    GV_HIP(hipMemcpyAsync(h->cy, y, n * sizeof(float), hipMemcpyHostToDevice, h->stream));
-    GV_HIP(hipMemcpyAsync(h->cz, z, n * sizeof(float), hipMemcpyHostToDevice, h->stream));
-  }
-  GV_HIP(hipStreamSynchronize(h->stream));
-  h->n = n;
-  h->have_cell_idx = h->have_bbox_id = false;
-  return GV_OK;
+  return upload_xyz(h, x, y, z, n, true);
+  GV_CATCH
+}
+
+int gv_cloud_upload_xyz_async(gv_handle h, const float *x, const float *y, const float *z, size_t n)
+{
+  if (!h || (n && (!x || !y || !z)) || n > 0x7fffffffu) return GV_ERR_BAD_ARG;
+  GV_TRY
+  return upload_xyz(h, x, y, z, n, false);
   GV_CATCH
 }
 
@@ -1050,21 +1272,28 @@ int gv_cloud_upload_pointcloud2(gv_handle h, const uint8_t *data, size_t n, uint
   if (point_step < 4 || off_x + 4 > point_step || off_y + 4 > point_step || off_z + 4 > point_step)
     return GV_ERR_BAD_ARG;
   GV_TRY
-  int rc = use_device(h);
-  if (rc) return rc;
-  if ((rc = ensure_cloud(h, n))) return rc;
-  const size_t bytes = n * (size_t)point_step;
-  if ((rc = grow(h, h->raw, h->raw_cap, bytes + 16))) return rc;
-  if (n) {
-    GV_HIP(hipMemcpyAsync(h->raw, data, bytes, hipMemcpyHostToDevice, h->stream));
-    launch_deinterleave(h->raw, (uint32_t)n, point_step, off_x, off_y, off_z, h->cx, h->cy, h->cz, h->stream);
-    GV_HIP(hipGetLastError());
-  }
-  GV_HIP(hipStreamSynchronize(h->stream));
-  h->n = n;
-  h->have_cell_idx = h->have_bbox_id = false;
-  return GV_OK;
+  return upload_pc2(h, data, n, point_step, off_x, off_y, off_z, true);
   GV_CATCH
+}
+
+int gv_cloud_upload_pointcloud2_async(gv_handle h, const uint8_t *data, size_t n, uint32_t point_step, uint32_t off_x,
+                                      uint32_t off_y, uint32_t off_z)
+{
+  if (!h || (n && !data) || n > 0x7fffffffu) return GV_ERR_BAD_ARG;
+  if (point_step < 4 || off_x + 4 > point_step || off_y + 4 > point_step || off_z + 4 > point_step)
+    return GV_ERR_BAD_ARG;
+  GV_TRY
+  return upload_pc2(h, data, n, point_step, off_x, off_y, off_z, false);
+  GV_CATCH
+}
+
+int gv_cloud_upload_wait(gv_handle h)
+{
+  if (!h) return GV_ERR_BAD_ARG;
+  int rc = set_device_only(h);
+  if (rc) return rc;
+  GV_HIP(hipStreamSynchronize(h->stream_copy));
+  return GV_OK;
 }
 
 int gv_transform_lidar_to_camera(gv_handle h, float *x_cam, float *y_cam, float *z_cam)
@@ -1098,30 +1327,44 @@ int gv_transform_lidar_to_camera(gv_handle h, float *x_cam, float *y_cam, float 
   GV_CATCH
 }
 
-int gv_extract_cloud_per_bbox(gv_handle h, const gv_bbox *bboxes, int32_t nb, int32_t *bbox_id, int32_t *counts)
+static void bbox_points_args(gv_context *h, PointsArgs &a)
 {
-  if (!h || nb < 0 || (nb && !bboxes) || !bbox_id) return GV_ERR_BAD_ARG;
-  if (!h->has_cl) return GV_ERR_TF;
-  GV_TRY
-  int rc = use_device(h);
-  if (rc) return rc;
-  if ((rc = upload_bboxes(h, bboxes, nb))) return rc;
-  PointsArgs a{};
   a.x = h->cx; a.y = h->cy; a.z = h->cz;
   a.n = (uint32_t)h->n;
   a.g = h->g;
   a.m_cam = h->m_cam;
   a.cam = h->camk;
-  a.bboxes = h->d_bboxes;
-  a.nb = nb;
-  a.bbox_f = h->d_bbox_f;
-  a.tile_mask = h->d_tile_mask;
-  a.tiles_x = h->tiles_x; a.tiles_y = h->tiles_y; a.mask_words = h->mask_words;
+  a.bt = bbox_test_of(h, h->det[2]);
   a.bbox_id = h->bbox_id;
   a.do_bbox = true;
+}
+
+// device int16 ids -> caller's int32 array
+static int read_back_ids(gv_context *h, int32_t *out)
+{
+  if (!h->n) return GV_OK;
+  int rc = ensure_scratch_i32(h, h->n);
+  if (rc) return rc;
+  launch_i16_to_i32(h->bbox_id, h->scratch_i32, h->n, h->stream);
+  GV_HIP(hipGetLastError());
+  GV_HIP(hipMemcpyAsync(out, h->scratch_i32, h->n * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+  GV_HIP(hipStreamSynchronize(h->stream));
+  return GV_OK;
+}
+
+int gv_extract_cloud_per_bbox(gv_handle h, const gv_bbox *bboxes, int32_t nb, int32_t *bbox_id, int32_t *counts)
+{
+  if (!h || nb < 0 || nb > 32767 || (nb && !bboxes) || !bbox_id) return GV_ERR_BAD_ARG;
+  if (!h->has_cl) return GV_ERR_TF;
+  GV_TRY
+  int rc = use_device(h);
+  if (rc) return rc;
+  if ((rc = upload_scratch_bboxes(h, bboxes, nb))) return rc;
+  PointsArgs a{};
+  bbox_points_args(h, a);
   launch_points(a, h->stream);
   GV_HIP(hipGetLastError());
-  if (h->n) GV_HIP(hipMemcpyAsync(bbox_id, h->bbox_id, h->n * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+  if ((rc = read_back_ids(h, bbox_id))) return rc;
   GV_HIP(hipStreamSynchronize(h->stream));
   h->have_bbox_id = true;
   if (counts) {
@@ -1163,11 +1406,10 @@ int gv_vision_post_process(gv_handle h, const float *orient, const float *conf, 
   if (nb == 0) return GV_OK;
   int rc = use_device(h);
   if (rc) return rc;
-  if ((rc = upload_bboxes(h, bboxes, nb))) return rc;
-  GV_HIP(hipMemcpyAsync(h->d_orient, orient, (size_t)nb * 4 * sizeof(float), hipMemcpyHostToDevice, h->stream));
-  GV_HIP(hipMemcpyAsync(h->d_conf, conf, (size_t)nb * 2 * sizeof(float), hipMemcpyHostToDevice, h->stream));
-  GV_HIP(hipMemcpyAsync(h->d_dims, dims, (size_t)nb * 3 * sizeof(float), hipMemcpyHostToDevice, h->stream));
-  launch_vision(h->d_orient, h->d_conf, h->d_dims, h->d_bboxes, nb, h->cam, h->d_vout, h->d_poses, h->stream);
+  DetSet &d = h->det[2];
+  if ((rc = upload_det(h, d, bboxes, nb, nullptr, 0, orient, conf, dims, h->stream))) return rc;
+  GV_HIP(hipEventRecord(d.ready, h->stream));
+  launch_vision(d.orient, d.conf, d.dims, d.bboxes, nb, h->cam, h->d_vout, d.poses, h->stream);
   GV_HIP(hipGetLastError());
   std::vector<VisionOut> vo((size_t)nb);
   GV_HIP(hipMemcpyAsync(vo.data(), h->d_vout, (size_t)nb * sizeof(VisionOut), hipMemcpyDeviceToHost, h->stream));
@@ -1268,11 +1510,10 @@ int gv_update_map_poses(gv_handle h, const gv_lshape_pose *poses, int32_t n)
   GV_TRY
   int rc = use_device(h);
   if (rc) return rc;
-  if ((rc = ensure_det(h, n))) return rc;
-  if (n) {
-    GV_HIP(hipMemcpyAsync(h->d_poses, poses, (size_t)n * sizeof(gv_lshape_pose), hipMemcpyHostToDevice, h->stream));
-    launch_rects_from_poses(h->d_poses, n, h->g, false, h->x_bc, h->d_rects, h->stream);
-  }
+  DetSet &d = h->det[2];
+  if ((rc = upload_det(h, d, nullptr, 0, poses, n, nullptr, nullptr, nullptr, h->stream))) return rc;
+  GV_HIP(hipEventRecord(d.ready, h->stream));
+  if (n) launch_rects_from_poses(d.poses, n, h->g, false, h->x_bc, h->x_rects[0], h->stream);
   if ((rc = enqueue_plain_update(h, n))) return rc;
   GV_HIP(hipStreamSynchronize(h->stream));
   return GV_OK;
@@ -1285,10 +1526,10 @@ int gv_update_map_points(gv_handle h, const double *pts, const gv_bbox *bboxes, 
   GV_TRY
   int rc = use_device(h);
   if (rc) return rc;
-  if ((rc = upload_bboxes(h, bboxes, n))) return rc;
+  if ((rc = upload_scratch_bboxes(h, bboxes, n))) return rc;
   if (n) {
     GV_HIP(hipMemcpyAsync(h->d_pts, pts, (size_t)n * 3 * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    launch_rects_from_points(h->d_pts, h->d_bboxes, n, h->g, h->d_rects, h->stream);
+    launch_rects_from_points(h->d_pts, h->det[2].bboxes, n, h->g, h->x_rects[0], h->stream);
   }
   if ((rc = enqueue_plain_update(h, n))) return rc;
   GV_HIP(hipStreamSynchronize(h->stream));
@@ -1348,32 +1589,15 @@ int gv_set_log_odds(gv_handle h, const float *in)
 
 int gv_frame_set_detections(gv_handle h, const gv_frame_desc *d)
 {
-  if (!h || !d) return GV_ERR_BAD_ARG;
-  if (d->n_bboxes < 0 || d->n_poses < 0) return GV_ERR_BAD_ARG;
-  if (d->n_bboxes && !d->bboxes) return GV_ERR_BAD_ARG;
-  const bool vision = d->flags & GV_FRAME_VISION_ORIENT;
-  if (vision && d->n_bboxes && (!d->orient || !d->conf || !d->dims)) return GV_ERR_BAD_ARG;
-  if (!vision && d->n_poses && !d->poses) return GV_ERR_BAD_ARG;
   GV_TRY
-  int rc = use_device(h);
-  if (rc) return rc;
-  const int32_t need = std::max(d->n_bboxes, d->n_poses);
-  if ((rc = ensure_det(h, need))) return rc;
-  if ((rc = upload_bboxes(h, d->bboxes, d->n_bboxes))) return rc;
-  if (vision && d->n_bboxes) {
-    const size_t nb = (size_t)d->n_bboxes;
-    GV_HIP(hipMemcpyAsync(h->d_orient, d->orient, nb * 4 * sizeof(float), hipMemcpyHostToDevice, h->stream));
-    GV_HIP(hipMemcpyAsync(h->d_conf, d->conf, nb * 2 * sizeof(float), hipMemcpyHostToDevice, h->stream));
-    GV_HIP(hipMemcpyAsync(h->d_dims, d->dims, nb * 3 * sizeof(float), hipMemcpyHostToDevice, h->stream));
-  } else if (!vision && d->n_poses) {
-    GV_HIP(hipMemcpyAsync(h->d_poses, d->poses, (size_t)d->n_poses * sizeof(gv_lshape_pose), hipMemcpyHostToDevice,
-                          h->stream));
-  }
-  GV_HIP(hipStreamSynchronize(h->stream));   // host buffers are free to reuse after return
-  h->frame_flags = d->flags;
-  h->nb = d->n_bboxes;
-  h->n_poses = vision ? 0 : d->n_poses;
-  return GV_OK;
+  return set_detections(h, d, true);
+  GV_CATCH
+}
+
+int gv_frame_set_detections_async(gv_handle h, const gv_frame_desc *d)
+{
+  GV_TRY
+  return set_detections(h, d, false);
   GV_CATCH
 }
 
@@ -1381,26 +1605,39 @@ int gv_frame_enqueue(gv_handle h)
 {
   if (!h) return GV_ERR_BAD_ARG;
   GV_TRY
-  const uint32_t keep = GV_FRAME_KEEP_CELL_IDX | GV_FRAME_KEEP_COUNTS;
-  const bool pipelined = h->tile_path && !h->force_simple && !h->no_pipeline && !(h->frame_flags & keep);
-  if (pipelined) {
+  if (!h->det[h->det_cur].valid) return GV_ERR_STATE;   // no gv_frame_set_detections yet
+  if (sector_path(h) && !h->no_pipeline) {
     int rc = set_device_only(h);
     if (rc) return rc;
-    return enqueue_frame_pipelined(h);
+    return enqueue_frame_tiles(h, true, false);
   }
   int rc = use_device(h);
   if (rc) return rc;
-  return enqueue_frame(h, false);
+  return sector_path(h) ? enqueue_frame_tiles(h, false, false) : enqueue_frame_generic(h, false);
   GV_CATCH
+}
+
+int gv_frame_fence(gv_handle h)
+{
+  if (!h) return GV_ERR_BAD_ARG;
+  int rc = set_device_only(h);
+  if (rc) return rc;
+  if (h->pipe_busy) {   // join streams B and C (and the copy stream) into stream A
+    hipStream_t others[3] = {h->stream2, h->stream3, h->stream_copy};
+    for (int k = 0; k < 3; ++k) {
+      GV_HIP(hipEventRecord(h->ev_join[k], others[k]));
+      GV_HIP(hipStreamWaitEvent(h->stream, h->ev_join[k], 0));
+    }
+  }
+  return GV_OK;
 }
 
 int gv_synchronize(gv_handle h)
 {
   if (!h) return GV_ERR_BAD_ARG;
-  int rc = use_device(h);
+  int rc = set_device_only(h);
   if (rc) return rc;
-  GV_HIP(hipStreamSynchronize(h->stream));
-  return GV_OK;
+  return drain(h);
 }
 
 int gv_process_frame(gv_handle h, const gv_frame_desc *desc)
@@ -1414,20 +1651,20 @@ int gv_process_frame(gv_handle h, const gv_frame_desc *desc)
 int gv_get_hits(gv_handle h, int32_t *out)
 {
   if (!h || !out) return GV_ERR_BAD_ARG;
-  if (!h->have_counts) return GV_ERR_STATE;
+  if (!h->have_hits) return GV_ERR_STATE;
   return copy_out(h, out, h->hits, (size_t)h->g.G * sizeof(int32_t));
 }
 
 int gv_get_miss(gv_handle h, int32_t *out)
 {
   if (!h || !out) return GV_ERR_BAD_ARG;
-  if (!h->have_counts) return GV_ERR_STATE;
+  if (!h->have_miss) return GV_ERR_STATE;
   int rc = use_device(h);
   if (rc) return rc;
-  if (h->tile_path && !h->force_simple)
-    launch_miss_to_i32(h->miss, h->missT, h->g.nx, h->g.ny, h->scratch_i32, h->stream);
+  if (sector_path(h))
+    launch_miss_to_i32(h->x_miss[h->last_set], h->x_missT[h->last_set], h->g.nx, h->g.ny, h->scratch_i32, h->stream);
   else
-    launch_u8_to_i32(h->miss, h->scratch_i32, (size_t)h->g.G, h->stream);
+    launch_u8_to_i32(h->x_miss[0], h->scratch_i32, (size_t)h->g.G, h->stream);
   GV_HIP(hipGetLastError());
   return copy_out(h, out, h->scratch_i32, (size_t)h->g.G * sizeof(int32_t));
 }
@@ -1443,7 +1680,11 @@ int gv_get_bbox_id(gv_handle h, int32_t *out)
 {
   if (!h || !out) return GV_ERR_BAD_ARG;
   if (!h->have_bbox_id) return GV_ERR_STATE;
-  return copy_out(h, out, h->bbox_id, h->n * sizeof(int32_t));
+  GV_TRY
+  int rc = use_device(h);
+  if (rc) return rc;
+  return read_back_ids(h, out);
+  GV_CATCH
 }
 
 int gv_get_ray_stats(gv_handle h, uint64_t *n_rays, uint64_t *n_visits)
@@ -1451,7 +1692,7 @@ int gv_get_ray_stats(gv_handle h, uint64_t *n_rays, uint64_t *n_visits)
   if (!h) return GV_ERR_BAD_ARG;
   GV_TRY
   std::vector<unsigned long long> st(2 * h->stat_slots, 0ull);
-  int rc = copy_out(h, st.data(), h->x_stats[h->last_stats_set], st.size() * sizeof(unsigned long long));
+  int rc = copy_out(h, st.data(), h->x_stats[h->last_set], st.size() * sizeof(unsigned long long));
   if (rc) return rc;
   unsigned long long rays = 0, visits = 0;
   for (size_t i = 0; i < h->stat_slots; ++i) { rays += st[2 * i]; visits += st[2 * i + 1]; }
@@ -1461,16 +1702,17 @@ int gv_get_ray_stats(gv_handle h, uint64_t *n_rays, uint64_t *n_visits)
   GV_CATCH
 }
 
-// diagnostic only (tools/sector_phases.py): copies the phase stamps of the last sector launch
+#ifdef GV_DIAG
+// diagnostic build only (tools/sector_phases.py): copies the phase stamps of the last sector launch
 int gv_debug_sector_stamps(gv_handle h, unsigned long long *out, size_t n_wg)
 {
   if (!h || !out || !h->d_dbg) return GV_ERR_STATE;
   return copy_out(h, out, h->d_dbg, n_wg * 16 * sizeof(unsigned long long));
 }
 
-// diagnostic (not part of the ABI): enqueue `frames` pipelined frames with timing events around every
-// kernel; out[frame*10 + 2*k + {0,1}] = start/end in us of kernel k (rects, points, bitmaps, sectors, grid pass)
-extern "C" int gv_debug_pipeline_trace(gv_handle h, int32_t frames, float *out)
+// diagnostic build only: enqueue `frames` pipelined frames with timing events around every kernel;
+// out[frame*10 + 2*k + {0,1}] = start/end in us of kernel k (rects, partition, tiles, sectors, grid pass)
+int gv_debug_pipeline_trace(gv_handle h, int32_t frames, float *out)
 {
   if (!h || frames <= 0 || !out) return GV_ERR_BAD_ARG;
   GV_TRY
@@ -1493,6 +1735,7 @@ extern "C" int gv_debug_pipeline_trace(gv_handle h, int32_t frames, float *out)
   return rc ? rc : rc2;
   GV_CATCH
 }
+#endif
 
 void *gv_stream(gv_handle h) { return h ? (void *)h->stream : nullptr; }
 
@@ -1506,16 +1749,7 @@ int gv_time_frames(gv_handle h, int32_t frames, float *ms_total)
   GV_HIP(hipEventRecord(e0, h->stream));
   for (int32_t i = 0; i < frames; ++i)
     if ((rc = gv_frame_enqueue(h))) return rc;
-  if (h->pipe_busy) {   // join streams B and C into stream A before the closing event
-    GV_HIP(hipEventRecord(h->ev[1], h->stream2));
-    GV_HIP(hipStreamWaitEvent(h->stream, h->ev[1], 0));
-    GV_HIP(hipEventRecord(h->ev[2], h->stream3));
-    GV_HIP(hipStreamWaitEvent(h->stream, h->ev[2], 0));
-    GV_HIP(hipEventRecord(h->ev[3], h->stream2b));
-    GV_HIP(hipStreamWaitEvent(h->stream, h->ev[3], 0));
-    GV_HIP(hipEventRecord(h->ev[4], h->stream4));
-    GV_HIP(hipStreamWaitEvent(h->stream, h->ev[4], 0));
-  }
+  if ((rc = gv_frame_fence(h))) return rc;
   GV_HIP(hipEventRecord(e1, h->stream));
   GV_HIP(hipEventSynchronize(e1));
   GV_HIP(hipEventElapsedTime(ms_total, e0, e1));
@@ -1527,11 +1761,12 @@ int gv_time_frame_stages(gv_handle h, int32_t frames, float *stage_ms)
 {
   if (!h || frames <= 0 || !stage_ms) return GV_ERR_BAD_ARG;
   GV_TRY
+  if (!h->det[h->det_cur].valid) return GV_ERR_STATE;
   int rc = use_device(h);
   if (rc) return rc;
   for (int s = 0; s < kNumStages; ++s) stage_ms[s] = 0.0f;
   for (int32_t i = 0; i < frames; ++i) {
-    if ((rc = enqueue_frame(h, true))) return rc;
+    if ((rc = sector_path(h) ? enqueue_frame_tiles(h, false, true) : enqueue_frame_generic(h, true))) return rc;
     GV_HIP(hipEventSynchronize(h->ev[kNumStages]));
     for (int s = 0; s < kNumStages; ++s) {
       float ms = 0.0f;
@@ -1568,7 +1803,7 @@ int gv_compute_depth_for_bboxes(gv_handle h, const gv_bbox *bboxes, int32_t nb, 
   if (nb == 0) return GV_OK;
   int rc = use_device(h);
   if (rc) return rc;
-  if ((rc = upload_bboxes(h, bboxes, nb))) return rc;
+  if ((rc = upload_scratch_bboxes(h, bboxes, nb))) return rc;
   if ((rc = ensure_tbuf(h, std::max<size_t>(h->n, 1)))) return rc;
   const int nchunks = 64;
   if ((rc = grow(h, h->knn_partial, h->knn_partial_cap, (size_t)nb * nchunks * k))) return rc;
@@ -1583,7 +1818,7 @@ int gv_compute_depth_for_bboxes(gv_handle h, const gv_bbox *bboxes, int32_t nb, 
   }
   // buildKDTree projection (cloud_detections.cpp:8-33) then the exact k nearest (:43-87)
   launch_project_uvd(h->cx, h->cy, h->cz, (uint32_t)h->n, h->m_cam, h->camk, h->tx, h->ty, h->tz, h->stream);
-  launch_knn(h->tx, h->ty, h->tz, (uint32_t)h->n, h->d_bboxes, nb, k, nchunks, h->knn_partial, h->d_depths,
+  launch_knn(h->tx, h->ty, h->tz, (uint32_t)h->n, h->det[2].bboxes, nb, k, nchunks, h->knn_partial, h->d_depths,
              h->d_knn_d2, h->stream);
   GV_HIP(hipGetLastError());
   GV_HIP(hipMemcpyAsync(depths, h->d_depths, (size_t)nb * sizeof(float), hipMemcpyDeviceToHost, h->stream));
@@ -1606,30 +1841,19 @@ static int compute_bbox_pose_impl(gv_handle h, const gv_bbox *bboxes, int32_t nb
   const size_t n = h->n;
   for (int32_t b = 0; b < nb; ++b) { valid[b] = 0; poses_out[b] = gv_lshape_pose{}; }
   if (n == 0) return GV_OK;
-  if ((rc = upload_bboxes(h, bboxes, nb))) return rc;
+  if ((rc = upload_scratch_bboxes(h, bboxes, nb))) return rc;
   if ((rc = ensure_tbuf(h, n))) return rc;
   // extractCloudPerBBox (cloud_detections.cpp:250-298): first-match bbox id per point,
   // and the camera-frame cloud the per-bbox clouds are cut from
   {
     PointsArgs a{};
-    a.x = h->cx; a.y = h->cy; a.z = h->cz;
-    a.n = (uint32_t)n;
-    a.g = h->g;
-    a.m_cam = h->m_cam;
-    a.cam = h->camk;
-    a.bboxes = h->d_bboxes;
-    a.nb = nb;
-    a.bbox_f = h->d_bbox_f;
-    a.tile_mask = h->d_tile_mask;
-    a.tiles_x = h->tiles_x; a.tiles_y = h->tiles_y; a.mask_words = h->mask_words;
-    a.bbox_id = h->bbox_id;
-    a.do_bbox = true;
+    bbox_points_args(h, a);
     launch_points(a, h->stream);
     launch_transform_cloud(h->cx, h->cy, h->cz, (uint32_t)n, h->m_cam, h->tx, h->ty, h->tz, h->stream);
     GV_HIP(hipGetLastError());
   }
-  std::vector<int32_t> ids(n);
-  GV_HIP(hipMemcpyAsync(ids.data(), h->bbox_id, n * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+  std::vector<int16_t> ids(n);
+  GV_HIP(hipMemcpyAsync(ids.data(), h->bbox_id, n * sizeof(int16_t), hipMemcpyDeviceToHost, h->stream));
   GV_HIP(hipStreamSynchronize(h->stream));
   h->have_bbox_id = true;
   // per-bbox point lists in cloud order (the reference appends in cloud order, :286)
@@ -1783,7 +2007,7 @@ int gv_segment_ground_plane(gv_handle h, double threshold, int32_t iterations, u
 int gv_compute_bbox_pose_ground_removed(gv_handle h, const gv_bbox *bboxes, int32_t nb, gv_lshape_pose *poses_out,
                                         uint8_t *valid, int32_t *n_poses_or_fail)
 {
-  if (!h) return GV_ERR_BAD_ARG;
+  if (!h || nb < 0 || (nb && (!bboxes || !poses_out || !valid))) return GV_ERR_BAD_ARG;
   // computeBBoxPose (cloud_detections.cpp:300-321): segmentGroundPlane -> extractCloudPerBBox -> PCA
   int64_t m = 0;
   int rc = gv_segment_ground_plane(h, 0.04, 50, 12345ull, nullptr, nullptr, &m);
@@ -1844,11 +2068,12 @@ int gv_process_frame_sharded(gv_handle h, const gv_frame_desc *desc)
 {
   if (!h || !desc) return GV_ERR_BAD_ARG;
   if (!h->comm) return GV_ERR_STATE;
+  if (!sector_path(h)) return GV_ERR_STATE;
   int rc = gv_frame_set_detections(h, desc);
   if (rc) return rc;
   GV_TRY
   if ((rc = use_device(h))) return rc;
-  if ((rc = enqueue_frame(h, false, true))) return rc;
+  if ((rc = enqueue_frame_tiles(h, false, false, true))) return rc;
   GV_HIP(hipStreamSynchronize(h->stream));
   return GV_OK;
   GV_CATCH

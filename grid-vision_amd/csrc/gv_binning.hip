@@ -1,0 +1,391 @@
+// gv_binning.hip -- [EXTENSION] X1 per-point binning with int32 hit counts for the tile path of
+// the production frame, plus the X2 ray ends and the A5 bbox test that share the pass over the
+// cloud.  gfx950, wave64, built with -ffp-contract=off (gv_device.hpp).
+//
+// Two kernels, no global atomics on the count grid, no cleared buffers:
+//
+//   k_bin_partition  one workgroup per chunk of the SoA cloud.  Per point: base<-lidar
+//       transform, getIndex -> (128x128-cell tile, cell inside the tile); out-of-map points go
+//       through the fp64 slab clip on dense lanes afterwards and become "clipped end" keys; the
+//       camera transform + projection + first-match bbox id ride along.  The chunk's 16-bit keys
+//       are counting-sorted by tile in LDS and written out as ONE contiguous run per workgroup
+//       (fully coalesced whatever the cloud looks like) with a row of per-tile start offsets.
+//   k_bin_tiles      one workgroup per tile: gathers the tile's key segments from every chunk,
+//       histograms them in LDS (int32, 64 KB), writes the tile of hits[] with plain coalesced
+//       stores and emits the four end bitmaps (hit/clip, both orientations) the sector ray stage
+//       reads -- every cell and every bitmap word is written every frame, so nothing is cleared.
+//       A tile that holds more than kSplitKeys keys (the cells next to the sensor of a real
+//       lidar) is shared by up to kSplitMax workgroups, each histogramming every k-th chunk; the
+//       partial tiles meet in a scratch slab and the workgroup whose ticket comes last sums them
+//       (integer sums: the result does not depend on the arrival order).
+//
+// Keys: bits 0..13 = cell inside the tile (ly << 7 | lx), bit 14 = clipped ray end (X2: end of
+// an out-of-map point's ray on the map border, counts as traversed), bit 15 unused.
+#include "gv_kernels.hpp"
+#include "gv_device.hpp"
+
+#include <algorithm>
+
+namespace gv {
+
+constexpr unsigned kKeyClip = 1u << 14;
+constexpr unsigned kStagedNone = 0xFFFFFFFFu;      // dropped point (non-finite, or outside with no ray)
+constexpr unsigned kStagedOutside = 0xFFFFFFFEu;   // out-of-map point waiting for the clip
+constexpr int kPartThreads = 256;
+constexpr int kTileThreads = 1024;
+constexpr int kSegBatch = 2048;                    // chunk descriptors staged in LDS per round
+
+__device__ __forceinline__ unsigned wave_incl_scan_add(unsigned v)
+{
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const unsigned u = __shfl_up(v, off);
+    if ((int)(threadIdx.x & 63) >= off) v += u;
+  }
+  return v;
+}
+
+// ------------------------------------------------------------- partition -----
+template <bool RAY, bool BBOX, bool KEEPCELL>
+__global__ void __launch_bounds__(kPartThreads) k_bin_partition(BinArgs a)
+{
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int T = a.n_tiles;
+  unsigned *staged = reinterpret_cast<unsigned *>(smem);                      // [chunk] tile << 16 | key
+  unsigned *hist = staged + a.chunk;                                          // [T] counts, then cursors
+  unsigned short *sorted = reinterpret_cast<unsigned short *>(hist + T);      // [chunk] keys grouped by tile
+  unsigned short *outl = sorted;                                              // outside-point list (dead before `sorted` is written)
+  __shared__ unsigned s_wsum[kPartThreads / 64], s_nout;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint32_t w = blockIdx.x;
+  const uint32_t base = w * a.chunk;
+  const uint32_t npts = min(a.chunk, a.n - base);
+  for (int t = tid; t < T; t += kPartThreads) hist[t] = 0;
+  if (tid == 0) s_nout = 0;
+  __syncthreads();
+
+  for (uint32_t k = tid; k < a.chunk; k += kPartThreads) {
+    unsigned st = kStagedNone;
+    if (k < npts) {
+      const uint32_t i = base + k;
+      const float px = a.x[i], py = a.y[i], pz = a.z[i];
+      float bx, by, bz;
+      xform34(a.m_base, px, py, pz, bx, by, bz);
+      int cell = -1;
+      if (isfinite(bx) && isfinite(by) && isfinite(bz)) {
+        int ix, iy;
+        if (get_index_fast(a.g, (double)bx, (double)by, ix, iy)) {
+          cell = iy * a.g.nx + ix;
+          const unsigned tile = (unsigned)((iy >> kBinTileLog) * a.tiles_x + (ix >> kBinTileLog));
+          st = (tile << 16) | (unsigned)(((iy & (kBinTile - 1)) << kBinTileLog) | (ix & (kBinTile - 1)));
+          atomicAdd(&hist[tile], 1u);
+        } else if (RAY && a.org.valid) {
+          st = kStagedOutside;
+        }
+      }
+      if (KEEPCELL) a.cell_idx[i] = cell;
+      if (BBOX) {
+        float cx, cy, cz;
+        xform34(a.m_cam, px, py, pz, cx, cy, cz);
+        a.bbox_id[i] = (int16_t)first_bbox(a.cam, a.bt, cx, cy, cz);
+      }
+    }
+    staged[k] = st;
+  }
+  __syncthreads();
+
+  if (RAY) {
+    // Out-of-map points (a minority) need the fp64 slab clip, ~10x the work of an in-map point:
+    // their positions in the chunk are compacted so that the clip runs on dense lanes.
+    for (uint32_t k = tid; k < a.chunk; k += kPartThreads) {   // chunk % kPartThreads == 0: uniform trip count
+      const bool o = staged[k] == kStagedOutside;
+      const unsigned long long bm = __ballot(o);
+      if (bm) {
+        unsigned wbase = 0;
+        if (lane == 0) wbase = atomicAdd(&s_nout, (unsigned)__popcll(bm));
+        wbase = (unsigned)__builtin_amdgcn_readfirstlane((int)wbase);
+        if (o) outl[wbase + (unsigned)__popcll(bm & ((1ull << lane) - 1ull))] = (unsigned short)k;
+      }
+    }
+    __syncthreads();
+    const unsigned nout = s_nout;
+    for (unsigned j = tid; j < nout; j += kPartThreads) {
+      const unsigned k = outl[j];
+      const uint32_t i = base + k;
+      float bx, by, bz;
+      xform34(a.m_base, a.x[i], a.y[i], a.z[i], bx, by, bz);
+      int ex, ey;
+      clip_ray_end(a.g, a.org, (double)bx, (double)by, ex, ey);
+      const unsigned tile = (unsigned)((ey >> kBinTileLog) * a.tiles_x + (ex >> kBinTileLog));
+      staged[k] = (tile << 16) | kKeyClip | (unsigned)(((ey & (kBinTile - 1)) << kBinTileLog) | (ex & (kBinTile - 1)));
+      atomicAdd(&hist[tile], 1u);
+    }
+    __syncthreads();
+  }
+
+  // exclusive prefix over the tile counts: thread owns the tiles [tid*per, tid*per + per)
+  const int per = (T + kPartThreads - 1) / kPartThreads;
+  const int t0 = tid * per, t1 = min(T, t0 + per);
+  unsigned mine = 0;
+  for (int t = t0; t < t1; ++t) mine += hist[t];
+  const unsigned incl = wave_incl_scan_add(mine);
+  if (lane == 63) s_wsum[wave] = incl;
+  __syncthreads();
+  unsigned run = incl - mine, total = 0;
+#pragma unroll
+  for (int wv = 0; wv < kPartThreads / 64; ++wv) {
+    const unsigned s = s_wsum[wv];
+    if (wv < wave) run += s;
+    total += s;
+  }
+  unsigned short *row = a.tab + (size_t)w * (size_t)(T + 1);
+  for (int t = t0; t < t1; ++t) {
+    const unsigned c = hist[t];
+    row[t] = (unsigned short)run;
+    hist[t] = run;   // placement cursor
+    if (c) atomicAdd(&a.tile_total[t], c);   // no-return; 256 B contiguous per wavefront when per == 1
+    run += c;
+  }
+  if (tid == 0) row[T] = (unsigned short)total;
+  __syncthreads();
+
+  for (uint32_t k = tid; k < a.chunk; k += kPartThreads) {
+    const unsigned st = staged[k];
+    if (st < kStagedOutside) sorted[atomicAdd(&hist[st >> 16], 1u)] = (unsigned short)(st & 0xFFFFu);
+  }
+  __syncthreads();
+  // one contiguous run per workgroup (base of the chunk's key region is 4-byte aligned: chunk is even)
+  const unsigned *src = reinterpret_cast<const unsigned *>(sorted);
+  unsigned *dst = reinterpret_cast<unsigned *>(a.keys + (size_t)w * a.chunk);
+  for (unsigned j = tid; j < (total + 1) / 2; j += kPartThreads) dst[j] = src[j];
+}
+
+// ------------------------------------------------------------------ tiles -----
+__device__ __forceinline__ unsigned bin_splits(unsigned n, unsigned split_keys)
+{
+  const unsigned k = (n + split_keys - 1) / split_keys;
+  return k < 1u ? 1u : (k > (unsigned)kBinSplitMax ? (unsigned)kBinSplitMax : k);
+}
+
+template <bool WRITE_HITS>
+__global__ void __launch_bounds__(kTileThreads) k_bin_tiles(BinTileArgs a)
+{
+  __shared__ unsigned hist[kBinTileCells];           // 64 KB
+  __shared__ unsigned bits[2][kBinTile][4];          // [0] hit, [1] clipped end: bit x of row y
+  __shared__ unsigned seg[kSegBatch];                // start | end << 16 of a chunk's segment
+  __shared__ unsigned s_scanh[kTileThreads / 64], s_scane[kTileThreads / 64];
+  __shared__ int s_t, s_sp, s_slot;
+  __shared__ unsigned s_ticket;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int T = a.n_tiles;
+  const bool primary = (int)blockIdx.x < T;
+  int t = primary ? (int)blockIdx.x : -1, sp = 0, slot = 0;
+  unsigned k = 1;
+  if (primary) {
+    k = bin_splits(a.tile_total[t], a.split_keys);
+    if (tid == 0) a.tile_total_next[t] = 0;   // the next frame's partition adds into it
+  }
+  if (!primary || k > 1) {
+    // Every workgroup of a shared tile derives the same (slot, share) from the tile totals: slot =
+    // number of shared tiles before t, helper j serves the tile whose run of extra shares holds j.
+    if (tid == 0) { s_t = -1; s_sp = 0; s_slot = 0; }
+    const int per = (T + kTileThreads - 1) / kTileThreads;
+    const int q0 = tid * per, q1 = min(T, q0 + per);
+    unsigned hv = 0, ex = 0;
+    for (int q = q0; q < q1; ++q) {
+      const unsigned kq = bin_splits(a.tile_total[q], a.split_keys);
+      hv += (kq > 1u);
+      ex += kq - 1u;
+    }
+    const unsigned ih = wave_incl_scan_add(hv), ie = wave_incl_scan_add(ex);
+    if (lane == 63) { s_scanh[wave] = ih; s_scane[wave] = ie; }
+    __syncthreads();
+    unsigned bh = ih - hv, be = ie - ex;
+    for (int wv = 0; wv < wave; ++wv) { bh += s_scanh[wv]; be += s_scane[wv]; }
+    const unsigned j = primary ? 0u : (unsigned)((int)blockIdx.x - T);
+    for (int q = q0; q < q1; ++q) {
+      const unsigned kq = bin_splits(a.tile_total[q], a.split_keys);
+      if (primary) {
+        if (q == t) s_slot = (int)bh;
+      } else if (kq > 1u && j >= be && j < be + (kq - 1u)) {
+        s_t = q;
+        s_sp = 1 + (int)(j - be);
+        s_slot = (int)bh;
+      }
+      bh += (kq > 1u);
+      be += kq - 1u;
+    }
+    __syncthreads();
+    slot = s_slot;
+    if (!primary) {
+      t = s_t;
+      sp = s_sp;
+      if (t < 0) return;   // more helpers than extra shares this frame
+      k = bin_splits(a.tile_total[t], a.split_keys);
+    }
+    if (slot >= (int)a.max_slots) {   // cannot happen while max_slots > n / split_keys; keeps the scratch in bounds
+      if (!primary) return;
+      k = 1;
+    }
+  }
+
+  for (int c = tid; c < kBinTileCells; c += kTileThreads) hist[c] = 0;
+  if (tid < 2 * kBinTile * 4) (&bits[0][0][0])[tid] = 0;
+  // ---- gather: this share takes the chunks sp, sp + k, sp + 2k, ...
+  const uint32_t nshare = (a.n_wg > (uint32_t)sp) ? (a.n_wg - (uint32_t)sp + k - 1) / k : 0u;
+  const int grp = tid >> 4, l16 = tid & 15;
+  const size_t rowlen = (size_t)T + 1;
+  for (uint32_t b0 = 0; b0 < nshare; b0 += kSegBatch) {
+    __syncthreads();   // hist/bits zeroed; previous batch consumed
+    const uint32_t nb = min((uint32_t)kSegBatch, nshare - b0);
+    for (uint32_t q = tid; q < nb; q += kTileThreads) {
+      const unsigned short *row = a.tab + (size_t)((uint32_t)sp + (b0 + q) * k) * rowlen;
+      seg[q] = (unsigned)row[t] | ((unsigned)row[t + 1] << 16);
+    }
+    __syncthreads();
+    // 16 lanes per segment, four segments in flight per group
+    for (uint32_t q = grp; q < nb; q += 4 * (kTileThreads / 16)) {
+      unsigned key[4];
+      unsigned sg[4];
+      const unsigned short *kp[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const uint32_t qq = q + u * (kTileThreads / 16);
+        sg[u] = (qq < nb) ? seg[qq] : 0u;
+        kp[u] = a.keys + (size_t)((uint32_t)sp + (b0 + qq) * k) * a.chunk;
+        const unsigned s = sg[u] & 0xFFFFu, e = sg[u] >> 16;
+        key[u] = (s + l16 < e) ? (unsigned)kp[u][s + l16] : 0xFFFFu;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const unsigned s = sg[u] & 0xFFFFu, e = sg[u] >> 16;
+        unsigned kk = key[u];
+        for (unsigned jj = s + l16;;) {
+          if (kk != 0xFFFFu) {
+            const unsigned local = kk & (kBinTileCells - 1);
+            if (kk & kKeyClip) atomicOr(&bits[1][local >> kBinTileLog][(local & (kBinTile - 1)) >> 5], 1u << (local & 31u));
+            else atomicAdd(&hist[local], 1u);
+          }
+          jj += 16;
+          if (jj >= e) break;
+          kk = kp[u][jj];
+        }
+      }
+    }
+  }
+  __syncthreads();
+
+  if (k > 1) {
+    // partial tile -> scratch slab; the last of the k shares to arrive sums them
+    const size_t stride = (size_t)kBinTileCells + 512;
+    unsigned *slab = a.scratch + (size_t)slot * kBinSplitMax * stride;
+    unsigned *dst = slab + (size_t)sp * stride;
+    for (int c = tid; c < kBinTileCells / 4; c += kTileThreads)
+      reinterpret_cast<uint4 *>(dst)[c] = reinterpret_cast<const uint4 *>(hist)[c];
+    if (tid < 512) dst[kBinTileCells + tid] = (&bits[1][0][0])[tid];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const unsigned ticket = __hip_atomic_fetch_add(&a.done[t], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (ticket == k - 1u) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(&a.done[t], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next frame
+      }
+      s_ticket = ticket;
+    }
+    __syncthreads();
+    if (s_ticket != k - 1u) return;
+    for (int c = tid; c < kBinTileCells / 4; c += kTileThreads) {
+      uint4 v = make_uint4(0, 0, 0, 0);
+      for (unsigned q = 0; q < k; ++q) {
+        const uint4 p = reinterpret_cast<const uint4 *>(slab + (size_t)q * stride)[c];
+        v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
+      }
+      reinterpret_cast<uint4 *>(hist)[c] = v;
+    }
+    if (tid < 512) {
+      unsigned v = 0;
+      for (unsigned q = 0; q < k; ++q) v |= slab[(size_t)q * stride + kBinTileCells + tid];
+      (&bits[1][0][0])[tid] = v;
+    }
+    __syncthreads();
+  }
+
+  // ---- write-out: the tile of hits[] (plain coalesced stores) and the hit bits of every row
+  const int x0 = (t % a.tiles_x) << kBinTileLog, y0 = (t / a.tiles_x) << kBinTileLog;
+#pragma unroll 4
+  for (int it = 0; it < kBinTileCells / kTileThreads; ++it) {
+    const int c = it * kTileThreads + tid;
+    const int ly = c >> kBinTileLog, lx = c & (kBinTile - 1);
+    const unsigned v = hist[c];
+    if (WRITE_HITS) {
+      const int x = x0 + lx, y = y0 + ly;
+      if (x < a.nx && y < a.ny) a.hits[(size_t)y * a.nx + x] = (int32_t)v;
+    }
+    const unsigned long long m = __ballot(v > 0u);
+    if (lane == 0) {
+      bits[0][ly][(lx >> 5) + 0] = (unsigned)m;
+      bits[0][ly][(lx >> 5) + 1] = (unsigned)(m >> 32);
+    }
+  }
+  __syncthreads();
+  // end bitmaps, 32-bit words stored transposed (gv_raysector.hip):
+  //   N: bits run along x, word(x>>5, y) at (x>>5)*ny_pad + y;  T: bits run along y, word(y>>5, x) at (y>>5)*nx_pad + x
+  {
+    const int which = tid >> 9, wq = (tid >> 7) & 3, l = tid & (kBinTile - 1);
+    {
+      const int gw = (x0 >> 5) + wq, gy = y0 + l;
+      unsigned *dN = which ? a.clipN : a.hitN;
+      if (gw < a.nxw && gy < a.ny_pad) dN[(size_t)gw * a.ny_pad + gy] = bits[which][l][wq];
+    }
+    {
+      unsigned wv = 0;
+#pragma unroll
+      for (int r = 0; r < 32; ++r) wv |= ((bits[which][32 * wq + r][l >> 5] >> (l & 31)) & 1u) << r;
+      const int gw = (y0 >> 5) + wq, gx = x0 + l;
+      unsigned *dT = which ? a.clipT : a.hitT;
+      if (gw < a.nyw && gx < a.nx_pad) dT[(size_t)gw * a.nx_pad + gx] = wv;
+    }
+  }
+}
+
+// ---------------------------------------------------------------- launch -----
+uint32_t bin_chunk_for(size_t n)
+{
+  // ~500..1500 partition workgroups: enough of them to fill 256 CUs several times over, few enough
+  // that a tile's gather (one segment descriptor per chunk) stays short
+  uint32_t chunk = 2048;
+  while ((n + chunk - 1) / chunk > 1536 && chunk < 8192) chunk *= 2;
+  return chunk;
+}
+
+size_t bin_partition_lds(uint32_t chunk, int n_tiles) { return (size_t)chunk * 4 + (size_t)n_tiles * 4 + (size_t)chunk * 2; }
+
+void launch_bin_partition(const BinArgs &a, hipStream_t s)
+{
+  if (a.n_wg == 0) return;
+  const size_t lds = bin_partition_lds(a.chunk, a.n_tiles);
+  const bool keep = a.cell_idx != nullptr;
+#define GV_BP(R, X, K) hipLaunchKernelGGL((k_bin_partition<R, X, K>), dim3(a.n_wg), dim3(kPartThreads), lds, s, a)
+  if (a.do_ray && a.do_bbox && keep) GV_BP(true, true, true);
+  else if (a.do_ray && a.do_bbox) GV_BP(true, true, false);
+  else if (a.do_ray && keep) GV_BP(true, false, true);
+  else if (a.do_ray) GV_BP(true, false, false);
+  else if (a.do_bbox && keep) GV_BP(false, true, true);
+  else if (a.do_bbox) GV_BP(false, true, false);
+  else if (keep) GV_BP(false, false, true);
+  else GV_BP(false, false, false);
+#undef GV_BP
+}
+
+void launch_bin_tiles(const BinTileArgs &a, uint32_t n_helpers, hipStream_t s)
+{
+  const uint32_t grid = (uint32_t)a.n_tiles + n_helpers;
+  if (a.hits) hipLaunchKernelGGL(k_bin_tiles<true>, dim3(grid), dim3(kTileThreads), 0, s, a);
+  else hipLaunchKernelGGL(k_bin_tiles<false>, dim3(grid), dim3(kTileThreads), 0, s, a);
+}
+
+}  // namespace gv

@@ -7,148 +7,35 @@
 //
 // Reference lines are cited as file:line relative to the reference root.
 #include "gv_kernels.hpp"
-
-#include <float.h>
-#include <math.h>
+#include "gv_device.hpp"
 
 #include <algorithm>
 #include <cstdlib>
 
 namespace gv {
 
-// ---------------------------------------------------------------- helpers --
-
-// pcl::detail::Transformer<float>::se3 (SSE2 path): x*c0 + (y*c1 + (z*c2 + c3)),
-// fp32, no FMA.  Call site: src/grid_vision_node.cpp:304.
-__device__ __forceinline__ void xform34(const Mat34f &m, float px, float py, float pz, float &ox,
-                                        float &oy, float &oz)
-{
-  ox = __fadd_rn(__fmul_rn(px, m.m[0]), __fadd_rn(__fmul_rn(py, m.m[1]), __fadd_rn(__fmul_rn(pz, m.m[2]), m.m[3])));
-  oy = __fadd_rn(__fmul_rn(px, m.m[4]), __fadd_rn(__fmul_rn(py, m.m[5]), __fadd_rn(__fmul_rn(pz, m.m[6]), m.m[7])));
-  oz = __fadd_rn(__fmul_rn(px, m.m[8]), __fadd_rn(__fmul_rn(py, m.m[9]), __fadd_rn(__fmul_rn(pz, m.m[10]), m.m[11])));
-}
-
-// grid_map::GridMap::getIndex (called at src/occupancy_grid.cpp:152):
-//   indexVector = (position - 0.5*length - mapPosition) / resolution, index = (int)(-indexVector)
-//   inside iff t = -(position - mapPosition - 0.5*length), 0 <= t < length
-__device__ __forceinline__ bool get_index(const GridParams &g, double x, double y, int &ix, int &iy)
-{
-  const double tx = -((x - g.pos_x) - g.off_x);
-  const double ty = -((y - g.pos_y) - g.off_y);
-  if (!(tx >= 0.0 && ty >= 0.0 && tx < g.len_x && ty < g.len_y)) return false;  // NaN/inf land here
-  const double vx = ((x - g.off_x) - g.pos_x) / g.res;
-  const double vy = ((y - g.off_y) - g.pos_y) / g.res;
-  const int jx = (int)(-vx);
-  const int jy = (int)(-vy);
-  if (jx < 0 || jy < 0 || jx >= g.nx || jy >= g.ny) return false;
-  ix = jx;
-  iy = jy;
-  return true;
-}
-
-// Same result as get_index without the two fp64 divisions (the points pass is bound by fp64
-// issue, a division is ~15 dependent fp64 ops): (int)(-(d / res)) only depends on which side
-// of an integer the correctly rounded quotient lies.  q' = (-d) * fl(1/res) is within 3 roundings
-// (< 1e-11 absolute for |q| < 2^14) of that quotient, so whenever q' is further than 1e-6 from
-// every integer both truncate to the same cell; otherwise the exact division decides.
-__device__ __forceinline__ bool get_index_fast(const GridParams &g, double x, double y, int &ix, int &iy)
-{
-  const double tx = -((x - g.pos_x) - g.off_x);
-  const double ty = -((y - g.pos_y) - g.off_y);
-  if (!(tx >= 0.0 && ty >= 0.0 && tx < g.len_x && ty < g.len_y)) return false;  // NaN/inf land here
-  const double dx = (x - g.off_x) - g.pos_x;
-  const double dy = (y - g.off_y) - g.pos_y;
-  double qx = -dx * g.inv_res;
-  double qy = -dy * g.inv_res;
-  if (fabs(qx - rint(qx)) < 1e-6) qx = -(dx / g.res);
-  if (fabs(qy - rint(qy)) < 1e-6) qy = -(dy / g.res);
-  const int jx = (int)qx;
-  const int jy = (int)qy;
-  if (jx < 0 || jy < 0 || jx >= g.nx || jy >= g.ny) return false;
-  ix = jx;
-  iy = jy;
-  return true;
-}
-
-// (float)(n / d) for finite n, d without the division: r ~ 1/d by v_rcp_f64 + two Newton steps
-// (<= 1 ulp), q' = n * r is within a few ulp64 of the correctly rounded quotient, and both round
-// to the same float unless q' sits within 2^-45 (relative) of a float rounding boundary, i.e. its
-// 29 discarded mantissa bits are within 128 of the midpoint pattern; then the exact division
-// decides.  Non-finite or subnormal-float results take the exact path too.
-__device__ __forceinline__ double rcp_newton(double d)
-{
-  double r = __builtin_amdgcn_rcp(d);
-  r = fma(fma(-d, r, 1.0), r, r);
-  r = fma(fma(-d, r, 1.0), r, r);
-  return r;
-}
-__device__ __forceinline__ float div_to_float(double n, double d, double r)
-{
-  const double q = n * r;
-  const unsigned long long bits = (unsigned long long)__double_as_longlong(q);
-  const unsigned low = (unsigned)bits & 0x1FFFFFFFu;
-  const unsigned ex = (unsigned)(bits >> 52) & 0x7FFu;
-  const bool risky = (low - (0x10000000u - 128u)) <= 256u || ex < 1023u - 120u || ex > 1023u + 120u;
-  return risky ? (float)(n / d) : (float)q;
-}
-
-// [EXTENSION] X2 ray end of an out-of-map point: fp64 slab clip of
-// origin + t*(p - origin) against the map rectangle, then the clamped floor cell.
-__device__ __forceinline__ void clip_ray_end(const GridParams &g, const RayOrigin &o, double px, double py,
-                                             int &ex, int &ey)
-{
-  const double hix = g.pos_x + g.off_x, hiy = g.pos_y + g.off_y;
-  const double lox = hix - g.len_x, loy = hiy - g.len_y;
-  const double dx = px - o.ox, dy = py - o.oy;
-  double t = 1.0;
-  if (dx > 0.0) { const double tx = (hix - o.ox) / dx; if (tx < t) t = tx; }
-  if (dx < 0.0) { const double tx = (lox - o.ox) / dx; if (tx < t) t = tx; }
-  if (dy > 0.0) { const double ty = (hiy - o.oy) / dy; if (ty < t) t = ty; }
-  if (dy < 0.0) { const double ty = (loy - o.oy) / dy; if (ty < t) t = ty; }
-  if (t < 0.0) t = 0.0;
-  const double qx = o.ox + t * dx;
-  const double qy = o.oy + t * dy;
-  double fx = floor(-(((qx - g.off_x) - g.pos_x) / g.res));
-  double fy = floor(-(((qy - g.off_y) - g.pos_y) / g.res));
-  if (!(fx >= 0.0)) fx = 0.0;
-  if (!(fy >= 0.0)) fy = 0.0;
-  if (fx > (double)(g.nx - 1)) fx = (double)(g.nx - 1);
-  if (fy > (double)(g.ny - 1)) fy = (double)(g.ny - 1);
-  ex = (int)fx;
-  ey = (int)fy;
-}
-
-// Eigen Matrix3d * Vector3d, coefficient r: (K(r,0)*x + K(r,1)*y) + K(r,2)*z
-__device__ __forceinline__ double krow(const double *k, int r, double x, double y, double z)
-{
-  return (k[r * 3 + 0] * x + k[r * 3 + 1] * y) + k[r * 3 + 2] * z;
-}
-
 // ------------------------------------------------------------ points pass --
+// Generic points pass (any grid shape; also the bbox-only calls of the reference surface).
+// The tile path of the production frame bins through gv_binning.hip instead.
 // One pass over the resident SoA cloud (12 B/point read):
 //   X1  base<-lidar transform, getIndex, hits[cell] += 1
 //   X2  ray end of out-of-map points (clip_end[cell] = 1)
 //   A1+A5 camera<-lidar transform, pinhole projection, first-match bbox id
 //       (src/cloud_detections.cpp:250-298)
-// Hit marking (COUNTS == false, the production frame): the X2 update rule only asks
-// "hits > 0", so a point stores the byte 1 into hit8[cell] -- an idempotent plain store,
-// no atomics; every writer stores the same value, the L2s merge byte-masked lines.
-// Hit counting (COUNTS == true, GV_FRAME_KEEP_COUNTS / generic path): points of one
-// workgroup that fall into the same cell (the cells next to the sensor collect hundreds of
-// hits per frame) are combined in an LDS direct-mapped cache (cell -> count) and flushed
-// with ONE global atomicAdd per cached cell; a cell that loses its slot to another cell
-// goes straight to the global atomic.  Integer adds: the grid is the same whatever the
-// interleaving.
+// Hit counting: points of one workgroup that fall into the same cell (the cells next to the
+// sensor collect hundreds of hits per frame) are combined in an LDS direct-mapped cache
+// (cell -> count) and flushed with ONE global atomicAdd per cached cell; a cell that loses its
+// slot to another cell goes straight to the global atomic.  Integer adds: the grid is the same
+// whatever the interleaving.
 constexpr int kHitSlots = 4096;
 constexpr unsigned kHitEmpty = 0xFFFFFFFFu;
 
-template <bool BIN, bool RAY, bool BBOX, bool KEEPCELL, bool COUNTS>
-__global__ void __launch_bounds__(COUNTS ? 1024 : 256) k_points(PointsArgs a)
+template <bool BIN, bool RAY, bool BBOX, bool KEEPCELL>
+__global__ void __launch_bounds__(BIN ? 1024 : 256) k_points(PointsArgs a)
 {
-  constexpr bool CACHE = BIN && COUNTS;
-  __shared__ unsigned s_key[CACHE ? kHitSlots : 1];
-  __shared__ unsigned s_cnt[CACHE ? kHitSlots : 1];
-  if (CACHE) {
+  __shared__ unsigned s_key[BIN ? kHitSlots : 1];
+  __shared__ unsigned s_cnt[BIN ? kHitSlots : 1];
+  if (BIN) {
     for (int k = threadIdx.x; k < kHitSlots; k += blockDim.x) { s_key[k] = kHitEmpty; s_cnt[k] = 0; }
     __syncthreads();
   }
@@ -156,9 +43,10 @@ __global__ void __launch_bounds__(COUNTS ? 1024 : 256) k_points(PointsArgs a)
   // are compacted through LDS so that the clip runs on dense lanes of as few wavefronts as
   // possible instead of on a few lanes of every wavefront.
   constexpr bool CLIP = BIN && RAY;
-  constexpr int kMaxThreads = COUNTS ? 1024 : 256;
+  constexpr int kMaxThreads = BIN ? 1024 : 256;
   __shared__ float2 s_out[CLIP ? kMaxThreads : 1];
   __shared__ unsigned s_nout;
+  const BBoxTest bt = a.bt;
   const uint32_t stride = gridDim.x * blockDim.x;
   for (uint32_t base = blockIdx.x * blockDim.x; base < a.n; base += stride) {   // uniform per workgroup
     const uint32_t i = base + threadIdx.x;
@@ -176,16 +64,12 @@ __global__ void __launch_bounds__(COUNTS ? 1024 : 256) k_points(PointsArgs a)
       bool outside = false;
       if (live && isfinite(bx) && isfinite(by) && isfinite(bz)) {
         int ix, iy;
-        if ((a.ablate & 32) ? false : get_index_fast(a.g, (double)bx, (double)by, ix, iy)) {
+        if (get_index_fast(a.g, (double)bx, (double)by, ix, iy)) {
           cell = iy * a.g.nx + ix;
-          if (COUNTS) {
-            const unsigned slot = ((unsigned)cell * 2654435761u) >> 20;   // 12 bits
-            const unsigned old = atomicCAS(&s_key[slot], kHitEmpty, (unsigned)cell);
-            if (old == kHitEmpty || old == (unsigned)cell) atomicAdd(&s_cnt[slot], 1u);
-            else atomicAdd(&a.hits[cell], 1);   // no-return global_atomic_add
-          } else {
-            if (!(a.ablate & 1)) a.hit8[cell] = 1;   // idempotent byte store
-          }
+          const unsigned slot = ((unsigned)cell * 2654435761u) >> 20;   // 12 bits
+          const unsigned old = atomicCAS(&s_key[slot], kHitEmpty, (unsigned)cell);
+          if (old == kHitEmpty || old == (unsigned)cell) atomicAdd(&s_cnt[slot], 1u);
+          else atomicAdd(&a.hits[cell], 1);   // no-return global_atomic_add
         } else if (RAY && a.org.valid) {
           outside = true;
         }
@@ -205,40 +89,11 @@ __global__ void __launch_bounds__(COUNTS ? 1024 : 256) k_points(PointsArgs a)
     if (BBOX) {
       float cx, cy, cz;
       xform34(a.m_cam, px, py, pz, cx, cy, cz);
-      int id = -1;
-      // :264 pcl::isFinite(pt) && pt.z > 0.001f
-      if (live && isfinite(cx) && isfinite(cy) && isfinite(cz) && !(cz <= 0.001f) && !(a.ablate & 16)) {
-        const double X = (double)cx, Y = (double)cy, Z = (double)cz;
-        const double iz = krow(a.cam.k, 2, X, Y, Z);
-        const double riz = rcp_newton(iz);
-        const float u = div_to_float(krow(a.cam.k, 0, X, Y, Z), iz, riz);   // :268-272  (float)(n / iz)
-        const float v = div_to_float(krow(a.cam.k, 1, X, Y, Z), iz, riz);   // :273
-        if (!(u < 0 || u >= (float)a.cam.W || v < 0 || v >= (float)a.cam.H) && !(a.ablate & 4)) {   // :276
-          // :280-288 first match wins.  The reference compares (double)u against the
-          // double bounds; bbox_f holds the float thresholds with the identical truth
-          // table (host: smallest float >= x_min, largest float <= x_max), and the
-          // tile masks only prune boxes that cannot contain this pixel, in index order.
-          const int tx = (int)u >> 4, ty = (int)v >> 4;
-          const unsigned long long *tm = a.tile_mask + ((size_t)ty * a.tiles_x + tx) * a.mask_words;
-          for (int wd = 0; wd < a.mask_words && id < 0; ++wd) {
-            unsigned long long m = tm[wd];
-            while (m) {
-              const int b = wd * 64 + (__ffsll((long long)m) - 1);
-              m &= m - 1;
-              const float4 f = a.bbox_f[b];
-              if (u >= f.x && u <= f.z && v >= f.y && v <= f.w) {
-                id = b;
-                break;
-              }
-            }
-          }
-        }
-      }
-      if (live && !(a.ablate & 2)) a.bbox_id[i] = id;
+      if (live) a.bbox_id[i] = (int16_t)first_bbox(a.cam, bt, cx, cy, cz);
     }
     if (CLIP) {
       __syncthreads();
-      const unsigned nout = (a.ablate & 8) ? 0u : s_nout;
+      const unsigned nout = s_nout;
       for (unsigned k = threadIdx.x; k < nout; k += blockDim.x) {
         const float2 p = s_out[k];
         int ex, ey;
@@ -248,7 +103,7 @@ __global__ void __launch_bounds__(COUNTS ? 1024 : 256) k_points(PointsArgs a)
       __syncthreads();   // the list is reused by the next chunk
     }
   }
-  if (CACHE) {
+  if (BIN) {
     __syncthreads();
     for (int k = threadIdx.x; k < kHitSlots; k += blockDim.x) {
       const unsigned key = s_key[k];
@@ -257,33 +112,71 @@ __global__ void __launch_bounds__(COUNTS ? 1024 : 256) k_points(PointsArgs a)
   }
 }
 
-void launch_points(const PointsArgs &a_in, hipStream_t s)
+void launch_points(const PointsArgs &a, hipStream_t s)
 {
-  if (a_in.n == 0) return;
-  PointsArgs a = a_in;
-  { static const int ab = [] { const char *e = std::getenv("GV_POINTS_ABLATE"); return e ? std::atoi(e) : 0; }(); a.ablate = ab; }
-  // counting: 8192 points per 1024-thread workgroup (measured best of 2k..16k) so that the LDS hit cache sees the
-  // duplicates of the hot cells; byte marking / bbox-only: plain streaming configuration
-  const bool cache = a.do_bin && a.counts;
-  const uint32_t threads = cache ? 1024u : 256u;
-  static const uint32_t chunk = [] { const char *e = std::getenv("GV_POINTS_CHUNK"); return (uint32_t)(e ? std::max(1024, std::atoi(e)) : 8192); }();
-  static const uint32_t ppt = [] { const char *e = std::getenv("GV_POINTS_PPT"); return (uint32_t)(e ? std::max(1, std::atoi(e)) : 1); }();
-  const uint32_t blocks = cache ? (uint32_t)std::min<uint64_t>(((uint64_t)a.n + chunk - 1) / chunk, (uint64_t)2048)
-                                : (uint32_t)std::min<uint64_t>(((uint64_t)a.n + 256 * ppt - 1) / (256 * ppt), (uint64_t)1 << 20);
+  if (a.n == 0) return;
+  // counting: 8192 points per 1024-thread workgroup (measured best of 2k..16k) so that the LDS hit cache
+  // sees the duplicates of the hot cells; bbox-only: plain streaming configuration
+  const uint32_t threads = a.do_bin ? 1024u : 256u;
+  const uint32_t blocks = a.do_bin ? (uint32_t)std::min<uint64_t>(((uint64_t)a.n + 8191) / 8192, (uint64_t)2048)
+                                   : (uint32_t)std::min<uint64_t>(((uint64_t)a.n + 255) / 256, (uint64_t)1 << 20);
   const bool keep = a.cell_idx != nullptr;
-#define GV_LP(B, R, X, K, C) hipLaunchKernelGGL((k_points<B, R, X, K, C>), dim3(blocks), dim3(threads), 0, s, a)
-#define GV_LPC(B, R, X, K) do { if (a.counts) GV_LP(B, R, X, K, true); else GV_LP(B, R, X, K, false); } while (0)
-  if (a.do_bin && a.do_ray && a.do_bbox && keep) GV_LPC(true, true, true, true);
-  else if (a.do_bin && a.do_ray && a.do_bbox) GV_LPC(true, true, true, false);
-  else if (a.do_bin && a.do_ray && keep) GV_LPC(true, true, false, true);
-  else if (a.do_bin && a.do_ray) GV_LPC(true, true, false, false);
-  else if (a.do_bin && a.do_bbox && keep) GV_LPC(true, false, true, true);
-  else if (a.do_bin && a.do_bbox) GV_LPC(true, false, true, false);
-  else if (a.do_bin && keep) GV_LPC(true, false, false, true);
-  else if (a.do_bin) GV_LPC(true, false, false, false);
-  else if (a.do_bbox) GV_LP(false, false, true, false, false);
-#undef GV_LPC
+#define GV_LP(B, R, X, K) hipLaunchKernelGGL((k_points<B, R, X, K>), dim3(blocks), dim3(threads), 0, s, a)
+  if (a.do_bin && a.do_ray && a.do_bbox && keep) GV_LP(true, true, true, true);
+  else if (a.do_bin && a.do_ray && a.do_bbox) GV_LP(true, true, true, false);
+  else if (a.do_bin && a.do_ray && keep) GV_LP(true, true, false, true);
+  else if (a.do_bin && a.do_ray) GV_LP(true, true, false, false);
+  else if (a.do_bin && a.do_bbox && keep) GV_LP(true, false, true, true);
+  else if (a.do_bin && a.do_bbox) GV_LP(true, false, true, false);
+  else if (a.do_bin && keep) GV_LP(true, false, false, true);
+  else if (a.do_bin) GV_LP(true, false, false, false);
+  else if (a.do_bbox) GV_LP(false, false, true, false);
 #undef GV_LP
+}
+
+// Exact fp32 form of the first-match bbox test, built on the device from the uploaded gv_bbox
+// array: (double)u >= x_min <=> u >= (smallest float >= x_min), (double)u <= x_max <=> u <= (largest
+// float <= x_max) for every float u (NaN bounds stay NaN: always false), and per 16x16-pixel tile the
+// mask of boxes whose float range can contain a pixel of that tile (a superset is enough: the mask
+// only prunes).  One thread per (tile, 64-box word); the first nb threads also store the thresholds.
+__global__ void __launch_bounds__(256) k_bbox_prepare(const gv_bbox *__restrict__ bb, int32_t nb, int32_t tiles_x,
+                                                      int32_t tiles_y, int32_t mask_words, float4 *__restrict__ bbox_f,
+                                                      unsigned long long *__restrict__ tile_mask)
+{
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid < nb) {
+    const gv_bbox b = bb[gid];
+    bbox_f[gid] = make_float4(__double2float_ru(b.x_min), __double2float_ru(b.y_min), __double2float_rd(b.x_max),
+                              __double2float_rd(b.y_max));
+  }
+  const int nwords = tiles_x * tiles_y * mask_words;
+  if (gid >= nwords) return;
+  const int wd = gid % mask_words, tile = gid / mask_words;
+  const int tx = tile % tiles_x, ty = tile / tiles_x;
+  unsigned long long m = 0ull;
+  const int b1 = min(nb, 64 * wd + 64);
+  for (int i = 64 * wd; i < b1; ++i) {
+    const gv_bbox b = bb[i];
+    const float fx = __double2float_ru(b.x_min), fy = __double2float_ru(b.y_min);
+    const float fz = __double2float_rd(b.x_max), fw = __double2float_rd(b.y_max);
+    if (!(fx <= fz && fy <= fw)) continue;   // empty or NaN box never matches
+    // tiles whose pixel range [16t, 16t+16) can contain a u in [fx, fz]
+    int tx0 = (int)floorf(fmaxf(fx, 0.0f) / 16.0f), tx1 = (int)floorf(fminf(fz, 16.0f * tiles_x - 1.0f) / 16.0f);
+    int ty0 = (int)floorf(fmaxf(fy, 0.0f) / 16.0f), ty1 = (int)floorf(fminf(fw, 16.0f * tiles_y - 1.0f) / 16.0f);
+    tx0 = max(tx0, 0); ty0 = max(ty0, 0);
+    tx1 = min(tx1, tiles_x - 1); ty1 = min(ty1, tiles_y - 1);
+    if (tx >= tx0 && tx <= tx1 && ty >= ty0 && ty <= ty1) m |= 1ull << (i & 63);
+  }
+  tile_mask[gid] = m;
+}
+
+void launch_bbox_prepare(const gv_bbox *bboxes, int32_t nb, int32_t tiles_x, int32_t tiles_y, int32_t mask_words,
+                         float4 *bbox_f, unsigned long long *tile_mask, hipStream_t s)
+{
+  const int n = std::max(nb, tiles_x * tiles_y * mask_words);
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_bbox_prepare, dim3((n + 255) / 256), dim3(256), 0, s, bboxes, nb, tiles_x, tiles_y, mask_words,
+                     bbox_f, tile_mask);
 }
 
 // A1 standalone: camera-frame copy of the cloud (transformLidarToCamera)
@@ -935,6 +828,19 @@ void launch_fill_f32(float *p, float v, size_t n, hipStream_t s)
   if (!n) return;
   const uint32_t blocks = (uint32_t)std::min<size_t>((n + 255) / 256, (size_t)4096);
   hipLaunchKernelGGL(k_fill_f32, dim3(blocks), dim3(256), 0, s, p, v, n);
+}
+
+__global__ void k_i16_to_i32(const int16_t *in, int32_t *out, size_t n)
+{
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += stride) out[i] = (int32_t)in[i];
+}
+
+void launch_i16_to_i32(const int16_t *in, int32_t *out, size_t n, hipStream_t s)
+{
+  if (!n) return;
+  const uint32_t blocks = (uint32_t)std::min<size_t>((n + 255) / 256, (size_t)4096);
+  hipLaunchKernelGGL(k_i16_to_i32, dim3(blocks), dim3(256), 0, s, in, out, n);
 }
 
 __global__ void k_u8_to_i32(const uint8_t *in, int32_t *out, size_t n)

@@ -8,6 +8,14 @@
 
 namespace gv {
 
+// exact fp32 form of the bbox test + per-16x16-pixel-tile candidate masks (built on the device by
+// launch_bbox_prepare from the uploaded gv_bbox array)
+struct BBoxTest {
+  const float4 *bbox_f;                  // (x_min, y_min, x_max, y_max) as float thresholds
+  const unsigned long long *tile_mask;   // [tiles_y][tiles_x][mask_words]
+  int32_t tiles_x, tiles_y, mask_words;
+};
+
 struct PointsArgs {
   const float *x, *y, *z;
   uint32_t n;
@@ -16,21 +24,17 @@ struct PointsArgs {
   Mat34f m_cam;      // camera <- lidar (A1/A5)
   CamK cam;
   RayOrigin org;
-  const gv_bbox *bboxes;
-  int32_t nb;
-  // exact fp32 form of the bbox test + per-16x16-pixel-tile candidate masks (host built)
-  const float4 *bbox_f;          // (x_min, y_min, x_max, y_max) as float thresholds
-  const unsigned long long *tile_mask;   // [tiles_y][tiles_x][mask_words]
-  int32_t tiles_x, tiles_y, mask_words;
-  int32_t *hits;       // G   (counts == true: hits[cell] += 1)
-  uint8_t *hit8;       // G   (counts == false: hit8[cell] = 1, the update rule is binary per cell)
+  BBoxTest bt;
+  int32_t *hits;       // G   hits[cell] += 1
   uint8_t *clip_end;   // G
   int32_t *cell_idx;   // N or null
-  int32_t *bbox_id;    // N or null
-  bool do_bin, do_ray, do_bbox, counts;
-  int32_t ablate;      // timing experiments only (GV_POINTS_ABLATE)
+  int16_t *bbox_id;    // N or null
+  bool do_bin, do_ray, do_bbox;
 };
 void launch_points(const PointsArgs &a, hipStream_t s);
+// float thresholds + 16x16-pixel tile candidate masks of the bbox test, from the device copy of the bboxes
+void launch_bbox_prepare(const gv_bbox *bboxes, int32_t nb, int32_t tiles_x, int32_t tiles_y, int32_t mask_words,
+                         float4 *bbox_f, unsigned long long *tile_mask, hipStream_t s);
 
 void launch_transform_cloud(const float *x, const float *y, const float *z, uint32_t n, const Mat34f &m,
                             float *ox, float *oy, float *oz, hipStream_t s);
@@ -72,6 +76,52 @@ void launch_finalize(const FinalizeArgs &a, hipStream_t s);
 
 void launch_fill_f32(float *p, float v, size_t n, hipStream_t s);
 void launch_u8_to_i32(const uint8_t *in, int32_t *out, size_t n, hipStream_t s);
+void launch_i16_to_i32(const int16_t *in, int32_t *out, size_t n, hipStream_t s);
+
+// ---- tile-path binning: partition by 128x128-cell tile + per-tile LDS histogram (gv_binning.hip) ----
+constexpr int kBinTileLog = 7;
+constexpr int kBinTile = 1 << kBinTileLog;             // cells per tile side
+constexpr int kBinTileCells = kBinTile * kBinTile;     // 16384: an int32 tile is 64 KB of LDS
+constexpr int kBinSplitMax = 8;                        // workgroups that may share one crowded tile
+constexpr uint32_t kBinSplitKeys = 32768;              // keys per share of a crowded tile
+
+struct BinArgs {
+  const float *x, *y, *z;
+  uint32_t n;
+  GridParams g;
+  Mat34f m_base, m_cam;
+  CamK cam;
+  RayOrigin org;
+  BBoxTest bt;
+  int16_t *bbox_id;        // N (do_bbox)
+  int32_t *cell_idx;       // N or null
+  bool do_ray, do_bbox;
+  uint32_t chunk;          // points per partition workgroup (multiple of 256, <= 32768)
+  uint32_t n_wg;           // ceil(n / chunk)
+  int32_t tiles_x, tiles_y, n_tiles;
+  uint16_t *keys;          // [n_wg][chunk]  keys of a chunk grouped by tile
+  uint16_t *tab;           // [n_wg][n_tiles + 1]  start of every tile's run inside the chunk; [n_tiles] = count
+  uint32_t *tile_total;    // [n_tiles]  keys per tile over all chunks (zero on entry)
+};
+uint32_t bin_chunk_for(size_t n);
+void launch_bin_partition(const BinArgs &a, hipStream_t s);
+
+struct BinTileArgs {
+  int32_t nx, ny, tiles_x, tiles_y, n_tiles;
+  uint32_t n_wg, chunk;
+  const uint16_t *keys;
+  const uint16_t *tab;
+  const uint32_t *tile_total;   // this frame's totals
+  uint32_t *tile_total_next;    // cleared here for the next frame's partition
+  uint32_t *done;               // [n_tiles] arrival tickets of shared tiles (zero between frames)
+  uint32_t *scratch;            // [max_slots][kBinSplitMax][kBinTileCells + 512] partial tiles
+  uint32_t split_keys, max_slots;
+  int32_t *hits;                // G int32 (every cell written) or null
+  uint32_t *hitN, *clipN, *hitT, *clipT;   // end bitmaps (layout: BitmapArgs), every word written
+  int32_t nxw, nyw, nx_pad, ny_pad;
+};
+// n_helpers >= n / split_keys extra workgroups serve the shares 1.. of crowded tiles
+void launch_bin_tiles(const BinTileArgs &a, uint32_t n_helpers, hipStream_t s);
 
 // ---- sector/gather ray stage + tile grid pass (gv_raysector.hip) ----
 struct BitmapArgs {

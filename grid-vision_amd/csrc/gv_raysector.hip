@@ -209,6 +209,13 @@ __device__ __forceinline__ int ab_a(unsigned p) { return (int)(p >> 14) & 0x1FFF
 __device__ __forceinline__ int ab_b(unsigned p) { return (int)(p >> 1) & 0x1FFF; }
 
 constexpr int kSecThreads = 512;   // 8 wavefronts per sector workgroup
+// Timing experiments (phase ablation, in-kernel clock stamps) exist only in the diagnostic build
+// (-DGV_DIAG, tools/): the production kernel carries none of their branches or stores.
+#ifdef GV_DIAG
+#define GV_ABL(bit) (((A.ablate) & (bit)) != 0)
+#else
+#define GV_ABL(bit) (false)
+#endif
 #ifndef GV_SECTOR_WPE
 #define GV_SECTOR_WPE 4             // min waves per SIMD the register allocator must allow
 #endif
@@ -295,8 +302,9 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
   __shared__ unsigned long long s_wvis[NT / 64];
   __shared__ unsigned s_rowpart[CH][NT / 64];   // multi-group path: ends per (row, wavefront)
 
-  // diagnostic build only (GV_SECTOR_DBG=1): thread 0 stamps the shader clock at phase
-  // boundaries into a debug buffer nothing else reads; A.dbg is null in production
+  // diagnostic build only (-DGV_DIAG with GV_SECTOR_DBG=1): thread 0 stamps the shader clock at
+  // phase boundaries into a debug buffer nothing else reads
+#ifdef GV_DIAG
   int stamp_n = 0;
   auto stamp = [&]() {
     if (A.dbg && tid == 0 && stamp_n < 16) A.dbg[(size_t)wg * 16 + stamp_n] = __builtin_amdgcn_s_memtime();
@@ -304,13 +312,17 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
   };
   stamp();
   if (A.dbg && tid == 0) A.dbg[(size_t)wg * 16 + 14] = ((unsigned long long)o << 32) | (unsigned)s | ((unsigned long long)log2s << 40);
+#else
+  auto stamp = []() {};
+  (void)wg;
+#endif
   for (int i = tid; i <= oc.imax; i += NT) marks[i] = 0;
   if (tid < NT / 64) s_wvis[tid] = 0;
   for (int m = tid; m < M; m += NT) { cnt[m] = 0; bmax32[m] = 0; }
   if (tid == 0) s_nlong = 0;
   __syncthreads();
   stamp();   // 1: init done
-  if (A.ablate & 8) return;    // timing experiment: launch + init only
+  if GV_ABL(8) return;    // timing experiment: launch + init only
 
   const unsigned *bmH = oc.xmaj ? A.hitT : A.hitN;
   const unsigned *bmC = oc.xmaj ? A.clipT : A.clipN;
@@ -459,7 +471,7 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
 #pragma unroll
   for (int wv = 0; wv < NT / 64; ++wv) total += (int)s_wsum[wv];
   stamp();   // 2: scan done
-  if (A.ablate & 16) return;   // timing experiment: + scan
+  if GV_ABL(16) return;   // timing experiment: + scan
   if (total == 0) {
     if (tid == 0 && A.stats) { A.stats[2 * blockIdx.x] = 0; A.stats[2 * blockIdx.x + 1] = 0; }
     return;
@@ -696,7 +708,7 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
         const int lf = __builtin_amdgcn_readlane((int)lmv, f);
         T0 = max(prev, min(hf, lf - 1));
       }
-      if (A.ablate & 64) T0 = 0;
+      if GV_ABL(64) T0 = 0;
     }
     if (lane == 0) { s_T = (unsigned)T0; s_maxreach = maxreach0; }
     }
@@ -704,13 +716,15 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
     const int T = (int)s_T;
     const unsigned maxreach = s_maxreach;
     stamp();   // 7: threshold
+#ifdef GV_DIAG
     if (A.dbg && tid == 0) {
       const unsigned mr = maxreach;
       A.dbg[(size_t)wg * 16 + 12] = ((unsigned long long)T << 48) | ((unsigned long long)mr << 32) | ((unsigned long long)oc.imax << 16) | (unsigned long long)min(n, 65535u);
     }
+#endif
     // long rays (reach > T+1) -> compact list in the (now free) cursor array `cnt`
     bool march_tail = false;
-    if (T < oc.imax && !(A.ablate & 256)) {
+    if (T < oc.imax && !GV_ABL(256)) {
       unsigned st = 0;
       for (unsigned k0 = 0; k0 < n; k0 += NT) {
         const unsigned k = k0 + tid;
@@ -750,9 +764,9 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
           if ((unsigned)A.flat_k * ncells < tail_steps + 32u * nlong) march_tail = false;
         }
       }
-      if (A.dbg && tid == 0) {
-        A.dbg[(size_t)wg * 16 + 13] = ((unsigned long long)tail_steps << 32) | nlong;
-      }
+#ifdef GV_DIAG
+      if (A.dbg && tid == 0) A.dbg[(size_t)wg * 16 + 13] = ((unsigned long long)tail_steps << 32) | nlong;
+#endif
       stamp();   // 8: long rays compacted
       if (march_tail) {
         // one ray per wavefront, lanes over consecutive columns: distinct LDS words
@@ -774,12 +788,14 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
         }
       }
     }
+#ifdef GV_DIAG
     if (A.dbg) __syncthreads();
+#endif
     stamp();   // 9: tail marched (barrier only in the diagnostic build)
     // gather: one lane per column of the wedge
-    const bool flat_tail = !march_tail && T < oc.imax && !(A.ablate & 512);   // columns beyond T, every cell exactly
+    const bool flat_tail = !march_tail && T < oc.imax && !GV_ABL(512);   // columns beyond T, every cell exactly
     const int gather_hi = (march_tail || flat_tail) ? T : oc.imax;
-    for (int i = tid; i <= ((A.ablate & 2) ? -1 : gather_hi); i += NT) {
+    for (int i = tid; i <= (GV_ABL(2) ? -1 : gather_hi); i += NT) {
       if (i == 0) {
         marks[0] |= 1u;   // every ray (reach >= 1) starts in the origin cell
         continue;
@@ -794,8 +810,8 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
       // cell that lies inside the sector's slope range (k = 1..w-2) is traversed.
       // columns up to T have every interior cell free (monotone test, computed once above)
       bool interior_free = (w > 2) && (i <= T);
-      if (A.ablate & 64) interior_free = false;           // timing experiment: always the full loop
-      if ((A.ablate & 128) && !interior_free) continue;   // timing experiment: skip the full loop
+      if GV_ABL(64) interior_free = false;           // timing experiment: always the full loop
+      if (GV_ABL(128) && !interior_free) continue;   // timing experiment: skip the full loop
       unsigned mask = 0, todo = 0;   // todo: cells of this column to evaluate exactly
       if (interior_free) {
         mask = ((w >= 32) ? 0xFFFFFFFFu : ((1u << w) - 1u)) & ~1u & ~(1u << (w - 1));
@@ -872,7 +888,7 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
     stamp();   // 10: gather done
   };
 
-  if (A.ablate & 32) return;   // timing experiment
+  if GV_ABL(32) return;   // timing experiment
   // Normally the whole wedge is one group.  With more ends than one LDS group holds: one group
   // per row of columns, and per wavefront (64 columns x <= 32 ends <= 2048 <= cap) where a row
   // alone is too big.
@@ -903,7 +919,7 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
     uint8_t *grid = oc.xmaj ? A.missN : A.missT;
     const int pitch = oc.xmaj ? A.g.nx : A.g.ny;
     const int step = oc.smin * pitch;
-    for (int i = tid; i <= ((A.ablate & 4) ? -1 : oc.imax); i += NT) {
+    for (int i = tid; i <= (GV_ABL(4) ? -1 : oc.imax); i += NT) {
       unsigned w = marks[i];
       const int jlo = (2 * i * s + S) >> (log2s + 1);
       const int tmax = oc.jmaxo - jlo;                        // bits beyond it are outside the map

@@ -41,6 +41,8 @@ ABI_SYMBOLS = [
     "gv_get_cell_idx", "gv_get_bbox_id", "gv_get_ray_stats", "gv_stream", "gv_time_frames",
     "gv_time_frame_stages", "gv_comm_unique_id", "gv_comm_init", "gv_comm_destroy",
     "gv_process_frame_sharded", "gv_comm_band",
+    "gv_cloud_upload_xyz_async", "gv_cloud_upload_pointcloud2_async", "gv_cloud_upload_wait", "gv_host_alloc",
+    "gv_host_free", "gv_frame_set_detections_async", "gv_frame_fence",
 ]
 
 
@@ -131,6 +133,30 @@ def filter_bboxes(bboxes):
     return st[:ns.value].copy(), dy[:nd.value].copy()
 
 
+class PinnedF32:
+    """float32 array in page-locked host memory (gv_host_alloc) for the asynchronous uploads."""
+
+    def __init__(self, n):
+        self._lib = load()
+        self._p = C.c_void_p()
+        rc = self._lib.gv_host_alloc(C.byref(self._p), C.c_size_t(max(int(n), 1) * 4))
+        if rc:
+            raise GVError(rc, "gv_host_alloc")
+        self.array = np.ctypeslib.as_array(C.cast(self._p, C.POINTER(C.c_float)), shape=(int(n),))
+
+    def close(self):
+        if self._p:
+            self.array = None
+            self._lib.gv_host_free(self._p)
+            self._p = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class GridVisionHIP:
     """One handle = one MI355X + one stream + one resident occupancy grid."""
 
@@ -186,6 +212,17 @@ class GridVisionHIP:
         x, y, z = _f32(x), _f32(y), _f32(z)
         self._ck(self._lib.gv_cloud_upload_xyz(self._h, _ptr(x), _ptr(y), _ptr(z), C.c_size_t(len(x))), "upload_xyz")
         self.n = len(x)
+
+    def upload_xyz_async(self, x, y, z):
+        """x, y, z: float32 arrays that stay alive and unchanged until upload_wait() (pinned: see PinnedF32)."""
+        for a in (x, y, z):
+            assert a.dtype == np.float32 and a.flags["C_CONTIGUOUS"]
+        self._ck(self._lib.gv_cloud_upload_xyz_async(self._h, _ptr(x), _ptr(y), _ptr(z), C.c_size_t(len(x))),
+                 "upload_xyz_async")
+        self.n = len(x)
+
+    def upload_wait(self):
+        self._ck(self._lib.gv_cloud_upload_wait(self._h), "upload_wait")
 
     def upload_pointcloud2(self, data: np.ndarray, n, point_step, off_x, off_y, off_z):
         data = np.ascontiguousarray(data, dtype=np.uint8)
@@ -324,6 +361,16 @@ class GridVisionHIP:
     def set_detections(self, flags, bboxes=None, poses=None, net=None):
         d = self._desc(flags, bboxes, poses, net)
         self._ck(self._lib.gv_frame_set_detections(self._h, C.byref(d)), "frame_set_detections")
+
+    def set_detections_async(self, flags, bboxes=None, poses=None, net=None):
+        d = self._desc(flags, bboxes, poses, net)
+        self._ck(self._lib.gv_frame_set_detections_async(self._h, C.byref(d)), "frame_set_detections_async")
+
+    def frame_fence(self):
+        self._ck(self._lib.gv_frame_fence(self._h), "frame_fence")
+
+    def stream(self):
+        return self._lib.gv_stream(self._h)
 
     def enqueue_frame(self):
         self._ck(self._lib.gv_frame_enqueue(self._h), "frame_enqueue")

@@ -14,11 +14,14 @@
  *   - every function returns a gv_status (0 = ok); out-of-map rectangles and
  *     points are NOT errors (the reference skips them silently,
  *     src/occupancy_grid.cpp:152-156,171-172);
- *   - one handle = one GPU + one HIP stream + one resident grid; a handle is
- *     used by one thread at a time; handles are independent;
+ *   - one handle = one GPU + one resident grid + the HIP streams of its frame
+ *     pipeline (gv_stream returns the one callers may order their own work on,
+ *     after gv_frame_fence); a handle is used by one thread at a time; handles
+ *     are independent;
  *   - host pointers are caller owned and may be pageable; every call returns
  *     after its results are complete in the caller's buffers (synchronous),
- *     except gv_frame_enqueue (see there);
+ *     except the streaming calls gv_frame_enqueue, gv_cloud_upload_*_async and
+ *     gv_frame_set_detections_async (see there);
  *   - grid layers use the reference's storage order: grid_map's column-major
  *     Eigen::MatrixXf(size0,size1) with row = x index, i.e. linear = iy*nx+ix;
  *   - [EXTENSION] marks what north_star asks for and the reference lacks.
@@ -92,7 +95,7 @@ int gv_create(gv_handle *out, uint8_t grid_x, uint8_t grid_y, double resolution,
 int gv_destroy(gv_handle h);
 /* text of the last HIP/RCCL failure on this handle ("" if none) */
 const char *gv_last_error(gv_handle h);
-/* ABI version of the library (this header: 1) */
+/* ABI version of the library (this header: 2) */
 int gv_abi_version(void);
 /* geometry read-back: nx, ny, pos_x, pos_y (grid_map size / position) */
 int gv_grid_geometry(gv_handle h, int32_t *nx, int32_t *ny, double *pos_x, double *pos_y);
@@ -115,6 +118,23 @@ int gv_cloud_upload_xyz(gv_handle h, const float *x, const float *y, const float
  * fp32 fields at off_x/off_y/off_z; de-interleaved on the device. */
 int gv_cloud_upload_pointcloud2(gv_handle h, const uint8_t *data, size_t n, uint32_t point_step,
                                 uint32_t off_x, uint32_t off_y, uint32_t off_z);
+/* Streaming ingest: the node receives a new cloud (cloudCallback, grid_vision_node.cpp:103-106)
+ * while the previous frame is still being processed (timerCallback, :108-244).  The handle
+ * keeps TWO resident clouds: the *_async calls enqueue the host-to-device copy of the next one
+ * on a copy stream, ordered after the last frame that reads the buffer being replaced, and return
+ * at once; frames enqueued afterwards use the new cloud (stream-ordered, no host wait).  The copy
+ * is truly asynchronous when the host buffers are pinned (gv_host_alloc); pageable buffers work
+ * too (the HIP runtime then stages them before returning).  The host buffers must stay unchanged
+ * until gv_cloud_upload_wait (or gv_synchronize) returns.  The synchronous gv_cloud_upload_*
+ * calls above are the same upload followed by that wait; neither kind drains the frame pipeline. */
+int gv_cloud_upload_xyz_async(gv_handle h, const float *x, const float *y, const float *z, size_t n);
+int gv_cloud_upload_pointcloud2_async(gv_handle h, const uint8_t *data, size_t n, uint32_t point_step,
+                                      uint32_t off_x, uint32_t off_y, uint32_t off_z);
+/* wait until every upload enqueued so far has left the host buffers */
+int gv_cloud_upload_wait(gv_handle h);
+/* page-locked host memory for the *_async uploads (hipHostMalloc / hipHostFree) */
+int gv_host_alloc(void **ptr, size_t bytes);
+int gv_host_free(void *ptr);
 /* Replaces GridVision::transformLidarToCamera (grid_vision_node.cpp:280-307,
  * include/grid_vision/grid_vision_node.hpp:95-97): camera-frame copy of the
  * resident cloud written to caller SoA buffers (each n floats). */
@@ -237,17 +257,30 @@ typedef struct {
   int32_t n_poses;
   const float *orient, *conf, *dims;  /* GV_FRAME_VISION_ORIENT: nb*4, nb*2, nb*3 */
 } gv_frame_desc;
-/* Upload the small per-frame detection inputs (bboxes, poses / net outputs). */
+/* Upload the small per-frame detection inputs (bboxes, poses / net outputs).  Two sets
+ * alternate like the clouds do: the arrays are copied to pinned staging (the caller's arrays
+ * are free on return), uploaded on the copy stream and turned into the bbox-test tables on
+ * the device; frames enqueued afterwards use them.  The _async form returns without waiting
+ * for the copy; neither form drains the frame pipeline.  The standalone entry points above
+ * (gv_extract_cloud_per_bbox, gv_update_map_poses, ...) keep their inputs in a set of their
+ * own and never change what gv_frame_enqueue uses. */
 int gv_frame_set_detections(gv_handle h, const gv_frame_desc *desc);
-/* Enqueue one frame on the handle's stream using the resident cloud and the
- * last uploaded detections; returns without waiting (asynchronous). */
+int gv_frame_set_detections_async(gv_handle h, const gv_frame_desc *desc);
+/* Enqueue one frame using the resident cloud and the last detections set; returns without
+ * waiting (asynchronous).  GV_ERR_STATE before the first gv_frame_set_detections.  The
+ * default frame is pipelined over internal streams (rectangles + binning of frame f+1
+ * overlap the ray stage and the grid pass of frame f): work a caller puts on gv_stream() is
+ * ordered after the enqueued frames only once gv_frame_fence has been called. */
 int gv_frame_enqueue(gv_handle h);
-/* Wait for everything enqueued on the handle's stream. */
+/* Make gv_stream(h) wait (on the device, not the host) for every frame and upload enqueued so
+ * far: afterwards an event recorded or a kernel launched on gv_stream(h) sees their results. */
+int gv_frame_fence(gv_handle h);
+/* Wait (host) for everything enqueued on the handle. */
 int gv_synchronize(gv_handle h);
 /* gv_frame_set_detections + gv_frame_enqueue + gv_synchronize */
 int gv_process_frame(gv_handle h, const gv_frame_desc *desc);
 /* Per-frame outputs of the last frame (need GV_FRAME_KEEP_* where noted). */
-int gv_get_hits(gv_handle h, int32_t *out);          /* G ints, KEEP_COUNTS   */
+int gv_get_hits(gv_handle h, int32_t *out);          /* G ints; any BIN frame (generic grids: KEEP_COUNTS) */
 int gv_get_miss(gv_handle h, int32_t *out);          /* G ints in {0,1}, KEEP_COUNTS */
 int gv_get_cell_idx(gv_handle h, int32_t *out);      /* N ints, KEEP_CELL_IDX */
 int gv_get_bbox_id(gv_handle h, int32_t *out);       /* N ints, BBOX_TEST     */
@@ -255,8 +288,9 @@ int gv_get_bbox_id(gv_handle h, int32_t *out);       /* N ints, BBOX_TEST     */
 int gv_get_ray_stats(gv_handle h, uint64_t *n_rays, uint64_t *n_visits);
 
 /* ------------------------------------------------ raw stream / timing hooks -- */
-/* The HIP stream of the handle (hipStream_t as void*), for callers that record
- * their own events around gv_frame_enqueue. */
+/* The HIP stream of the handle (hipStream_t as void*), for callers that record their own
+ * events around gv_frame_enqueue or consume the grid layers on the device: call
+ * gv_frame_fence first, the pipelined frame finishes on internal streams. */
 void *gv_stream(gv_handle h);
 /* Time `frames` back-to-back gv_frame_enqueue calls with HIP events on the
  * handle's stream; *ms_total is the elapsed device time. */
@@ -266,8 +300,8 @@ int gv_time_frames(gv_handle h, int32_t frames, float *ms_total);
  * stage_ms has GV_NUM_STAGES entries. */
 enum {
   GV_STAGE_DETECTIONS = 0,   /* vision-orientation geometry + rectangles       */
-  GV_STAGE_POINTS = 1,       /* transform + bin + ray ends + bbox test         */
-  GV_STAGE_RAY_COMPACT = 2,  /* ray-end compaction                             */
+  GV_STAGE_POINTS = 1,       /* transform + cell index + ray ends + bbox test, keys partitioned by tile */
+  GV_STAGE_RAY_COMPACT = 2,  /* per-tile hit histogram -> hits[] + ray-end bitmaps */
   GV_STAGE_RAY_MARCH = 3,    /* Bresenham free-space march                     */
   GV_STAGE_FINALIZE = 4,     /* decay/rect/hit-miss/clamp/sigmoid/int8 pass    */
   GV_NUM_STAGES = 5

@@ -820,11 +820,11 @@ def test_pipelined_equals_serial(gvamd, monkeypatch):
 @pytest.mark.parametrize("grid,n", [((50, 20, 0.1), 60_000), ((120, 200, 0.25), 40_000), ((50, 20, 0.3), 20_000),
                                     ((200, 200, 0.1), 1_000_000)])
 @pytest.mark.parametrize("pipeline", ["1", "0"])
-def test_production_frame_byte_flags_vs_oracle(gvamd, monkeypatch, grid, n, pipeline):
-    """The production frame (no KEEP_* flags) marks hits as byte flags instead of counting them
-    (the update rule is binary per cell): grid layers must still equal the oracle's, frame after
-    frame (the flag maps are cleared inside the frame), serial and pipelined, including a grid with
-    nx % 4 != 0 (generic kernels) and config 3 at full size."""
+def test_production_frame_vs_oracle(gvamd, monkeypatch, grid, n, pipeline):
+    """The production frame (no KEEP_* flags): int32 hit counts read back from the PIPELINED path are
+    bit-exact, and the grid layers equal the oracle's frame after frame, serial and pipelined,
+    including a grid with nx % 4 != 0 (generic kernels, no counts without KEEP_COUNTS) and config 3
+    at full size."""
     monkeypatch.setenv("GV_PIPELINE", pipeline)
     gx, gy, res = grid
     h = gvamd.GridVisionHIP(gx, gy, res)
@@ -851,31 +851,151 @@ def test_production_frame_byte_flags_vs_oracle(gvamd, monkeypatch, grid, n, pipe
         h.enqueue_frame()          # the same cloud twice: two frames in flight when pipelined
         h.synchronize()
         for _ in range(2):
-            _, _, _, ids, _ = oracle_frame(og, tfs, x, y, z, bboxes, poses)
+            hits, _, _, ids, _ = oracle_frame(og, tfs, x, y, z, bboxes, poses)
         assert np.array_equal(h.bbox_id(), ids)
+        if og.g.nx % 4 == 0:
+            assert np.array_equal(h.hits(), hits), "int32 hit counts of the production (pipelined) frame"
+            assert int(h.hits().sum()) == int(hits.sum())
         nlo, _, _ = check_grid(h, og)
         assert nlo == 0
     h.close()
 
 
-def test_forced_counts_equals_byte_flags(gvamd, monkeypatch):
-    """GV_HIT_COUNTS=1 (int32 counting with atomics in the production frame) and the default
-    byte flags give the same grid."""
-    config = 2
-    x, y, z, _ = synth.cloud_lidar_like(config, 80_000)
-    outs = []
-    for force in ("1", "0"):
-        monkeypatch.setenv("GV_HIT_COUNTS", force)
-        h, tfs = make_handle(gvamd, config, perturbed=True)
+def _crowded_cloud(n, seed, spread):
+    """points packed around the sensor: most of them in one or two 128x128-cell tiles"""
+    st = synth.Stream(seed, n)
+    r = st.uniform(n, 0.0, 1.0) ** 2 * spread
+    a = st.uniform(n, 0.0, 2.0 * np.pi)
+    return (r * np.cos(a)).astype(np.float32), (r * np.sin(a)).astype(np.float32), st.uniform(n, -1.0, 1.0)
+
+
+@pytest.mark.parametrize("n,spread", [(300_000, 6.0), (150_000, 25.0)])
+def test_crowded_tiles_are_shared(gvamd, n, spread):
+    """A tile that holds more than 32768 keys is histogrammed by several workgroups whose partial
+    tiles are summed by the last one to arrive: counts bit-exact, hundreds of hits per cell, several
+    frames so that the arrival tickets and per-tile totals have to reset themselves."""
+    config = 3
+    h, tfs = make_handle(gvamd, config, perturbed=True)
+    g = synth.CONFIGS[config]["grid"]
+    og = ol.OGrid(g.grid_x, g.grid_y, g.resolution)
+    flags = gvamd.FRAME_BIN | gvamd.FRAME_RAYMARCH | gvamd.FRAME_KEEP_CELL_IDX | gvamd.FRAME_KEEP_COUNTS
+    for frame in range(3):
+        x, y, z = _crowded_cloud(n, 77 + frame, spread)
         h.upload_xyz(x, y, z)
-        h.set_detections(gvamd.FRAME_BIN | gvamd.FRAME_RAYMARCH, poses=synth.lshape_poses(config, 10))
-        for _ in range(3):
-            h.enqueue_frame()
+        h.process_frame(flags)
+        hits, cell, miss, _, _ = oracle_frame(og, tfs, x, y, z)
+        assert hits.max() > 50, "fixture must pile points up"
+        assert np.array_equal(h.cell_idx(), cell)
+        assert np.array_equal(h.hits(), hits)
+        assert np.array_equal(h.miss(), miss.astype(np.int32))
+        nlo, _, _ = check_grid(h, og)
+        assert nlo == 0
+    # a sparse frame afterwards: no tile is shared any more
+    x, y, z, _ = synth.cloud_uniform(config, 50_000)
+    h.upload_xyz(x, y, z)
+    h.process_frame(flags)
+    hits, cell, miss, _, _ = oracle_frame(og, tfs, x, y, z)
+    assert np.array_equal(h.hits(), hits)
+    assert np.array_equal(h.miss(), miss.astype(np.int32))
+    h.close()
+
+
+def test_streaming_ingest_matches_oracle(gvamd):
+    """grid_vision_node.cpp:103-106,108-244: a new cloud and new detections every frame.  Six distinct
+    clouds / detection sets go through the asynchronous, double-buffered uploads and the pipelined
+    frame with no host wait in between; the grid after every frame count must equal the oracle's (a
+    frame that read a stale or half-copied cloud or detection set would change it), and the per-point
+    outputs of the last frame are compared too."""
+    config = 2
+    g = synth.CONFIGS[config]["grid"]
+    n = 80_000
+    clouds, dets = [], []
+    pins = []
+    for f in range(6):
+        gen = synth.cloud_uniform if f % 2 == 0 else synth.cloud_lidar_like
+        x, y, z, _ = gen(config, n - 1000 * f, seed_extra=f)
+        px, py, pz = (gvamd.PinnedF32(len(x)) for _ in range(3))
+        px.array[:], py.array[:], pz.array[:] = x, y, z
+        pins.append((px, py, pz))
+        clouds.append((x, y, z))
+        dets.append((synth.detections(3, 10 + 5 * f, seed_extra=f), synth.lshape_poses(config, 8 + 3 * f, seed_extra=f)))
+    flags = gvamd.FRAME_BIN | gvamd.FRAME_RAYMARCH | gvamd.FRAME_BBOX_TEST
+    for upto in (1, 2, 6):
+        h, tfs = make_handle(gvamd, config, perturbed=True)
+        og = ol.OGrid(g.grid_x, g.grid_y, g.resolution)
+        for rep in range(2):
+            for f in range(upto):
+                px, py, pz = pins[f]
+                h.upload_xyz_async(px.array, py.array, pz.array)
+                h.set_detections_async(flags, bboxes=dets[f][0], poses=dets[f][1])
+                h.enqueue_frame()
         h.synchronize()
-        outs.append((h.log_odds(), h.occupancy(), h.to_occupancy_grid()[0]))
+        for rep in range(2):
+            for f in range(upto):
+                hits, _, _, ids, _ = oracle_frame(og, tfs, *clouds[f], dets[f][0], dets[f][1])
+        assert np.array_equal(h.hits(), hits)
+        assert np.array_equal(h.bbox_id(), ids)
+        nlo, _, _ = check_grid(h, og)
+        assert nlo == 0
         h.close()
-    for a, b in zip(*outs):
-        assert np.array_equal(a, b)
+    for p3 in pins:
+        for p in p3:
+            p.close()
+
+
+def test_standalone_calls_keep_frame_detections(gvamd):
+    """The reference-surface calls (extractCloudPerBBox, updateMap(poses), ...) must not change what the
+    next gv_frame_enqueue uses: set_detections(50 boxes) -> extract_cloud_per_bbox(3 other boxes) ->
+    update_map_poses(other poses) -> enqueue_frame still runs with the 50."""
+    config = 2
+    h, tfs = make_handle(gvamd, config, perturbed=True)
+    g = synth.CONFIGS[config]["grid"]
+    og = ol.OGrid(g.grid_x, g.grid_y, g.resolution)
+    x, y, z, _ = synth.cloud_uniform(config, 60_000)
+    h.upload_xyz(x, y, z)
+    bboxes, poses = synth.detections(3, 50), synth.lshape_poses(config, 50)
+    flags = gvamd.FRAME_BIN | gvamd.FRAME_RAYMARCH | gvamd.FRAME_BBOX_TEST
+    h.set_detections(flags, bboxes=bboxes, poses=poses)
+    other = synth.detections(3, 3, seed_extra=9)
+    ids3, _ = h.extract_cloud_per_bbox(other)
+    cx, cy, cz = ol.transform_cloud(ol.tf_to_matrix4f(tfs["cam_lidar"]), x, y, z)
+    K = ol.set_intrinsic(synth.FX, synth.FY, synth.CX, synth.CY)
+    assert np.array_equal(ids3, ol.extract_cloud_per_bbox(K, cx, cy, cz, other, synth.IMG_W, synth.IMG_H))
+    other_poses = synth.lshape_poses(config, 5, seed_extra=4)
+    h.update_map_poses(other_poses)
+    og.update_map_poses(other_poses)
+    h.enqueue_frame()
+    h.synchronize()
+    hits, _, _, ids, _ = oracle_frame(og, tfs, x, y, z, bboxes, poses)
+    assert np.array_equal(h.bbox_id(), ids)
+    assert np.array_equal(h.hits(), hits)
+    nlo, _, _ = check_grid(h, og)
+    assert nlo == 0
+    h.close()
+
+
+def test_diagnostic_switches_do_not_exist_in_the_product(gvamd, monkeypatch):
+    """GV_ABLATE / GV_POINTS_ABLATE / GV_SECTOR_DBG only exist in the -DGV_DIAG build: the shipped
+    library ignores them and the grid equals the oracle's."""
+    for k, v in (("GV_ABLATE", "6"), ("GV_POINTS_ABLATE", "3"), ("GV_SECTOR_DBG", "1"), ("GV_HIT_COUNTS", "0")):
+        monkeypatch.setenv(k, v)
+    config = 2
+    h, tfs = make_handle(gvamd, config, perturbed=True)
+    g = synth.CONFIGS[config]["grid"]
+    og = ol.OGrid(g.grid_x, g.grid_y, g.resolution)
+    x, y, z, _ = synth.cloud_uniform(config, 70_000)
+    bboxes = synth.detections(3, 12)
+    h.upload_xyz(x, y, z)
+    h.set_detections(gvamd.FRAME_BIN | gvamd.FRAME_RAYMARCH | gvamd.FRAME_BBOX_TEST, bboxes=bboxes)
+    for _ in range(2):
+        h.enqueue_frame()
+        hits, _, _, ids, _ = oracle_frame(og, tfs, x, y, z, bboxes)
+    h.synchronize()
+    assert np.array_equal(h.hits(), hits)
+    assert np.array_equal(h.bbox_id(), ids)
+    nlo, _, _ = check_grid(h, og)
+    assert nlo == 0
+    h.close()
 
 
 @pytest.mark.parametrize("origin", ["corner++", "corner--", "edge_x", "edge_y", "near_corner", "centre"])
