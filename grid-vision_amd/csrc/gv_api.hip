@@ -61,10 +61,13 @@ struct gv_context {
   hipEvent_t ev_join[3]{};
   int n_sets = 3;                 // GV_PIPE_SETS (2..4): buffer sets the pipelined frames rotate through
   // per-set buffers of the frames in flight: end bitmaps, rectangles, miss grids, ray statistics
+  uint32_t *x_ends[kSets]{};      // one allocation per set: [hitN | clipN | hitT | clipT], ends_words in all
   uint32_t *x_hitN[kSets]{}, *x_clipN[kSets]{}, *x_hitT[kSets]{}, *x_clipT[kSets]{};
+  uint32_t *x_free[kSets]{};      // [freeN | freeT]: free-cell bitmaps of the ray stage
+  uint32_t *x_freeN[kSets]{}, *x_freeT[kSets]{};
+  size_t ends_words = 0, bmN_words = 0, bmT_words = 0;
   Rect *x_rects[kSets]{};
-  uint8_t *x_miss[kSets]{}, *x_missT[kSets]{};
-  bool miss_dirty[kSets]{};       // the set holds a kept frame's miss grids (GV_FRAME_KEEP_COUNTS)
+  uint8_t *miss8 = nullptr;       // generic path only: byte miss grid of the literal march
   unsigned long long *x_stats[kSets]{};
   int last_set = 0;
   uint64_t frame_no = 0;
@@ -151,6 +154,8 @@ struct gv_context {
   // multi-GPU (one large frame sharded by points)
   ncclComm_t comm = nullptr;
   int32_t rank = 0, world = 1;
+  uint32_t *sh_xchg = nullptr;    // exchange scratch: `world` received slices / packed bands
+  size_t sh_xchg_cap = 0;
 
   hipEvent_t ev[kNumStages + 1]{};
   std::string err;
@@ -336,7 +341,7 @@ int clear_counts(gv_context *h)
 {
   const size_t G = (size_t)h->g.G;
   GV_HIP(hipMemsetAsync(h->hits, 0, G * sizeof(int32_t), h->stream));
-  GV_HIP(hipMemsetAsync(h->x_miss[0], 0, G, h->stream));
+  GV_HIP(hipMemsetAsync(h->miss8, 0, G, h->stream));
   GV_HIP(hipMemsetAsync(h->clip_end, 0, G, h->stream));
   h->counts_dirty = false;
   return GV_OK;
@@ -419,13 +424,11 @@ int enqueue_plain_update(gv_context *h, int32_t n_rects)
     t.rects = h->x_rects[0];
     t.n_rects = n_rects;
     t.hitN = h->x_hitN[0];
-    t.nxw = h->nxw;
+    t.freeN = h->x_freeN[0];
+    t.freeT = h->x_freeT[0];
+    t.nx_pad = h->nx_pad;
     t.ny_pad = h->ny_pad;
-    t.missN = h->x_miss[0];
-    t.missT = h->x_missT[0];
     t.counts = false;
-    t.zero = false;
-    t.use_missT = false;
     t.y_begin = 0;
     t.y_end = h->g.ny;
     launch_finalize_tiles(t, h->stream);
@@ -450,7 +453,7 @@ int enqueue_plain_update(gv_context *h, int32_t n_rects)
   return GV_OK;
 }
 
-int sharded_tail(gv_context *h, int32_t n_rects);
+int sharded_tail(gv_context *h, const Rect *rects, int32_t n_rects);
 
 // sector-kernel launch parameters for the resident cloud and grid, buffer set p
 int fill_sector_args(gv_context *h, SectorArgs &sa, int p)
@@ -512,9 +515,11 @@ int fill_sector_args(gv_context *h, SectorArgs &sa, int p)
   sa.wg_base[8] = (uint16_t)base;
   sa.hitN = h->x_hitN[p]; sa.clipN = h->x_clipN[p]; sa.hitT = h->x_hitT[p]; sa.clipT = h->x_clipT[p];
   sa.nxw = h->nxw; sa.nyw = h->nyw; sa.nx_pad = h->nx_pad; sa.ny_pad = h->ny_pad;
-  sa.missN = h->x_miss[p];
-  sa.missT = h->x_missT[p];
+  sa.freeN = h->x_freeN[p];
+  sa.freeT = h->x_freeT[p];
   sa.stats = h->x_stats[p];
+  sa.wg_first = 0;
+  sa.wg_stride = 1;
   h->stat_slots = (size_t)sa.wg_base[8];
   return GV_OK;
 }
@@ -545,6 +550,98 @@ int check_frame_flags(const gv_context *h, uint32_t fl)
   return GV_OK;
 }
 
+// --- building blocks of the tile-path frame (shared by the one-GPU frame, the sharded frame and its
+// one-device emulation) ---
+
+// partition + tile histogram of points [lo, lo + n) of the current cloud: hits[] (or not) and the end
+// bitmaps of buffer set p; zeroes the set's free-cell bitmaps.  ev_* are stage-timing events or null.
+int enqueue_binning(gv_context *h, const DetSet &D, int p, size_t lo, size_t n, bool keep_cell, bool do_ray,
+                    bool do_bbox, bool write_hits, hipStream_t s, hipEvent_t ev_points)
+{
+  const uint32_t chunk = bin_chunk_for(n);
+  const uint32_t n_wg = (uint32_t)((n + chunk - 1) / chunk);
+  BinArgs a{};
+  a.x = h->cx + lo; a.y = h->cy + lo; a.z = h->cz + lo;
+  a.n = (uint32_t)n;
+  a.g = h->g;
+  a.m_base = h->m_base;
+  a.m_cam = h->m_cam;
+  a.cam = h->camk;
+  a.org = h->org;
+  a.bt = bbox_test_of(h, D);
+  a.bbox_id = h->bbox_id + lo;
+  a.cell_idx = keep_cell ? h->cell_idx + lo : nullptr;
+  a.do_ray = do_ray;
+  a.do_bbox = do_bbox;
+  a.chunk = chunk;
+  a.n_wg = n_wg;
+  a.tiles_x = h->tiles_x; a.tiles_y = h->tiles_y; a.n_tiles = h->n_tiles;
+  a.keys = h->bin_keys;
+  a.tab = h->bin_tab;
+  a.tile_total = h->bin_total[h->bin_parity];
+  launch_bin_partition(a, s);
+  if (ev_points) GV_HIP(hipEventRecord(ev_points, s));
+  BinTileArgs t{};
+  t.nx = h->g.nx; t.ny = h->g.ny;
+  t.tiles_x = h->tiles_x; t.tiles_y = h->tiles_y; t.n_tiles = h->n_tiles;
+  t.n_wg = n_wg;
+  t.chunk = chunk;
+  t.keys = h->bin_keys;
+  t.tab = h->bin_tab;
+  t.tile_total = h->bin_total[h->bin_parity];
+  t.tile_total_next = h->bin_total[h->bin_parity ^ 1];
+  t.done = h->bin_done;
+  t.scratch = h->bin_scratch;
+  t.split_keys = kBinSplitKeys;
+  t.max_slots = (uint32_t)h->bin_slots;
+  t.hits = write_hits ? h->hits : nullptr;
+  t.hitN = h->x_hitN[p]; t.clipN = h->x_clipN[p]; t.hitT = h->x_hitT[p]; t.clipT = h->x_clipT[p];
+  t.freeN = h->x_freeN[p]; t.freeT = h->x_freeT[p];
+  t.nxw = h->nxw; t.nyw = h->nyw; t.nx_pad = h->nx_pad; t.ny_pad = h->ny_pad;
+  launch_bin_tiles(t, (uint32_t)(n / kBinSplitKeys), s);
+  h->bin_parity ^= 1;
+  GV_HIP(hipGetLastError());
+  return GV_OK;
+}
+
+// sector ray stage over the end bitmaps of set p into its free-cell bitmaps; workgroups first,
+// first + stride, ... of the dispatch order (one GPU: 0, 1)
+int enqueue_sectors(gv_context *h, int p, int first, int stride, hipStream_t s)
+{
+  if (!h->org.valid) return GV_OK;
+  SectorArgs sa{};
+  int rc = fill_sector_args(h, sa, p);
+  if (rc) return rc;
+  sa.wg_first = first;
+  sa.wg_stride = stride;
+  launch_ray_sectors(sa, s);
+  GV_HIP(hipGetLastError());
+  return GV_OK;
+}
+
+int enqueue_grid_pass(gv_context *h, int p, const Rect *rects, int32_t n_rects, bool counts, int32_t y0, int32_t y1,
+                      hipStream_t s)
+{
+  FinalizeTileArgs t{};
+  t.g = h->g;
+  t.log_odds = h->log_odds;
+  t.occupancy = h->occupancy;
+  t.occ_i8 = h->occ_i8;
+  t.rects = rects;
+  t.n_rects = n_rects;
+  t.hitN = h->x_hitN[p];
+  t.freeN = h->x_freeN[p];
+  t.freeT = h->x_freeT[p];
+  t.nx_pad = h->nx_pad;
+  t.ny_pad = h->ny_pad;
+  t.counts = counts;
+  t.y_begin = y0;
+  t.y_end = y1;
+  launch_finalize_tiles(t, s);
+  GV_HIP(hipGetLastError());
+  return GV_OK;
+}
+
 // The tile-path frame.  pipelined: stream A = rectangles, partition, tile histogram + end bitmaps of
 // frame f; stream B = sector ray stage; stream C = grid pass, over n_sets rotating buffer sets, so that A
 // runs up to n_sets frames ahead.  Serial (GV_PIPELINE=0, stage timing, the sharded frame): the same
@@ -554,7 +651,7 @@ int enqueue_frame_tiles(gv_context *h, bool pipelined, bool stage_events, bool s
   DetSet &D = h->det[h->det_cur];
   const uint32_t fl = D.flags;
   const bool do_bin = fl & GV_FRAME_BIN, do_ray = fl & GV_FRAME_RAYMARCH, do_bbox = fl & GV_FRAME_BBOX_TEST;
-  const bool keep_cell = fl & GV_FRAME_KEEP_CELL_IDX, keep_counts = fl & GV_FRAME_KEEP_COUNTS;
+  const bool keep_cell = fl & GV_FRAME_KEEP_CELL_IDX;
   int rc = check_frame_flags(h, fl);
   if (rc) return rc;
   if (sharded && (!do_bin || !h->comm)) return GV_ERR_STATE;
@@ -585,133 +682,63 @@ int enqueue_frame_tiles(gv_context *h, bool pipelined, bool stage_events, bool s
   mark(sA);
   if (stage_events) GV_HIP(hipEventRecord(h->ev[kStageDetections + 1], sA));
 
-  // --- points: partition by tile (+ ray ends, bbox test)
-  const uint32_t chunk = bin_chunk_for(h->n);
-  const uint32_t n_wg = (uint32_t)((h->n + chunk - 1) / chunk);
+  // --- points: partition by tile (+ ray ends, bbox test), then the tile histogram: hits[] + end bitmaps
   mark(sA);
   if (do_bin) {
-    BinArgs a{};
-    a.x = h->cx; a.y = h->cy; a.z = h->cz;
-    a.n = (uint32_t)h->n;
-    a.g = h->g;
-    a.m_base = h->m_base;
-    a.m_cam = h->m_cam;
-    a.cam = h->camk;
-    a.org = h->org;
-    a.bt = bbox_test_of(h, D);
-    a.bbox_id = h->bbox_id;
-    a.cell_idx = keep_cell ? h->cell_idx : nullptr;
-    a.do_ray = do_ray;
-    a.do_bbox = do_bbox;
-    a.chunk = chunk;
-    a.n_wg = n_wg;
-    a.tiles_x = h->tiles_x; a.tiles_y = h->tiles_y; a.n_tiles = h->n_tiles;
-    a.keys = h->bin_keys;
-    a.tab = h->bin_tab;
-    a.tile_total = h->bin_total[h->bin_parity];
-    launch_bin_partition(a, sA);
-  } else if (do_bbox) {
-    PointsArgs a{};
-    a.x = h->cx; a.y = h->cy; a.z = h->cz;
-    a.n = (uint32_t)h->n;
-    a.g = h->g;
-    a.m_cam = h->m_cam;
-    a.cam = h->camk;
-    a.bt = bbox_test_of(h, D);
-    a.bbox_id = h->bbox_id;
-    a.do_bbox = true;
-    launch_points(a, sA);
+    if ((rc = enqueue_binning(h, D, p, 0, h->n, keep_cell, do_ray, do_bbox, true, sA,
+                              stage_events ? h->ev[kStagePoints + 1] : nullptr)))
+      return rc;
+  } else {
+    if (do_bbox) {
+      PointsArgs a{};
+      a.x = h->cx; a.y = h->cy; a.z = h->cz;
+      a.n = (uint32_t)h->n;
+      a.g = h->g;
+      a.m_cam = h->m_cam;
+      a.cam = h->camk;
+      a.bt = bbox_test_of(h, D);
+      a.bbox_id = h->bbox_id;
+      a.do_bbox = true;
+      launch_points(a, sA);
+    }
+    if (stage_events) GV_HIP(hipEventRecord(h->ev[kStagePoints + 1], sA));
   }
   mark(sA);
   GV_HIP(hipEventRecord(CS.used, sA));   // the other cloud / detection set may be refilled from here on
   GV_HIP(hipEventRecord(D.used, sA));
-  if (stage_events) GV_HIP(hipEventRecord(h->ev[kStagePoints + 1], sA));
-
-  // --- tile histogram: hits[] + the four end bitmaps of set p
-  mark(sA);
-  if (do_bin) {
-    BinTileArgs t{};
-    t.nx = h->g.nx; t.ny = h->g.ny;
-    t.tiles_x = h->tiles_x; t.tiles_y = h->tiles_y; t.n_tiles = h->n_tiles;
-    t.n_wg = n_wg;
-    t.chunk = chunk;
-    t.keys = h->bin_keys;
-    t.tab = h->bin_tab;
-    t.tile_total = h->bin_total[h->bin_parity];
-    t.tile_total_next = h->bin_total[h->bin_parity ^ 1];
-    t.done = h->bin_done;
-    t.scratch = h->bin_scratch;
-    t.split_keys = kBinSplitKeys;
-    t.max_slots = (uint32_t)h->bin_slots;
-    t.hits = h->hits;
-    t.hitN = h->x_hitN[p]; t.clipN = h->x_clipN[p]; t.hitT = h->x_hitT[p]; t.clipT = h->x_clipT[p];
-    t.nxw = h->nxw; t.nyw = h->nyw; t.nx_pad = h->nx_pad; t.ny_pad = h->ny_pad;
-    launch_bin_tiles(t, (uint32_t)(h->n / kBinSplitKeys), sA);
-    h->bin_parity ^= 1;
-  }
-  mark(sA);
   if (stage_events) GV_HIP(hipEventRecord(h->ev[kStageRayCompact + 1], sA));
   if (pipelined) {
     GV_HIP(hipEventRecord(h->ev_build[p], sA));
     GV_HIP(hipStreamWaitEvent(sB, h->ev_build[p], 0));
-    if (set_reused) GV_HIP(hipStreamWaitEvent(sB, h->ev_fin[p], 0));   // miss set p cleared by its last reader
   }
+  h->last_set = p;
+  h->have_cell_idx = do_bin && keep_cell;
+  h->have_bbox_id = do_bbox;
+  if (sharded) return sharded_tail(h, rects, n_rects);
 
   // --- free-space ray stage
-  if (h->miss_dirty[p]) {   // a kept frame (GV_FRAME_KEEP_COUNTS) left its miss grids in this set
-    GV_HIP(hipMemsetAsync(h->x_miss[p], 0, (size_t)h->g.G, sB));
-    GV_HIP(hipMemsetAsync(h->x_missT[p], 0, (size_t)h->g.G, sB));
-    h->miss_dirty[p] = false;
-  }
   mark(sB);
-  if (do_ray && h->org.valid) {
-    SectorArgs sa{};
-    if ((rc = fill_sector_args(h, sa, p))) return rc;
-    launch_ray_sectors(sa, sB);
-  }
+  if (do_ray && (rc = enqueue_sectors(h, p, 0, 1, sB))) return rc;
   mark(sB);
   if (stage_events) GV_HIP(hipEventRecord(h->ev[kStageRayMarch + 1], sB));
-  h->last_set = p;
-  if (sharded) return sharded_tail(h, n_rects);
   if (pipelined) {
     GV_HIP(hipEventRecord(h->ev_sec[p], sB));
     GV_HIP(hipStreamWaitEvent(sC, h->ev_sec[p], 0));
   }
 
   // --- grid pass
-  FinalizeTileArgs t{};
-  t.g = h->g;
-  t.log_odds = h->log_odds;
-  t.occupancy = h->occupancy;
-  t.occ_i8 = h->occ_i8;
-  t.rects = rects;
-  t.n_rects = n_rects;
-  t.hitN = h->x_hitN[p];
-  t.nxw = h->nxw;
-  t.ny_pad = h->ny_pad;
-  t.missN = h->x_miss[p];
-  t.missT = h->x_missT[p];
-  t.counts = do_bin;
-  t.zero = do_bin && !keep_counts;
-  t.use_missT = true;
-  t.y_begin = 0;
-  t.y_end = h->g.ny;
   mark(sC);
-  launch_finalize_tiles(t, sC);
+  if ((rc = enqueue_grid_pass(h, p, rects, n_rects, do_bin, 0, h->g.ny, sC))) return rc;
   mark(sC);
-  if (do_bin && keep_counts) h->miss_dirty[p] = true;
   if (stage_events) GV_HIP(hipEventRecord(h->ev[kStageFinalize + 1], sC));
-  if (pipelined) GV_HIP(hipEventRecord(h->ev_fin[p], sC));
-  GV_HIP(hipGetLastError());
   if (pipelined) {
+    GV_HIP(hipEventRecord(h->ev_fin[p], sC));
     h->frame_no++;
     if (h->since_drain < h->n_sets) h->since_drain++;
     h->pipe_busy = true;
   }
   h->have_hits = do_bin;
-  h->have_miss = do_bin && keep_counts;
-  h->have_cell_idx = do_bin && keep_cell;
-  h->have_bbox_id = do_bbox;
+  h->have_miss = do_bin;   // the free-cell bitmaps of set p stay until the set is reused
   return GV_OK;
 }
 
@@ -754,7 +781,7 @@ int enqueue_frame_generic(gv_context *h, bool stage_events)
     h->stat_slots = 1;
     launch_ray_compact(h->hits, h->clip_end, h->g, h->ray_list, h->ray_count, s);
     if (stage_events) GV_HIP(hipEventRecord(h->ev[kStageRayCompact + 1], s));
-    launch_ray_march(h->ray_list, h->ray_count, h->g, h->org, h->x_miss[0], h->x_stats[0], s);
+    launch_ray_march(h->ray_list, h->ray_count, h->g, h->org, h->miss8, h->x_stats[0], s);
     if (stage_events) GV_HIP(hipEventRecord(h->ev[kStageRayMarch + 1], s));
   } else if (stage_events) {
     GV_HIP(hipEventRecord(h->ev[kStageRayCompact + 1], s));
@@ -768,7 +795,7 @@ int enqueue_frame_generic(gv_context *h, bool stage_events)
   f.rects = h->x_rects[0];
   f.n_rects = n_rects;
   f.hits = do_bin ? h->hits : nullptr;
-  f.miss = h->x_miss[0];
+  f.miss = h->miss8;
   f.clip_end = h->clip_end;
   f.zero_counts = do_bin && !keep_counts;
   f.cell_begin = 0;
@@ -795,76 +822,134 @@ int enqueue_frame_generic(gv_context *h, bool stage_events)
     }                                                                                          \
   } while (0)
 
-inline void band_rows(const gv_context *h, int r, int32_t &y0, int32_t &y1)
+// --- the frame sharded by points (BASELINE configs[4]) ---
+// Every rank bins ITS slice of the cloud into private end bitmaps.  Two exchanges follow, both of the
+// form "all-to-all of equal slices + local OR" (RCCL has no bitwise-OR reduction; the slices are bitmap
+// words, 32 cells per word):
+//   1. ray ends: the OR-ed slices are all-gathered, so every rank holds the complete end bitmaps and
+//      runs only every world-th workgroup of the sector ray stage (the dispatch order is sorted by
+//      expected cost, so the shares are balanced);
+//   2. free cells: each rank's partial free-cell bitmaps are packed by row band and rank q receives
+//      and ORs band q.
+// Rank q then runs the grid pass on band q (whole 64-row blocks) and the packed int8 bands are
+// broadcast.  OR and integer sums commute: the result is bit-identical to one GPU.
+// The exchanges are expressed over `ShardLink`, which is RCCL in production and a set of device
+// copies in the one-device emulation that the tests use to run every (rank, world).
+struct ShardLink {
+  gv_context *h;
+  int rank, world;
+  // emulation: the `world` per-rank source buffers of the current exchange (null with RCCL)
+  uint32_t *const *emu_src = nullptr;
+};
+
+// recv[q'] (count words each) <- slice `rank` of peer q'; send holds `world` slices of count words
+int shard_all_to_all(const ShardLink &L, const uint32_t *send, uint32_t *recv, size_t count, hipStream_t s)
 {
-  y0 = (int32_t)((int64_t)h->g.ny * r / h->world);
-  y1 = (int32_t)((int64_t)h->g.ny * (r + 1) / h->world);
+  gv_context *h = L.h;
+  if (L.emu_src) {
+    for (int q = 0; q < L.world; ++q)
+      GV_HIP(hipMemcpyAsync(recv + (size_t)q * count, L.emu_src[q] + (size_t)L.rank * count, count * sizeof(uint32_t),
+                            hipMemcpyDeviceToDevice, s));
+    return GV_OK;
+  }
+  ncclResult_t first_err = ncclGroupStart();
+  for (int q = 0; q < L.world && first_err == ncclSuccess; ++q) {
+    if (q == L.rank) continue;
+    ncclResult_t r = ncclSend(send + (size_t)q * count, count, ncclUint32, q, h->comm, s);
+    if (r == ncclSuccess) r = ncclRecv(recv + (size_t)q * count, count, ncclUint32, q, h->comm, s);
+    if (r != ncclSuccess) first_err = r;
+  }
+  const ncclResult_t ge = ncclGroupEnd();   // always closed, also on the error path
+  if (first_err == ncclSuccess) first_err = ge;
+  if (first_err != ncclSuccess) {
+    h->err = std::string("sharded all-to-all -> ") + ncclGetErrorString(first_err);
+    return GV_ERR_RCCL;
+  }
+  GV_HIP(hipMemcpyAsync(recv + (size_t)L.rank * count, send + (size_t)L.rank * count, count * sizeof(uint32_t),
+                        hipMemcpyDeviceToDevice, s));
+  return GV_OK;
 }
 
-// [EXTENSION] SURVEY 8(e)-2: the one exchange step of the sharded frame.  Every rank has
-// binned + ray-marched ITS slice of the points into private full-size count grids; integer
-// sum / byte max make the result independent of the reduce order, hence bit-identical to
-// one GPU.  Rank r then finalises row band r and the packed int8 bands are exchanged.
-int sharded_tail(gv_context *h, int32_t n_rects)
+size_t shard_ends_slice(const gv_context *h, int world)
 {
-  const int nx = h->g.nx, ny = h->g.ny;
-  const size_t G = (size_t)h->g.G;
-  uint8_t *miss = h->x_miss[0], *missT = h->x_missT[0];
-  launch_merge_miss(miss, missT, nx, ny, h->stream);   // miss = N | T^T, missT cleared
+  return (((h->ends_words + (size_t)world - 1) / (size_t)world) + 3) & ~(size_t)3;
+}
+
+int ensure_shard_scratch(gv_context *h, int world)
+{
+  const size_t chunk = free_band_chunk_words(h->nxw, h->nx_pad, h->ny_pad, world);
+  const size_t need = std::max(shard_ends_slice(h, world) * (size_t)world, 2 * chunk * (size_t)world) + 16;
+  return grow(h, h->sh_xchg, h->sh_xchg_cap, need);
+}
+
+// exchange 1 (this rank's part): OR of everyone's slice `rank` of the end bitmaps, written back in place
+int shard_or_ends_slice(const ShardLink &L, uint32_t *ends, hipStream_t s)
+{
+  gv_context *h = L.h;
+  const size_t slice = shard_ends_slice(h, L.world);
+  int rc = shard_all_to_all(L, ends, h->sh_xchg, slice, s);
+  if (rc) return rc;
+  launch_or_slices(h->sh_xchg, ends + (size_t)L.rank * slice, slice, L.world, s);
   GV_HIP(hipGetLastError());
+  return GV_OK;
+}
+
+// exchange 2 (this rank's part): band `rank` of everyone's free-cell bitmaps OR-ed into set p
+int shard_or_free_band(const ShardLink &L, int p, const uint32_t *packed, hipStream_t s)
+{
+  gv_context *h = L.h;
+  const size_t chunk = free_band_chunk_words(h->nxw, h->nx_pad, h->ny_pad, L.world);
+  uint32_t *recv = h->sh_xchg + chunk * (size_t)L.world;
+  int rc = shard_all_to_all(L, packed, recv, chunk, s);
+  if (rc) return rc;
+  launch_unpack_free_band(recv, L.world, chunk, L.rank, h->nxw, h->nx_pad, h->ny_pad, h->x_freeN[p], h->x_freeT[p], s);
+  GV_HIP(hipGetLastError());
+  return GV_OK;
+}
+
+int sharded_tail(gv_context *h, const Rect *rects, int32_t n_rects)
+{
+  hipStream_t s = h->stream;
+  const DetSet &D = h->det[h->det_cur];
+  const bool do_ray = D.flags & GV_FRAME_RAYMARCH, keep_counts = D.flags & GV_FRAME_KEEP_COUNTS;
+  ShardLink L{h, h->rank, h->world};
+  int rc = ensure_shard_scratch(h, h->world);
+  if (rc) return rc;
+  const size_t slice = shard_ends_slice(h, h->world);
+  // 1. complete end bitmaps everywhere
+  if ((rc = shard_or_ends_slice(L, h->x_ends[0], s))) return rc;
+  GV_NCCL(ncclAllGather(h->x_ends[0] + (size_t)h->rank * slice, h->x_ends[0], slice, ncclUint32, h->comm, s));
+  // 2. this rank's share of the ray stage, then the free cells of its band from everyone
+  if (do_ray && (rc = enqueue_sectors(h, 0, h->rank, h->world, s))) return rc;
+  const size_t chunk = free_band_chunk_words(h->nxw, h->nx_pad, h->ny_pad, h->world);
+  launch_pack_free_bands(h->x_freeN[0], h->x_freeT[0], h->nxw, h->nx_pad, h->ny_pad, h->world, chunk, h->sh_xchg, s);
+  GV_HIP(hipGetLastError());
+  if ((rc = shard_or_free_band(L, 0, h->sh_xchg, s))) return rc;
+  // 3. grid pass on the band, packed bands to everyone: band r sits at data[G - e_r, G - b_r)
   int32_t y0, y1;
-  band_rows(h, h->rank, y0, y1);
-  if (ny % h->world == 0) {
-    const size_t cnt = G / (size_t)h->world;
-    GV_NCCL(ncclReduceScatter(h->hits, h->hits + (size_t)h->rank * cnt, cnt, ncclInt32, ncclSum, h->comm, h->stream));
-    GV_NCCL(ncclReduceScatter(miss, miss + (size_t)h->rank * cnt, cnt, ncclUint8, ncclMax, h->comm, h->stream));
-  } else {   // bands are not equal sized: reduce everything everywhere
-    GV_NCCL(ncclAllReduce(h->hits, h->hits, G, ncclInt32, ncclSum, h->comm, h->stream));
-    GV_NCCL(ncclAllReduce(miss, miss, G, ncclUint8, ncclMax, h->comm, h->stream));
-  }
-  launch_band_hit_bitmap(h->hits, nx, h->ny_pad, y0, y1, h->x_hitN[0], h->stream);
-  FinalizeTileArgs t{};
-  t.g = h->g;
-  t.log_odds = h->log_odds;
-  t.occupancy = h->occupancy;
-  t.occ_i8 = h->occ_i8;
-  t.rects = h->x_rects[0];
-  t.n_rects = n_rects;
-  t.hitN = h->x_hitN[0];
-  t.nxw = h->nxw;
-  t.ny_pad = h->ny_pad;
-  t.missN = miss;
-  t.missT = missT;
-  t.counts = true;
-  t.zero = false;
-  t.use_missT = false;
-  t.y_begin = y0;
-  t.y_end = y1;
-  launch_finalize_tiles(t, h->stream);
-  GV_HIP(hipGetLastError());
-  GV_HIP(hipMemsetAsync(miss, 0, G, h->stream));
-  // packed bands to everyone: band r sits at data[G - e_r, G - b_r) (toOccupancyGrid order)
-  ncclResult_t gr = ncclGroupStart(), first_err = ncclSuccess;
-  if (gr != ncclSuccess) first_err = gr;
+  shard_band_rows(h->rank, h->world, h->g.ny, h->ny_pad, y0, y1);
+  if ((rc = enqueue_grid_pass(h, 0, rects, n_rects, true, y0, y1, s))) return rc;
+  const size_t G = (size_t)h->g.G;
+  ncclResult_t first_err = ncclGroupStart();
   for (int r = 0; r < h->world && first_err == ncclSuccess; ++r) {
     int32_t r0, r1;
-    band_rows(h, r, r0, r1);
-    const size_t b = (size_t)r0 * nx, e = (size_t)r1 * nx;
+    shard_band_rows(r, h->world, h->g.ny, h->ny_pad, r0, r1);
+    const size_t b = (size_t)r0 * h->g.nx, e = (size_t)r1 * h->g.nx;
     if (e > b) {
-      const ncclResult_t br = ncclBroadcast(h->occ_i8 + (G - e), h->occ_i8 + (G - e), e - b, ncclInt8, r, h->comm, h->stream);
+      const ncclResult_t br = ncclBroadcast(h->occ_i8 + (G - e), h->occ_i8 + (G - e), e - b, ncclInt8, r, h->comm, s);
       if (br != ncclSuccess) first_err = br;
     }
   }
-  gr = ncclGroupEnd();   // always closed, also on the error path
-  if (first_err == ncclSuccess && gr != ncclSuccess) first_err = gr;
+  const ncclResult_t ge = ncclGroupEnd();   // always closed, also on the error path
+  if (first_err == ncclSuccess) first_err = ge;
   if (first_err != ncclSuccess) {
     h->err = std::string("sharded band exchange -> ") + ncclGetErrorString(first_err);
     return GV_ERR_RCCL;
   }
-  h->have_hits = false;     // hits[] holds this rank's band of the sum only
-  h->have_miss = false;
-  h->have_cell_idx = false;
-  h->have_bbox_id = (h->det[h->det_cur].flags & GV_FRAME_BBOX_TEST) != 0;
+  // hit counts are per-rank partial sums; the total only on request
+  if (keep_counts) GV_NCCL(ncclAllReduce(h->hits, h->hits, G, ncclInt32, ncclSum, h->comm, s));
+  h->have_hits = keep_counts;
+  h->have_miss = false;    // free-cell bitmaps are complete for this rank's band only
   return GV_OK;
 }
 
@@ -980,12 +1065,10 @@ int gv_create(gv_handle *out, uint8_t grid_x, uint8_t grid_y, double resolution,
   const bool sectors = h->tile_path && !h->force_simple;
   const int nsets_alloc = sectors ? gv_context::kSets : 1;
   for (int k = 0; k < nsets_alloc; ++k) {
-    GV_C(hipMalloc(reinterpret_cast<void **>(&h->x_miss[k]), G + 16));
-    GV_C(hipMemsetAsync(h->x_miss[k], 0, G + 16, h->stream));
     GV_C(hipMalloc(reinterpret_cast<void **>(&h->x_stats[k]), kMaxStatSlots * 2 * sizeof(unsigned long long)));
     GV_C(hipMemsetAsync(h->x_stats[k], 0, kMaxStatSlots * 2 * sizeof(unsigned long long), h->stream));
   }
-  // end bitmaps: padded to whole binning tiles, so that every word belongs to exactly one tile
+  // bitmaps: padded to whole binning tiles, so that every word belongs to exactly one tile
   h->nx_pad = kBinTile * ((g.nx + kBinTile - 1) / kBinTile);
   h->ny_pad = kBinTile * ((g.ny + kBinTile - 1) / kBinTile);
   h->nxw = h->nx_pad / 32;
@@ -994,18 +1077,21 @@ int gv_create(gv_handle *out, uint8_t grid_x, uint8_t grid_y, double resolution,
   h->tiles_y = h->ny_pad / kBinTile;
   h->n_tiles = h->tiles_x * h->tiles_y;
   if (sectors) {
-    const size_t nN = (size_t)h->ny_pad * h->nxw + 4, nT = (size_t)h->nx_pad * h->nyw + 4;
+    h->bmN_words = (size_t)h->ny_pad * h->nxw;   // multiples of 4 words (pads are multiples of 128)
+    h->bmT_words = (size_t)h->nx_pad * h->nyw;
+    h->ends_words = 2 * (h->bmN_words + h->bmT_words);
     for (int k = 0; k < gv_context::kSets; ++k) {
-      GV_C(hipMalloc(reinterpret_cast<void **>(&h->x_missT[k]), G + 16));
-      GV_C(hipMemsetAsync(h->x_missT[k], 0, G + 16, h->stream));
-      GV_C(hipMalloc(reinterpret_cast<void **>(&h->x_hitN[k]), nN * sizeof(uint32_t)));
-      GV_C(hipMalloc(reinterpret_cast<void **>(&h->x_clipN[k]), nN * sizeof(uint32_t)));
-      GV_C(hipMalloc(reinterpret_cast<void **>(&h->x_hitT[k]), nT * sizeof(uint32_t)));
-      GV_C(hipMalloc(reinterpret_cast<void **>(&h->x_clipT[k]), nT * sizeof(uint32_t)));
-      GV_C(hipMemsetAsync(h->x_hitN[k], 0, nN * sizeof(uint32_t), h->stream));
-      GV_C(hipMemsetAsync(h->x_clipN[k], 0, nN * sizeof(uint32_t), h->stream));
-      GV_C(hipMemsetAsync(h->x_hitT[k], 0, nT * sizeof(uint32_t), h->stream));
-      GV_C(hipMemsetAsync(h->x_clipT[k], 0, nT * sizeof(uint32_t), h->stream));
+      // + slack: the sharded exchange pads the buffer to `world` equal slices
+      GV_C(hipMalloc(reinterpret_cast<void **>(&h->x_ends[k]), (h->ends_words + 1024) * sizeof(uint32_t)));
+      GV_C(hipMemsetAsync(h->x_ends[k], 0, (h->ends_words + 1024) * sizeof(uint32_t), h->stream));
+      h->x_hitN[k] = h->x_ends[k];
+      h->x_clipN[k] = h->x_hitN[k] + h->bmN_words;
+      h->x_hitT[k] = h->x_clipN[k] + h->bmN_words;
+      h->x_clipT[k] = h->x_hitT[k] + h->bmT_words;
+      GV_C(hipMalloc(reinterpret_cast<void **>(&h->x_free[k]), (h->bmN_words + h->bmT_words + 16) * sizeof(uint32_t)));
+      GV_C(hipMemsetAsync(h->x_free[k], 0, (h->bmN_words + h->bmT_words + 16) * sizeof(uint32_t), h->stream));
+      h->x_freeN[k] = h->x_free[k];
+      h->x_freeT[k] = h->x_free[k] + h->bmN_words;
     }
     for (int k = 0; k < 2; ++k) {
       GV_C(hipMalloc(reinterpret_cast<void **>(&h->bin_total[k]), (size_t)h->n_tiles * sizeof(uint32_t)));
@@ -1014,9 +1100,11 @@ int gv_create(gv_handle *out, uint8_t grid_x, uint8_t grid_y, double resolution,
     GV_C(hipMalloc(reinterpret_cast<void **>(&h->bin_done), (size_t)h->n_tiles * sizeof(uint32_t)));
     GV_C(hipMemsetAsync(h->bin_done, 0, (size_t)h->n_tiles * sizeof(uint32_t), h->stream));
   } else {
-    // generic path: byte flags of clipped ray ends + the compacted ray list
+    // generic path: byte flags of clipped ray ends and of free cells + the compacted ray list
     GV_C(hipMalloc(reinterpret_cast<void **>(&h->clip_end), G + 16));
     GV_C(hipMemsetAsync(h->clip_end, 0, G + 16, h->stream));
+    GV_C(hipMalloc(reinterpret_cast<void **>(&h->miss8), G + 16));
+    GV_C(hipMemsetAsync(h->miss8, 0, G + 16, h->stream));
     GV_C(hipMalloc(reinterpret_cast<void **>(&h->ray_list), G * sizeof(uint32_t)));
   }
   for (auto &e : h->ev) GV_C(hipEventCreate(&e));
@@ -1039,7 +1127,7 @@ int gv_destroy(gv_handle h)
   for (hipStream_t s : {h->stream_copy, h->stream, h->stream2, h->stream3})
     if (s) (void)hipStreamSynchronize(s);
   if (h->comm) { ncclCommDestroy(h->comm); h->comm = nullptr; }
-  void *bufs[] = {h->log_odds, h->occupancy, h->occ_i8, h->hits, h->clip_end, h->ray_list, h->ray_count, h->scratch_i32,
+  void *bufs[] = {h->log_odds, h->occupancy, h->occ_i8, h->hits, h->clip_end, h->miss8, h->sh_xchg, h->ray_list, h->ray_count, h->scratch_i32,
                   h->bin_keys, h->bin_tab, h->bin_total[0], h->bin_total[1], h->bin_done, h->bin_scratch,
                   h->tx, h->ty, h->tz, h->cell_idx, h->bbox_id, h->d_vout, h->d_pts, h->knn_partial, h->d_depths,
                   h->d_knn_d2, h->d_idx, h->d_segof, h->d_segstart, h->gx, h->gy, h->gz, h->d_keep, h->d_planes,
@@ -1050,7 +1138,7 @@ int gv_destroy(gv_handle h)
   if (h->d_dbg) (void)hipFree(h->d_dbg);
 #endif
   for (int k = 0; k < gv_context::kSets; ++k) {
-    void *xs[] = {h->x_hitN[k], h->x_clipN[k], h->x_hitT[k], h->x_clipT[k], h->x_rects[k], h->x_miss[k], h->x_missT[k], h->x_stats[k]};
+    void *xs[] = {h->x_ends[k], h->x_free[k], h->x_rects[k], h->x_stats[k]};
     for (void *p : xs)
       if (p) (void)hipFree(p);
   }
@@ -1662,9 +1750,10 @@ int gv_get_miss(gv_handle h, int32_t *out)
   int rc = use_device(h);
   if (rc) return rc;
   if (sector_path(h))
-    launch_miss_to_i32(h->x_miss[h->last_set], h->x_missT[h->last_set], h->g.nx, h->g.ny, h->scratch_i32, h->stream);
+    launch_miss_to_i32(h->x_freeN[h->last_set], h->x_freeT[h->last_set], h->g.nx, h->g.ny, h->nx_pad, h->ny_pad,
+                       h->scratch_i32, h->stream);
   else
-    launch_u8_to_i32(h->x_miss[0], h->scratch_i32, (size_t)h->g.G, h->stream);
+    launch_u8_to_i32(h->miss8, h->scratch_i32, (size_t)h->g.G, h->stream);
   GV_HIP(hipGetLastError());
   return copy_out(h, out, h->scratch_i32, (size_t)h->g.G * sizeof(int32_t));
 }
@@ -2079,11 +2168,88 @@ int gv_process_frame_sharded(gv_handle h, const gv_frame_desc *desc)
   GV_CATCH
 }
 
+// Test hook: the sharded frame for every rank of a `world`-GPU job, run on THIS device with the RCCL
+// exchanges replaced by device copies (ShardLink emulation).  The resident cloud is the whole cloud;
+// rank r takes points [n*r/world, n*(r+1)/world).  Every piece the ranks would run -- binning of a
+// slice, OR of the end-bitmap slices, every world-th sector workgroup, band packing, band OR, band grid
+// pass -- runs with its real (rank, world); the bands land in the one resident grid.
+int gv_debug_frame_sharded_emulated(gv_handle h, const gv_frame_desc *desc, int32_t world)
+{
+  if (!h || !desc || world < 1 || world > 16) return GV_ERR_BAD_ARG;
+  if (!sector_path(h)) return GV_ERR_STATE;
+  int rc = gv_frame_set_detections(h, desc);
+  if (rc) return rc;
+  GV_TRY
+  if ((rc = use_device(h))) return rc;
+  DetSet &D = h->det[h->det_cur];
+  const uint32_t fl = D.flags;
+  const bool do_bin = fl & GV_FRAME_BIN, do_ray = fl & GV_FRAME_RAYMARCH, do_bbox = fl & GV_FRAME_BBOX_TEST;
+  const bool keep_cell = fl & GV_FRAME_KEEP_CELL_IDX;
+  if ((rc = check_frame_flags(h, fl))) return rc;
+  if (!do_bin) return GV_ERR_STATE;
+  if ((rc = ensure_shard_scratch(h, world))) return rc;
+  hipStream_t s = h->stream;
+  const size_t slice = shard_ends_slice(h, world), Ep = slice * (size_t)world;
+  const size_t chunk = free_band_chunk_words(h->nxw, h->nx_pad, h->ny_pad, world);
+  std::vector<uint32_t *> ends((size_t)world, nullptr), packs((size_t)world, nullptr);
+  uint32_t *comb = nullptr;
+  auto cleanup = [&]() {
+    for (uint32_t *q : ends) if (q) (void)hipFree(q);
+    for (uint32_t *q : packs) if (q) (void)hipFree(q);
+    if (comb) (void)hipFree(comb);
+  };
+  auto body = [&]() -> int {
+    GV_HIP(hipMalloc(reinterpret_cast<void **>(&comb), Ep * sizeof(uint32_t)));
+    for (int r = 0; r < world; ++r) {
+      GV_HIP(hipMalloc(reinterpret_cast<void **>(&ends[r]), Ep * sizeof(uint32_t)));
+      GV_HIP(hipMalloc(reinterpret_cast<void **>(&packs[r]), chunk * (size_t)world * sizeof(uint32_t)));
+    }
+    Rect *rects = h->x_rects[0];
+    const int32_t n_rects = enqueue_rects(h, D, rects, s);
+    int rc2;
+    for (int r = 0; r < world; ++r) {   // every rank bins its slice
+      const size_t lo = h->n * (size_t)r / (size_t)world, hi = h->n * (size_t)(r + 1) / (size_t)world;
+      if ((rc2 = enqueue_binning(h, D, 0, lo, hi - lo, keep_cell, do_ray, do_bbox, false, s, nullptr))) return rc2;
+      GV_HIP(hipMemcpyAsync(ends[r], h->x_ends[0], Ep * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+    }
+    for (int q = 0; q < world; ++q) {   // exchange 1: rank q ORs slice q; the all-gather is the union of the slices
+      ShardLink L{h, q, world, ends.data()};
+      if ((rc2 = shard_or_ends_slice(L, comb, s))) return rc2;
+    }
+    GV_HIP(hipMemcpyAsync(h->x_ends[0], comb, Ep * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+    for (int r = 0; r < world; ++r) {   // every rank's share of the ray stage, packed by band
+      GV_HIP(hipMemsetAsync(h->x_free[0], 0, (h->bmN_words + h->bmT_words) * sizeof(uint32_t), s));
+      if (do_ray && (rc2 = enqueue_sectors(h, 0, r, world, s))) return rc2;
+      launch_pack_free_bands(h->x_freeN[0], h->x_freeT[0], h->nxw, h->nx_pad, h->ny_pad, world, chunk, packs[r], s);
+      GV_HIP(hipGetLastError());
+    }
+    for (int q = 0; q < world; ++q) {   // exchange 2 + grid pass of band q
+      ShardLink L{h, q, world, packs.data()};
+      if ((rc2 = shard_or_free_band(L, 0, nullptr, s))) return rc2;
+      int32_t y0, y1;
+      shard_band_rows(q, world, h->g.ny, h->ny_pad, y0, y1);
+      if ((rc2 = enqueue_grid_pass(h, 0, rects, n_rects, true, y0, y1, s))) return rc2;
+    }
+    GV_HIP(hipStreamSynchronize(s));
+    return GV_OK;
+  };
+  rc = body();
+  (void)hipStreamSynchronize(s);
+  cleanup();
+  h->last_set = 0;
+  h->have_hits = false;
+  h->have_miss = false;
+  h->have_cell_idx = do_bin && keep_cell;
+  h->have_bbox_id = do_bbox;
+  return rc;
+  GV_CATCH
+}
+
 int gv_comm_band(gv_handle h, int64_t *begin, int64_t *end)
 {
   if (!h) return GV_ERR_BAD_ARG;
   int32_t y0, y1;
-  band_rows(h, h->rank, y0, y1);
+  shard_band_rows(h->rank, h->world, h->g.ny, h->ny_pad, y0, y1);
   if (begin) *begin = (int64_t)y0 * h->g.nx;
   if (end) *end = (int64_t)y1 * h->g.nx;
   return GV_OK;

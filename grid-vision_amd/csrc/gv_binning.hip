@@ -339,7 +339,10 @@ __global__ void __launch_bounds__(kTileThreads) k_bin_tiles(BinTileArgs a)
     {
       const int gw = (x0 >> 5) + wq, gy = y0 + l;
       unsigned *dN = which ? a.clipN : a.hitN;
-      if (gw < a.nxw && gy < a.ny_pad) dN[(size_t)gw * a.ny_pad + gy] = bits[which][l][wq];
+      if (gw < a.nxw && gy < a.ny_pad) {
+        dN[(size_t)gw * a.ny_pad + gy] = bits[which][l][wq];
+        if (which == 0 && a.freeN) a.freeN[(size_t)gw * a.ny_pad + gy] = 0u;   // this set's ray stage starts from no free cells
+      }
     }
     {
       unsigned wv = 0;
@@ -347,7 +350,10 @@ __global__ void __launch_bounds__(kTileThreads) k_bin_tiles(BinTileArgs a)
       for (int r = 0; r < 32; ++r) wv |= ((bits[which][32 * wq + r][l >> 5] >> (l & 31)) & 1u) << r;
       const int gw = (y0 >> 5) + wq, gx = x0 + l;
       unsigned *dT = which ? a.clipT : a.hitT;
-      if (gw < a.nyw && gx < a.nx_pad) dT[(size_t)gw * a.nx_pad + gx] = wv;
+      if (gw < a.nyw && gx < a.nx_pad) {
+        dT[(size_t)gw * a.nx_pad + gx] = wv;
+        if (which == 0 && a.freeT) a.freeT[(size_t)gw * a.nx_pad + gx] = 0u;
+      }
     }
   }
 }

@@ -117,26 +117,14 @@ struct BinTileArgs {
   uint32_t *scratch;            // [max_slots][kBinSplitMax][kBinTileCells + 512] partial tiles
   uint32_t split_keys, max_slots;
   int32_t *hits;                // G int32 (every cell written) or null
-  uint32_t *hitN, *clipN, *hitT, *clipT;   // end bitmaps (layout: BitmapArgs), every word written
+  uint32_t *hitN, *clipN, *hitT, *clipT;   // end bitmaps (layout: gv_raysector.hip), every word written
+  uint32_t *freeN, *freeT;                 // free-cell bitmaps of the same buffer set: zeroed here (or null)
   int32_t nxw, nyw, nx_pad, ny_pad;
 };
 // n_helpers >= n / split_keys extra workgroups serve the shares 1.. of crowded tiles
 void launch_bin_tiles(const BinTileArgs &a, uint32_t n_helpers, hipStream_t s);
 
 // ---- sector/gather ray stage + tile grid pass (gv_raysector.hip) ----
-struct BitmapArgs {
-  int32_t nx, ny;
-  int32_t *hits;          // G   int32 counts (cleared here when zero_hits) -- used when hit8 == nullptr
-  uint8_t *hit8;          // G   byte flags (cleared here when zero_hits), or nullptr
-  uint8_t *clip_end;      // G   (always cleared here)
-  uint32_t *hitN, *clipN; // bits along x; word(x>>5, y) at (x>>5)*ny_pad + y
-  uint32_t *hitT, *clipT; // bits along y; word(y>>5, x) at (y>>5)*nx_pad + x
-  int32_t nxw, nyw;       // words along x / y (even)
-  int32_t nx_pad, ny_pad; // nx, ny rounded up to 64
-  bool zero_hits;
-};
-void launch_build_bitmaps(const BitmapArgs &a, hipStream_t s);
-
 struct SectorArgs {
   GridParams g;
   RayOrigin org;
@@ -149,9 +137,10 @@ struct SectorArgs {
   int32_t reorder;        // 1: longest octants and the rational-gap sectors (0, S/2-1, S/2, S-1) first
   const uint32_t *hitN, *clipN, *hitT, *clipT;
   int32_t nxw, nyw, nx_pad, ny_pad;
-  uint8_t *missN;         // G bytes, [y][x]
-  uint8_t *missT;         // G bytes, [x][y]
+  uint32_t *freeN;        // free-cell bitmap, bits along x (written for y-major octants); same layout as hitN
+  uint32_t *freeT;        // free-cell bitmap, bits along y (written for x-major octants); same layout as hitT
   unsigned long long *stats;
+  int32_t wg_first, wg_stride;   // this launch runs workgroups wg_first, wg_first + wg_stride, ... of the dispatch order
   int32_t flat_k;         // cost ratio exact-cell evaluation : marched cell for the choice beyond T (0: always march when possible)
   int32_t ablate;         // timing experiments only: 2 skip gather, 4 skip flush, 8/16/32 early exits
   unsigned long long *dbg; // diagnostic phase stamps, 16 per workgroup (null in production)
@@ -165,19 +154,25 @@ struct FinalizeTileArgs {
   int8_t *occ_i8;
   const Rect *rects;
   int32_t n_rects;
-  const uint32_t *hitN;
-  int32_t nxw, ny_pad;
-  uint8_t *missN, *missT;
+  const uint32_t *hitN;            // hit bitmap (bits along x)
+  const uint32_t *freeN, *freeT;   // free-cell bitmaps of the ray stage (N | T)
+  int32_t nx_pad, ny_pad;
   bool counts;            // apply the hit/miss rule
-  bool zero;              // clear the miss grids while reading them
-  bool use_missT;         // false: missT was already folded into missN (multi-GPU path)
   int32_t y_begin, y_end; // rows to finalise ([0, ny) on one GPU)
 };
 void launch_finalize_tiles(const FinalizeTileArgs &a, hipStream_t s);
-void launch_merge_miss(uint8_t *mN, uint8_t *mT, int nx, int ny, hipStream_t s);
-void launch_band_hit_bitmap(const int32_t *hits, int nx, int ny_pad, int y0, int y1, uint32_t *hitN, hipStream_t s);
-void launch_band_hit_bitmap8(const uint8_t *hit8, int nx, int ny_pad, int y0, int y1, uint32_t *hitN, hipStream_t s);
-void launch_miss_to_i32(const uint8_t *mN, const uint8_t *mT, int nx, int ny, int32_t *out, hipStream_t s);
+void launch_miss_to_i32(const uint32_t *freeN, const uint32_t *freeT, int nx, int ny, int nx_pad, int ny_pad,
+                        int32_t *out, hipStream_t s);
+
+// ---- frame sharded by points over several GPUs: OR-exchange helpers (gv_shard.hip) ----
+void launch_or_slices(const uint32_t *src, uint32_t *dst, size_t count_words, int world, hipStream_t s);
+size_t free_band_chunk_words(int nxw, int nx_pad, int ny_pad, int world);
+void launch_pack_free_bands(const uint32_t *fN, const uint32_t *fT, int nxw, int nx_pad, int ny_pad, int world,
+                            size_t chunk, uint32_t *out, hipStream_t s);
+void launch_unpack_free_band(const uint32_t *in, int world, size_t chunk, int rank, int nxw, int nx_pad, int ny_pad,
+                             uint32_t *fN, uint32_t *fT, hipStream_t s);
+// rows [y0, y1) rank `rank` of `world` finalises: whole 64-row blocks of the padded grid, clipped to ny
+void shard_band_rows(int rank, int world, int ny, int ny_pad, int32_t &y0, int32_t &y1);
 
 // ---- kNN depth + radius outlier counts (gv_knn_pca.hip) ----
 struct Cand2 {

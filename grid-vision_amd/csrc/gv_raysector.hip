@@ -24,122 +24,13 @@
 namespace gv {
 
 // ------------------------------------------------------------ bitmaps ------
-// hit/clip end flags as bitmaps in both orientations, with the 32-bit WORDS stored
-// transposed so that a wavefront scanning 64 consecutive wedge columns reads 64
-// adjacent words:
+// End flags (hit / clipped ray end) and free-cell flags live in bitmaps of two orientations, with the
+// 32-bit WORDS stored transposed so that a wavefront scanning 64 consecutive wedge columns reads (or
+// ORs into) 64 adjacent words:
 //   N: bits run along x, word(x>>5, y) at  (x>>5)*ny_pad + y   (y-major octants)
 //   T: bits run along y, word(y>>5, x) at  (y>>5)*nx_pad + x   (x-major octants)
-// One 64x64 tile per workgroup; also clears the per-frame clip bytes (and the
-// hit counts unless the caller keeps them).
-__global__ void __launch_bounds__(256) k_build_bitmaps(BitmapArgs a)
-{
-  __shared__ unsigned long long rows[2][64];   // [0] hit, [1] clip
-  const int x0 = blockIdx.x * 64, y0 = blockIdx.y * 64;
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int x = x0 + lane;
-#pragma unroll 4
-  for (int r = 0; r < 16; ++r) {
-    const int yl = wv * 16 + r;
-    const int y = y0 + yl;
-    const bool valid = (x < a.nx) && (y < a.ny);
-    int h = 0;
-    unsigned c = 0;
-    if (valid) {
-      const size_t cell = (size_t)y * a.nx + x;
-      h = a.hits[cell];
-      c = a.clip_end[cell];
-      if (c) a.clip_end[cell] = 0;
-      if (a.zero_hits && h) a.hits[cell] = 0;
-    }
-    const unsigned long long mh = __ballot(h > 0);
-    const unsigned long long mc = __ballot(c != 0);
-    if (lane == 0) {
-      rows[0][yl] = mh;
-      rows[1][yl] = mc;
-    }
-  }
-  __syncthreads();
-  const int t = threadIdx.x;
-  {
-    // N words: thread (which, half, yl)
-    const int which = t >> 7, half = (t >> 6) & 1, yl = t & 63;
-    unsigned *dst = which ? a.clipN : a.hitN;
-    dst[(size_t)(2 * blockIdx.x + half) * a.ny_pad + (y0 + yl)] = (unsigned)(rows[which][yl] >> (32 * half));
-  }
-  {
-    // T words: thread (which, half, xl) gathers bit xl of rows 32*half .. 32*half+31
-    const int which = t >> 7, half = (t >> 6) & 1, xl = t & 63;
-    unsigned w = 0;
-#pragma unroll
-    for (int r = 0; r < 32; ++r) w |= (unsigned)((rows[which][half * 32 + r] >> xl) & 1ull) << r;
-    unsigned *dst = which ? a.clipT : a.hitT;
-    dst[(size_t)(2 * blockIdx.y + half) * a.nx_pad + (x0 + xl)] = w;
-  }
-}
-
-// Byte-flag variant (production frame): hit8/clip_end hold 0/1 bytes, nx % 4 == 0 (tile path),
-// so one lane takes 4 cells per 32-bit load: 16 lanes per tile row, 4 rows per wavefront load.
-// Nibbles go through LDS (one byte per 4 cells), then the same N / T word assembly.
-__device__ __forceinline__ unsigned nibble_of(unsigned w)   // bit k = byte k of w is non-zero
-{
-  return ((w & 0xFFu) ? 1u : 0u) | ((w & 0xFF00u) ? 2u : 0u) | ((w & 0xFF0000u) ? 4u : 0u) | ((w & 0xFF000000u) ? 8u : 0u);
-}
-__device__ __forceinline__ unsigned pack_nibbles(unsigned w)   // 4 nibble-bytes -> 16 bits
-{
-  return (w & 0xFu) | ((w >> 4) & 0xF0u) | ((w >> 8) & 0xF00u) | ((w >> 12) & 0xF000u);
-}
-
-__global__ void __launch_bounds__(256) k_build_bitmaps8(BitmapArgs a)
-{
-  // 128 (x) by 32 (y) cells per workgroup: a tile row is one full 128-byte line of each flag map
-  // (64-wide tiles fetched every line twice), 4 N words per row, one T word per column
-  __shared__ unsigned nib[2][32][8];   // [hit|clip][row][32 nibble bytes]
-  const int x0 = blockIdx.x * 128, y0 = blockIdx.y * 32;
-  const int t = threadIdx.x;
-  unsigned char *nibb = reinterpret_cast<unsigned char *>(&nib[0][0][0]);
-#pragma unroll
-  for (int it = 0; it < 4; ++it) {
-    const int idx = it * 256 + t;
-    const int yl = idx >> 5, w = idx & 31;
-    const int y = y0 + yl, x = x0 + 4 * w;
-    unsigned hw = 0, cw = 0;
-    if (x < a.nx && y < a.ny) {
-      const size_t cell = (size_t)y * a.nx + x;
-      unsigned *hp = reinterpret_cast<unsigned *>(a.hit8 + cell);
-      unsigned *cp = reinterpret_cast<unsigned *>(a.clip_end + cell);
-      hw = *hp;
-      cw = *cp;
-      if (cw) *cp = 0;
-      if (a.zero_hits && hw) *hp = 0;
-    }
-    nibb[(0 * 32 + yl) * 32 + w] = (unsigned char)nibble_of(hw);
-    nibb[(1 * 32 + yl) * 32 + w] = (unsigned char)nibble_of(cw);
-  }
-  __syncthreads();
-  {
-    // N words: thread (which, yl, q): cells 32q .. 32q+31 of row yl
-    const int which = t >> 7, yl = (t >> 2) & 31, q = t & 3;
-    const unsigned lo = pack_nibbles(nib[which][yl][2 * q]), hi = pack_nibbles(nib[which][yl][2 * q + 1]);
-    unsigned *dst = which ? a.clipN : a.hitN;
-    if (4 * (int)blockIdx.x + q < a.nxw) dst[(size_t)(4 * blockIdx.x + q) * a.ny_pad + (y0 + yl)] = lo | (hi << 16);
-  }
-  {
-    // T words: thread (which, xl) gathers bit xl of the 32 rows (y0 is a multiple of 32)
-    const int which = t >> 7, xl = t & 127;
-    const int sh = (xl >> 2) * 8 + (xl & 3);   // bit position inside the row's 8 nibble words
-    unsigned w = 0;
-#pragma unroll
-    for (int r = 0; r < 32; ++r) w |= ((nib[which][r][sh >> 5] >> (sh & 31)) & 1u) << r;
-    unsigned *dst = which ? a.clipT : a.hitT;
-    if (x0 + xl < a.nx_pad) dst[(size_t)blockIdx.y * a.nx_pad + (x0 + xl)] = w;
-  }
-}
-
-void launch_build_bitmaps(const BitmapArgs &a, hipStream_t s)
-{
-  if (a.hit8) hipLaunchKernelGGL(k_build_bitmaps8, dim3((a.nx_pad + 127) / 128, a.ny_pad / 32), dim3(256), 0, s, a);
-  else hipLaunchKernelGGL(k_build_bitmaps, dim3((a.nx + 63) / 64, (a.ny + 63) / 64), dim3(256), 0, s, a);
-}
+// nx_pad / ny_pad are multiples of 128.  The end bitmaps are written by the binning tile pass
+// (gv_binning.hip), which also zeroes the free-cell bitmaps of the buffer set it is about to use.
 
 // ------------------------------------------------ wavefront primitives (DPP) --
 // Cross-lane steps as DPP modifiers of VALU ops (gfx9: row_shr, wave_shl:1, row_bcast:15/31)
@@ -256,6 +147,8 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
   extern __shared__ __align__(16) unsigned char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
+  // position in the dispatch order: a multi-GPU rank runs every wg_stride-th workgroup
+  const int bid = A.wg_first + (int)blockIdx.x * A.wg_stride;
   // Dispatch order (workgroups start roughly in blockIdx order and the launch is ~2 rounds deep):
   // octants with the longest wedges first, and inside an octant the sectors next to the slopes
   // 0, 1/2, 1 first (they run longest).  Every octant has its own sector count: a short wedge
@@ -263,25 +156,25 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
   // fixed per-workgroup cost and no ends.
   int k_oct = 0;
 #pragma unroll
-  for (int k = 1; k < 8; ++k) k_oct += ((int)blockIdx.x >= (int)A.wg_base[k]) ? 1 : 0;
+  for (int k = 1; k < 8; ++k) k_oct += (bid >= (int)A.wg_base[k]) ? 1 : 0;
   const int o = A.reorder ? ((int)(A.oct_perm >> (3 * k_oct)) & 7) : k_oct;
   const int log2s = A.log2s_oct[o];
   const int S = 1 << log2s;
-  int s = (int)blockIdx.x - (int)A.wg_base[k_oct];
+  int s = bid - (int)A.wg_base[k_oct];
   if (A.reorder && S >= 8) {
     const int r = s;
     if (r < 4) s = (r == 0) ? 0 : (r == 1) ? (S >> 1) - 1 : (r == 2) ? S - 1 : (S >> 1);
     else s = (r - 4 < (S >> 1) - 2) ? r - 3 : r - 1;
   }
-  const int wg = blockIdx.x;   // diagnostics slot
+  const int wg = bid;   // diagnostics slot
   // a clipped ray that ends in the origin cell itself (a == 0, inclusive end)
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    const unsigned wbit = A.clipN[(size_t)(A.org.cx >> 5) * A.ny_pad + A.org.cy] >> (A.org.cx & 31);
-    if (wbit & 1u) A.missN[(size_t)A.org.cy * A.g.nx + A.org.cx] = 1;
+  if (bid == 0 && threadIdx.x == 0) {
+    const size_t wo = (size_t)(A.org.cx >> 5) * A.ny_pad + A.org.cy;
+    if ((A.clipN[wo] >> (A.org.cx & 31)) & 1u) atomicOr(&A.freeN[wo], 1u << (A.org.cx & 31));
   }
   const Oct oc = make_octant(o, A.g, A.org);
   if (oc.imax < 1) {
-    if (threadIdx.x == 0 && A.stats) { A.stats[2 * blockIdx.x] = 0; A.stats[2 * blockIdx.x + 1] = 0; }
+    if (threadIdx.x == 0 && A.stats) { A.stats[2 * bid] = 0; A.stats[2 * bid + 1] = 0; }
     return;
   }
   const int cap = A.cap;
@@ -473,7 +366,7 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
   stamp();   // 2: scan done
   if GV_ABL(16) return;   // timing experiment: + scan
   if (total == 0) {
-    if (tid == 0 && A.stats) { A.stats[2 * blockIdx.x] = 0; A.stats[2 * blockIdx.x + 1] = 0; }
+    if (tid == 0 && A.stats) { A.stats[2 * bid] = 0; A.stats[2 * bid + 1] = 0; }
     return;
   }
 
@@ -913,24 +806,29 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
     }
   }
 
-  // ---- flush the wedge's marks as bytes: N grid for x-major, T grid for y-major.  One byte per
-  // free cell: bit t of column i goes to base + t*step (32-bit offsets: the grids are < 2^31 bytes)
+  // ---- flush the wedge's marks into the free-cell bitmaps.  marks[i] is a run of cell bits along the
+  // minor axis of column i, i.e. a shifted (for the negative minor direction: mirrored) slice of at
+  // most two 32-bit words of the bitmap whose bits run along that axis: T (bits along y) for x-major
+  // octants, N (bits along x) for y-major ones.  Consecutive columns are consecutive words of the
+  // transposed word layout, so a wavefront ORs 256 contiguous bytes.  Neighbouring sectors share words:
+  // atomicOr (no return value).
   {
-    uint8_t *grid = oc.xmaj ? A.missN : A.missT;
-    const int pitch = oc.xmaj ? A.g.nx : A.g.ny;
-    const int step = oc.smin * pitch;
+    unsigned *bm = oc.xmaj ? A.freeT : A.freeN;
+    const unsigned pad = (unsigned)(oc.xmaj ? A.nx_pad : A.ny_pad);
     for (int i = tid; i <= (GV_ABL(4) ? -1 : oc.imax); i += NT) {
       unsigned w = marks[i];
       const int jlo = (2 * i * s + S) >> (log2s + 1);
       const int tmax = oc.jmaxo - jlo;                        // bits beyond it are outside the map
       if (tmax < 31) w &= (tmax < 0) ? 0u : ((2u << tmax) - 1u);
       if (!w) continue;
-      uint8_t *base = grid + ((oc_minor + oc.smin * jlo) * pitch + (oc_major + oc.smaj * i));
-      while (w) {
-        const int t = __ffs(w) - 1;
-        w &= w - 1;
-        base[t * step] = 1;
-      }
+      const int mb = oc_minor + oc.smin * jlo;                // minor coordinate of bit 0 of w
+      const int b0 = (oc.smin > 0) ? mb : mb - 31;            // minor coordinate of bit 0 of v
+      const unsigned v = (oc.smin > 0) ? w : __brev(w);
+      const int wi = b0 >> 5, sh = b0 & 31;                   // arithmetic shift: floor for b0 < 0
+      const unsigned lo = v << sh, hi = sh ? (v >> (32 - sh)) : 0u;
+      const unsigned col = (unsigned)(oc_major + oc.smaj * i);
+      if (lo) atomicOr(&bm[(unsigned)wi * pad + col], lo);    // set bits are in-map cells: wi >= 0 whenever lo != 0
+      if (hi) atomicOr(&bm[(unsigned)(wi + 1) * pad + col], hi);
     }
   }
   __syncthreads();
@@ -941,8 +839,8 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
     if (A.stats) {
       unsigned long long vsum = 0;
       for (int wv = 0; wv < NT / 64; ++wv) vsum += s_wvis[wv];
-      A.stats[2 * blockIdx.x] = (unsigned long long)total;
-      A.stats[2 * blockIdx.x + 1] = vsum;
+      A.stats[2 * bid] = (unsigned long long)total;
+      A.stats[2 * bid + 1] = vsum;
     }
   }
 }
@@ -958,12 +856,15 @@ void launch_ray_sectors(const SectorArgs &a, hipStream_t s)
   const size_t lds = sector_lds_bytes(a.cap, a.marks_words, a.log2m);
   const int imax = std::max(std::max(a.org.cx, a.g.nx - 1 - a.org.cx), std::max(a.org.cy, a.g.ny - 1 - a.org.cy));
   // every wedge column lives in a register slot of one thread: CH * 512 >= imax
+  const int total = a.wg_base[8];
+  if (a.wg_first >= total) return;
+  const int grid = (total - a.wg_first + a.wg_stride - 1) / a.wg_stride;
   if (imax <= 4 * kSecThreads)
-    hipLaunchKernelGGL(k_ray_sectors<4>, dim3(a.wg_base[8]), dim3(kSecThreads), lds, s, a);
+    hipLaunchKernelGGL(k_ray_sectors<4>, dim3(grid), dim3(kSecThreads), lds, s, a);
   else if (imax <= 8 * kSecThreads)
-    hipLaunchKernelGGL(k_ray_sectors<8>, dim3(a.wg_base[8]), dim3(kSecThreads), lds, s, a);
+    hipLaunchKernelGGL(k_ray_sectors<8>, dim3(grid), dim3(kSecThreads), lds, s, a);
   else
-    hipLaunchKernelGGL(k_ray_sectors<16>, dim3(a.wg_base[8]), dim3(kSecThreads), lds, s, a);
+    hipLaunchKernelGGL(k_ray_sectors<16>, dim3(grid), dim3(kSecThreads), lds, s, a);
 }
 
 // ------------------------------------------------------ tile grid pass -----
@@ -1002,13 +903,13 @@ __device__ __forceinline__ float cell_update_t(float l, int k, bool counts, bool
   return l;
 }
 
-// One 64x64 tile per workgroup.  Requires nx % 4 == 0.  Reads the hit bitmap (N),
-// the miss bytes (N) and the transposed miss bytes (T, through an LDS transpose);
-// clears both miss grids for the next frame.
+// One 64x64 tile per workgroup.  Requires nx % 4 == 0.  Per cell: 4 B log-odds in, 4 + 4 + 1 B out;
+// hit and free-space flags come from the bitmaps (N: one word per 32 cells of a row; T: bits run
+// along y, a thread's four cells are four consecutive words = one 16-byte load).  Nothing is cleared
+// here: the binning tile pass rewrites / zeroes every bitmap word of the set it is about to use.
 template <bool COUNTS>
 __global__ void __launch_bounds__(256) k_finalize_tiles(FinalizeTileArgs a)
 {
-  __shared__ unsigned char tileT[64][68];
   __shared__ Rect s_rects[64];
   __shared__ int s_nr;
   const int x0 = blockIdx.x * 64, y0 = a.y_begin + blockIdx.y * 64;
@@ -1024,31 +925,6 @@ __global__ void __launch_bounds__(256) k_finalize_tiles(FinalizeTileArgs a)
       if (k < 64) s_rects[k] = R;
     }
   }
-  if (COUNTS && a.use_missT) {
-    // missT rows are x; each holds 64 contiguous y bytes of this tile
-    for (int t = tid; t < 64 * 16; t += 256) {
-      const int xr = t >> 4, wq = t & 15;
-      const int x = x0 + xr, y = y0 + wq * 4;
-      unsigned v = 0;
-      if (x < a.g.nx && y < a.g.ny) {   // ny % 4 == 0 is not required: guard per byte below
-        const size_t off = (size_t)x * a.g.ny + y;
-        if (y + 3 < a.g.ny && (off & 3) == 0) {
-          v = *reinterpret_cast<const unsigned *>(a.missT + off);
-          if (v && a.zero) *reinterpret_cast<unsigned *>(a.missT + off) = 0u;
-        } else {
-          for (int k = 0; k < 4 && y + k < a.g.ny; ++k) {
-            const unsigned b = a.missT[off + k];
-            v |= b << (8 * k);
-            if (b && a.zero) a.missT[off + k] = 0;
-          }
-        }
-      }
-      tileT[xr][wq * 4 + 0] = (unsigned char)(v & 0xff);
-      tileT[xr][wq * 4 + 1] = (unsigned char)((v >> 8) & 0xff);
-      tileT[xr][wq * 4 + 2] = (unsigned char)((v >> 16) & 0xff);
-      tileT[xr][wq * 4 + 3] = (unsigned char)(v >> 24);
-    }
-  }
   __syncthreads();
   const int nr = min(s_nr, 64);
   const bool overflow = s_nr > 64;
@@ -1061,11 +937,14 @@ __global__ void __launch_bounds__(256) k_finalize_tiles(FinalizeTileArgs a)
     if (x >= a.g.nx || y >= a.y_end) continue;
     const size_t c = (size_t)y * a.g.nx + x;
     float4 l4 = *reinterpret_cast<const float4 *>(a.log_odds + c);
-    unsigned hb = 0, mN = 0;
+    unsigned hb = 0, fb = 0;
     if (COUNTS) {
-      hb = (a.hitN[(size_t)(x >> 5) * a.ny_pad + y] >> (x & 31)) & 0xFu;
-      mN = *reinterpret_cast<const unsigned *>(a.missN + c);
-      if (mN && a.zero) *reinterpret_cast<unsigned *>(a.missN + c) = 0u;
+      const size_t wn = (size_t)(x >> 5) * a.ny_pad + y;
+      hb = (a.hitN[wn] >> (x & 31)) & 0xFu;
+      fb = (a.freeN[wn] >> (x & 31)) & 0xFu;
+      const uint4 ft = *reinterpret_cast<const uint4 *>(a.freeT + (size_t)(y >> 5) * a.nx_pad + x);
+      const int by = y & 31;
+      fb |= ((ft.x >> by) & 1u) | (((ft.y >> by) & 1u) << 1) | (((ft.z >> by) & 1u) << 2) | (((ft.w >> by) & 1u) << 3);
     }
     int k0 = 0, k1 = 0, k2 = 0, k3 = 0;
     if (!overflow) {
@@ -1089,17 +968,10 @@ __global__ void __launch_bounds__(256) k_finalize_tiles(FinalizeTileArgs a)
         }
       }
     }
-    const int xr = xq * 4;
-    unsigned t0 = 0, t1 = 0, t2 = 0, t3 = 0;
-    if (COUNTS && a.use_missT) { t0 = tileT[xr + 0][yl]; t1 = tileT[xr + 1][yl]; t2 = tileT[xr + 2][yl]; t3 = tileT[xr + 3][yl]; }
-    const bool m0 = COUNTS && ((mN & 0xffu) | t0);
-    const bool m1 = COUNTS && (((mN >> 8) & 0xffu) | t1);
-    const bool m2 = COUNTS && (((mN >> 16) & 0xffu) | t2);
-    const bool m3 = COUNTS && ((mN >> 24) | t3);
-    l4.x = cell_update_t(l4.x, k0, COUNTS, hb & 1u, m0);
-    l4.y = cell_update_t(l4.y, k1, COUNTS, hb & 2u, m1);
-    l4.z = cell_update_t(l4.z, k2, COUNTS, hb & 4u, m2);
-    l4.w = cell_update_t(l4.w, k3, COUNTS, hb & 8u, m3);
+    l4.x = cell_update_t(l4.x, k0, COUNTS, hb & 1u, fb & 1u);
+    l4.y = cell_update_t(l4.y, k1, COUNTS, hb & 2u, fb & 2u);
+    l4.z = cell_update_t(l4.z, k2, COUNTS, hb & 4u, fb & 4u);
+    l4.w = cell_update_t(l4.w, k3, COUNTS, hb & 8u, fb & 8u);
     float4 p4;
     p4.x = sigmoid_ref_t(l4.x); p4.y = sigmoid_ref_t(l4.y); p4.z = sigmoid_ref_t(l4.z); p4.w = sigmoid_ref_t(l4.w);
     *reinterpret_cast<float4 *>(a.log_odds + c) = l4;
@@ -1118,80 +990,25 @@ void launch_finalize_tiles(const FinalizeTileArgs &a, hipStream_t s)
   else hipLaunchKernelGGL(k_finalize_tiles<false>, grid, dim3(256), 0, s, a);
 }
 
-// [multi-GPU] fold the transposed miss grid into the row-major one (missN |= missT^T) and
-// clear missT, so that one byte grid can be reduced across ranks.  64x64 tiles.
-__global__ void __launch_bounds__(256) k_merge_miss(unsigned char *__restrict__ mN, unsigned char *__restrict__ mT,
-                                                    int nx, int ny)
-{
-  __shared__ unsigned char tile[64][68];
-  const int x0 = blockIdx.x * 64, y0 = blockIdx.y * 64, tid = threadIdx.x;
-  for (int t = tid; t < 64 * 64; t += 256) {
-    const int xr = t >> 6, yl = t & 63;
-    const int x = x0 + xr, y = y0 + yl;
-    unsigned char v = 0;
-    if (x < nx && y < ny) {
-      const size_t off = (size_t)x * ny + y;
-      v = mT[off];
-      if (v) mT[off] = 0;
-    }
-    tile[xr][yl] = v;
-  }
-  __syncthreads();
-  for (int t = tid; t < 64 * 64; t += 256) {
-    const int yl = t >> 6, xr = t & 63;
-    const int x = x0 + xr, y = y0 + yl;
-    if (x < nx && y < ny && tile[xr][yl]) mN[(size_t)y * nx + x] = 1;
-  }
-}
-
-void launch_merge_miss(uint8_t *mN, uint8_t *mT, int nx, int ny, hipStream_t s)
-{
-  hipLaunchKernelGGL(k_merge_miss, dim3((nx + 63) / 64, (ny + 63) / 64), dim3(256), 0, s, mN, mT, nx, ny);
-}
-
-// [multi-GPU] hit bitmap (N orientation only) of rows [y0, y1) from the reduced hit counts
-template <typename HT>
-__global__ void __launch_bounds__(256) k_band_hit_bitmap(const HT *__restrict__ hits, int nx, int ny_pad, int y0,
-                                                         int y1, unsigned *__restrict__ hitN)
-{
-  const int lane = threadIdx.x & 63;
-  const int y = y0 + blockIdx.y * 4 + (threadIdx.x >> 6);
-  const int x = blockIdx.x * 64 + lane;
-  if (y >= y1) return;
-  const int h = (x < nx) ? (int)hits[(size_t)y * nx + x] : 0;
-  const unsigned long long m = __ballot(h > 0);
-  if (lane < 2) hitN[(size_t)(2 * blockIdx.x + lane) * ny_pad + y] = (unsigned)(m >> (32 * lane));
-}
-
-void launch_band_hit_bitmap(const int32_t *hits, int nx, int ny_pad, int y0, int y1, uint32_t *hitN, hipStream_t s)
-{
-  if (y1 <= y0) return;
-  hipLaunchKernelGGL(k_band_hit_bitmap<int32_t>, dim3((nx + 63) / 64, (y1 - y0 + 3) / 4), dim3(256), 0, s, hits, nx,
-                     ny_pad, y0, y1, hitN);
-}
-void launch_band_hit_bitmap8(const uint8_t *hit8, int nx, int ny_pad, int y0, int y1, uint32_t *hitN, hipStream_t s)
-{
-  if (y1 <= y0) return;
-  hipLaunchKernelGGL(k_band_hit_bitmap<uint8_t>, dim3((nx + 63) / 64, (y1 - y0 + 3) / 4), dim3(256), 0, s, hit8, nx,
-                     ny_pad, y0, y1, hitN);
-}
-
-// miss read-back: N | T^T as int32 0/1
-__global__ void __launch_bounds__(256) k_miss_to_i32(const unsigned char *__restrict__ mN,
-                                                     const unsigned char *__restrict__ mT, int nx, int ny,
+// miss read-back: free-cell bitmaps N | T as int32 0/1 per cell
+__global__ void __launch_bounds__(256) k_miss_to_i32(const unsigned *__restrict__ fN, const unsigned *__restrict__ fT,
+                                                     int nx, int ny, int nx_pad, int ny_pad,
                                                      int32_t *__restrict__ out)
 {
   const size_t G = (size_t)nx * ny;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   for (size_t c = blockIdx.x * (size_t)blockDim.x + threadIdx.x; c < G; c += stride) {
     const int y = (int)(c / nx), x = (int)(c - (size_t)y * nx);
-    out[c] = (mN[c] | mT[(size_t)x * ny + y]) ? 1 : 0;
+    const unsigned n = fN[(size_t)(x >> 5) * ny_pad + y] >> (x & 31);
+    const unsigned t = fT[(size_t)(y >> 5) * nx_pad + x] >> (y & 31);
+    out[c] = (int32_t)((n | t) & 1u);
   }
 }
 
-void launch_miss_to_i32(const uint8_t *mN, const uint8_t *mT, int nx, int ny, int32_t *out, hipStream_t s)
+void launch_miss_to_i32(const uint32_t *fN, const uint32_t *fT, int nx, int ny, int nx_pad, int ny_pad, int32_t *out,
+                        hipStream_t s)
 {
-  hipLaunchKernelGGL(k_miss_to_i32, dim3(2048), dim3(256), 0, s, mN, mT, nx, ny, out);
+  hipLaunchKernelGGL(k_miss_to_i32, dim3(2048), dim3(256), 0, s, fN, fT, nx, ny, nx_pad, ny_pad, out);
 }
 
 }  // namespace gv

@@ -309,10 +309,13 @@ enum {
 int gv_time_frame_stages(gv_handle h, int32_t frames, float *stage_ms);
 
 /* ---------------------------------------- [EXTENSION] multi-GPU (RCCL/xGMI) -- */
-/* One large frame sharded by POINTS over `world` ranks: every
- * rank bins + ray-marches its slice into private count grids, one
- * reduce-scatter(sum) hands rank r the r-th band of cells, each rank finalises
- * its band, one all-gather returns the packed int8 grid to everyone.
+/* One large frame sharded by POINTS over `world` ranks: every rank bins its
+ * slice into private ray-end bitmaps; the bitmaps are OR-ed across ranks (all-to-all of slices +
+ * local OR + all-gather); every rank runs every world-th workgroup of the ray stage; the free-cell
+ * bitmaps are OR-ed by row band (rank r receives band r), each rank finalises its band and the
+ * packed int8 bands are broadcast.  After the call log_odds/occupancy are valid for the rank's own
+ * band only (gv_comm_band), the int8 grid everywhere; gv_get_hits needs GV_FRAME_KEEP_COUNTS
+ * (all-reduce of the per-rank counts), gv_get_miss returns GV_ERR_STATE.
  * gv_comm_unique_id fills a 128-byte RCCL id on rank 0 (broadcast it by any
  * means); gv_comm_init joins the communicator. */
 int gv_comm_unique_id(uint8_t id_out[128]);
@@ -321,8 +324,12 @@ int gv_comm_destroy(gv_handle h);
 /* Sharded frame: same inputs as gv_frame_enqueue, but the resident cloud is
  * this rank's slice.  Synchronous. */
 int gv_process_frame_sharded(gv_handle h, const gv_frame_desc *desc);
-/* Band of cells [begin,end) this rank finalises (linear cell indices). */
+/* Band of cells [begin,end) this rank finalises (linear cell indices): whole 64-row blocks. */
 int gv_comm_band(gv_handle h, int64_t *begin, int64_t *end);
+/* Test hook (no RCCL, one device): runs the sharded frame for EVERY rank of a `world`-GPU job on
+ * this handle -- the resident cloud is the whole cloud, rank r takes points [n*r/world, n*(r+1)/world)
+ * -- with the exchanges done by device copies; the result must equal gv_process_frame's. */
+int gv_debug_frame_sharded_emulated(gv_handle h, const gv_frame_desc *desc, int32_t world);
 
 #ifdef __cplusplus
 }

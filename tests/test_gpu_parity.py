@@ -603,9 +603,9 @@ def test_compute_bbox_pose_pca_path(gvamd):
 
 
 def test_sharded_frame_world1_matches_plain(gvamd):
-    """RCCL path with a 1-rank communicator (all this box has): merge-miss, reduce-scatter,
-    band bitmap, band finalise and band broadcast must reproduce the plain frame exactly.
-    world > 1 is covered algorithmically by tests/test_sharding_gloo.py (CPU, gloo)."""
+    """RCCL path with a 1-rank communicator (all this box has): send/recv group, slice OR, all-gather,
+    band packing, band grid pass and band broadcast must reproduce the plain frame exactly.
+    rank > 0 / world > 1 run on one device in test_sharded_frame_every_rank_emulated."""
     config = 2
     x, y, z, _ = synth.cloud_uniform(config)
     poses = synth.lshape_poses(config, 30)
@@ -626,6 +626,43 @@ def test_sharded_frame_world1_matches_plain(gvamd):
         assert np.array_equal(ha.bbox_id(), hb.bbox_id())
     hb.comm_destroy()
     ha.close(); hb.close()
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+@pytest.mark.parametrize("grid,n", [((200, 200, 0.2), 90_000), ((120, 200, 0.25), 50_001)])
+def test_sharded_frame_every_rank_emulated(gvamd, world, grid, n):
+    """SURVEY 8(e)-2 product code for rank > 0 / world > 1 on ONE device: every rank's binning of its
+    point slice, the OR of the end-bitmap slices, every world-th sector workgroup, band packing, band OR
+    and band grid pass run with their real (rank, world) -- only the RCCL transfers are device copies.
+    ny = 800 (ny_pad 896, 14 blocks of 64 rows) gives bands of unequal size and a clipped last block.
+    The union of the bands must equal the plain frame, i.e. the oracle, frame after frame."""
+    gx, gy, res = grid
+    h = gvamd.GridVisionHIP(gx, gy, res)
+    og = ol.OGrid(gx, gy, res)
+    tfs = synth.transforms(True)
+    tfs["base_lidar"] = np.array([0.0, 0.0, 0.0, 1.0, gx / 3.0 - 2.3, gy * 0.11, 1.8])
+    h.set_transforms(tfs["cam_lidar"], tfs["base_cam"], tfs["base_lidar"])
+    st = synth.Stream(991, world * 100 + n)
+    lx, ly = og.g.len_x, og.g.len_y
+    poses = np.zeros(9, dtype=synth.LSHAPE_DTYPE)
+    poses["px"] = st.uniform(9, og.g.pos_x - lx / 2, og.g.pos_x + lx / 2)
+    poses["py"] = st.uniform(9, -ly / 2, ly / 2)
+    poses["length"] = st.uniform(9, 0.5, 5.0)
+    poses["width"] = st.uniform(9, 0.5, 2.5)
+    bboxes = synth.detections(3, 10)
+    flags = gvamd.FRAME_BIN | gvamd.FRAME_RAYMARCH | gvamd.FRAME_BBOX_TEST | gvamd.FRAME_KEEP_CELL_IDX
+    for frame in range(2):
+        x = st.uniform(n, -0.7 * lx, 0.7 * lx)
+        y = st.uniform(n, -0.7 * ly, 0.7 * ly)
+        z = st.uniform(n, -1.0, 1.0)
+        h.upload_xyz(x, y, z)
+        h.frame_sharded_emulated(world, flags, bboxes=bboxes, poses=poses)
+        _, cell, _, ids, _ = oracle_frame(og, tfs, x, y, z, bboxes, poses)
+        assert np.array_equal(h.cell_idx(), cell)
+        assert np.array_equal(h.bbox_id(), ids)
+        nlo, _, _ = check_grid(h, og)
+        assert nlo == 0
+    h.close()
 
 
 def test_gpu_matches_frozen_fixture(gvamd):
