@@ -77,6 +77,7 @@ struct gv_context {
 #ifdef GV_DIAG
   std::vector<hipEvent_t> *trace = nullptr;   // timing events around every pipelined kernel (gv_debug_pipeline_trace)
   unsigned long long *d_dbg = nullptr;        // GV_SECTOR_DBG=1: phase stamps of the sector kernel
+  unsigned long long *d_bin_dbg[2] = {nullptr, nullptr};   // GV_BIN_DBG=1: phase stamps of the partition / tile kernels
   int32_t env_ablate = 0;                     // GV_ABLATE
 #endif
   GridParams g{};
@@ -579,6 +580,9 @@ int enqueue_binning(gv_context *h, const DetSet &D, int p, size_t lo, size_t n, 
   a.keys = h->bin_keys;
   a.tab = h->bin_tab;
   a.tile_total = h->bin_total[h->bin_parity];
+#ifdef GV_DIAG
+  a.dbg = h->d_bin_dbg[0];
+#endif
   launch_bin_partition(a, s);
   if (ev_points) GV_HIP(hipEventRecord(ev_points, s));
   BinTileArgs t{};
@@ -598,6 +602,9 @@ int enqueue_binning(gv_context *h, const DetSet &D, int p, size_t lo, size_t n, 
   t.hitN = h->x_hitN[p]; t.clipN = h->x_clipN[p]; t.hitT = h->x_hitT[p]; t.clipT = h->x_clipT[p];
   t.freeN = h->x_freeN[p]; t.freeT = h->x_freeT[p];
   t.nxw = h->nxw; t.nyw = h->nyw; t.nx_pad = h->nx_pad; t.ny_pad = h->ny_pad;
+#ifdef GV_DIAG
+  t.dbg = h->d_bin_dbg[1];
+#endif
   launch_bin_tiles(t, (uint32_t)(n / kBinSplitKeys), s);
   h->bin_parity ^= 1;
   GV_HIP(hipGetLastError());
@@ -1054,6 +1061,13 @@ int gv_create(gv_handle *out, uint8_t grid_x, uint8_t grid_y, double resolution,
     if (const char *e = std::getenv("GV_LOG2M")) h->env_log2m = std::min(9, std::max(4, std::atoi(e)));
 #ifdef GV_DIAG
     if (const char *e = std::getenv("GV_ABLATE")) h->env_ablate = std::atoi(e);
+    if (const char *e = std::getenv("GV_BIN_DBG")) {
+      if (std::atoi(e) > 0)
+        for (auto &q : h->d_bin_dbg) {
+          GV_C(hipMalloc(reinterpret_cast<void **>(&q), 8192 * 16 * sizeof(unsigned long long)));
+          GV_C(hipMemsetAsync(q, 0, 8192 * 16 * sizeof(unsigned long long), h->stream));
+        }
+    }
     if (const char *e = std::getenv("GV_SECTOR_DBG")) {
       if (std::atoi(e) > 0) {
         GV_C(hipMalloc(reinterpret_cast<void **>(&h->d_dbg), kMaxStatSlots * 16 * sizeof(unsigned long long)));
@@ -1136,6 +1150,7 @@ int gv_destroy(gv_handle h)
     if (p) (void)hipFree(p);
 #ifdef GV_DIAG
   if (h->d_dbg) (void)hipFree(h->d_dbg);
+  for (auto q : h->d_bin_dbg) if (q) (void)hipFree(q);
 #endif
   for (int k = 0; k < gv_context::kSets; ++k) {
     void *xs[] = {h->x_ends[k], h->x_free[k], h->x_rects[k], h->x_stats[k]};
@@ -1797,6 +1812,13 @@ int gv_debug_sector_stamps(gv_handle h, unsigned long long *out, size_t n_wg)
 {
   if (!h || !out || !h->d_dbg) return GV_ERR_STATE;
   return copy_out(h, out, h->d_dbg, n_wg * 16 * sizeof(unsigned long long));
+}
+
+// diagnostic build only (tools/bin_phases.py): phase stamps of the last partition (which = 0) / tile (1) launch
+int gv_debug_bin_stamps(gv_handle h, int which, unsigned long long *out, size_t n_wg)
+{
+  if (!h || !out || which < 0 || which > 1 || !h->d_bin_dbg[which] || n_wg > 8192) return GV_ERR_STATE;
+  return copy_out(h, out, h->d_bin_dbg[which], n_wg * 16 * sizeof(unsigned long long));
 }
 
 // diagnostic build only: enqueue `frames` pipelined frames with timing events around every kernel;

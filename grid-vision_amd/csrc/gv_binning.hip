@@ -31,9 +31,20 @@ namespace gv {
 constexpr unsigned kKeyClip = 1u << 14;
 constexpr unsigned kStagedNone = 0xFFFFFFFFu;      // dropped point (non-finite, or outside with no ray)
 constexpr unsigned kStagedOutside = 0xFFFFFFFEu;   // out-of-map point waiting for the clip
-constexpr int kPartThreads = 256;
+constexpr int kPartThreads = 1024;            // 16 wavefronts per chunk: the pass is latency bound, it wants every SIMD full
 constexpr int kTileThreads = 1024;
 constexpr int kSegBatch = 2048;                    // chunk descriptors staged in LDS per round
+
+// Diagnostic build only (-DGV_DIAG): thread 0 of every workgroup stamps the shader clock at phase
+// boundaries into a buffer nothing else reads (tools/bin_phases.py); absent from the shipped kernels.
+#ifdef GV_DIAG
+#define GV_STAMP(dbg, k)                                                                                  \
+  do {                                                                                                    \
+    if ((dbg) && threadIdx.x == 0) (dbg)[(size_t)blockIdx.x * 16 + (k)] = __builtin_amdgcn_s_memtime();   \
+  } while (0)
+#else
+#define GV_STAMP(dbg, k) do { } while (0)
+#endif
 
 __device__ __forceinline__ unsigned wave_incl_scan_add(unsigned v)
 {
@@ -60,6 +71,7 @@ __global__ void __launch_bounds__(kPartThreads) k_bin_partition(BinArgs a)
   const uint32_t w = blockIdx.x;
   const uint32_t base = w * a.chunk;
   const uint32_t npts = min(a.chunk, a.n - base);
+  GV_STAMP(a.dbg, 0);
   for (int t = tid; t < T; t += kPartThreads) hist[t] = 0;
   if (tid == 0) s_nout = 0;
   __syncthreads();
@@ -93,6 +105,7 @@ __global__ void __launch_bounds__(kPartThreads) k_bin_partition(BinArgs a)
     staged[k] = st;
   }
   __syncthreads();
+  GV_STAMP(a.dbg, 1);   // points done
 
   if (RAY) {
     // Out-of-map points (a minority) need the fp64 slab clip, ~10x the work of an in-map point:
@@ -123,6 +136,7 @@ __global__ void __launch_bounds__(kPartThreads) k_bin_partition(BinArgs a)
     __syncthreads();
   }
 
+  GV_STAMP(a.dbg, 2);   // clipped ends done
   // exclusive prefix over the tile counts: thread owns the tiles [tid*per, tid*per + per)
   const int per = (T + kPartThreads - 1) / kPartThreads;
   const int t0 = tid * per, t1 = min(T, t0 + per);
@@ -148,16 +162,19 @@ __global__ void __launch_bounds__(kPartThreads) k_bin_partition(BinArgs a)
   }
   if (tid == 0) row[T] = (unsigned short)total;
   __syncthreads();
+  GV_STAMP(a.dbg, 3);   // scan + table row
 
   for (uint32_t k = tid; k < a.chunk; k += kPartThreads) {
     const unsigned st = staged[k];
     if (st < kStagedOutside) sorted[atomicAdd(&hist[st >> 16], 1u)] = (unsigned short)(st & 0xFFFFu);
   }
   __syncthreads();
+  GV_STAMP(a.dbg, 4);   // sorted in LDS
   // one contiguous run per workgroup (base of the chunk's key region is 4-byte aligned: chunk is even)
   const unsigned *src = reinterpret_cast<const unsigned *>(sorted);
   unsigned *dst = reinterpret_cast<unsigned *>(a.keys + (size_t)w * a.chunk);
   for (unsigned j = tid; j < (total + 1) / 2; j += kPartThreads) dst[j] = src[j];
+  GV_STAMP(a.dbg, 5);
 }
 
 // ------------------------------------------------------------------ tiles -----
@@ -178,6 +195,7 @@ __global__ void __launch_bounds__(kTileThreads) k_bin_tiles(BinTileArgs a)
   __shared__ unsigned s_ticket;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int T = a.n_tiles;
+  GV_STAMP(a.dbg, 0);
   const bool primary = (int)blockIdx.x < T;
   int t = primary ? (int)blockIdx.x : -1, sp = 0, slot = 0;
   unsigned k = 1;
@@ -229,6 +247,7 @@ __global__ void __launch_bounds__(kTileThreads) k_bin_tiles(BinTileArgs a)
     }
   }
 
+  GV_STAMP(a.dbg, 1);   // role known
   for (int c = tid; c < kBinTileCells; c += kTileThreads) hist[c] = 0;
   if (tid < 2 * kBinTile * 4) (&bits[0][0][0])[tid] = 0;
   // ---- gather: this share takes the chunks sp, sp + k, sp + 2k, ...
@@ -243,6 +262,7 @@ __global__ void __launch_bounds__(kTileThreads) k_bin_tiles(BinTileArgs a)
       seg[q] = (unsigned)row[t] | ((unsigned)row[t + 1] << 16);
     }
     __syncthreads();
+    GV_STAMP(a.dbg, 2);   // descriptors staged (last batch)
     // 16 lanes per segment, four segments in flight per group
     for (uint32_t q = grp; q < nb; q += 4 * (kTileThreads / 16)) {
       unsigned key[4];
@@ -274,6 +294,7 @@ __global__ void __launch_bounds__(kTileThreads) k_bin_tiles(BinTileArgs a)
     }
   }
   __syncthreads();
+  GV_STAMP(a.dbg, 3);   // keys histogrammed
 
   if (k > 1) {
     // partial tile -> scratch slab; the last of the k shares to arrive sums them
@@ -332,6 +353,7 @@ __global__ void __launch_bounds__(kTileThreads) k_bin_tiles(BinTileArgs a)
     }
   }
   __syncthreads();
+  GV_STAMP(a.dbg, 4);   // hits[] written
   // end bitmaps, 32-bit words stored transposed (gv_raysector.hip):
   //   N: bits run along x, word(x>>5, y) at (x>>5)*ny_pad + y;  T: bits run along y, word(y>>5, x) at (y>>5)*nx_pad + x
   {
@@ -356,6 +378,7 @@ __global__ void __launch_bounds__(kTileThreads) k_bin_tiles(BinTileArgs a)
       }
     }
   }
+  GV_STAMP(a.dbg, 5);
 }
 
 // ---------------------------------------------------------------- launch -----

@@ -102,6 +102,7 @@ struct BinArgs {
   uint16_t *keys;          // [n_wg][chunk]  keys of a chunk grouped by tile
   uint16_t *tab;           // [n_wg][n_tiles + 1]  start of every tile's run inside the chunk; [n_tiles] = count
   uint32_t *tile_total;    // [n_tiles]  keys per tile over all chunks (zero on entry)
+  unsigned long long *dbg; // diagnostic build: 16 clock stamps per workgroup (null in production)
 };
 uint32_t bin_chunk_for(size_t n);
 void launch_bin_partition(const BinArgs &a, hipStream_t s);
@@ -120,6 +121,7 @@ struct BinTileArgs {
   uint32_t *hitN, *clipN, *hitT, *clipT;   // end bitmaps (layout: gv_raysector.hip), every word written
   uint32_t *freeN, *freeT;                 // free-cell bitmaps of the same buffer set: zeroed here (or null)
   int32_t nxw, nyw, nx_pad, ny_pad;
+  unsigned long long *dbg;                 // diagnostic build: 16 clock stamps per workgroup (null in production)
 };
 // n_helpers >= n / split_keys extra workgroups serve the shares 1.. of crowded tiles
 void launch_bin_tiles(const BinTileArgs &a, uint32_t n_helpers, hipStream_t s);
