@@ -711,6 +711,7 @@ int enqueue_frame_tiles(gv_context *h, bool pipelined, bool stage_events, bool s
     if (stage_events) GV_HIP(hipEventRecord(h->ev[kStagePoints + 1], sA));
   }
   mark(sA);
+  mark(sA); mark(sA);   // (trace slot of the former bitmap kernel: the tile pass is part of the binning pair)
   GV_HIP(hipEventRecord(CS.used, sA));   // the other cloud / detection set may be refilled from here on
   GV_HIP(hipEventRecord(D.used, sA));
   if (stage_events) GV_HIP(hipEventRecord(h->ev[kStageRayCompact + 1], sA));

@@ -33,7 +33,6 @@ constexpr unsigned kStagedNone = 0xFFFFFFFFu;      // dropped point (non-finite,
 constexpr unsigned kStagedOutside = 0xFFFFFFFEu;   // out-of-map point waiting for the clip
 constexpr int kPartThreads = 1024;            // 16 wavefronts per chunk: the pass is latency bound, it wants every SIMD full
 constexpr int kTileThreads = 1024;
-constexpr int kSegBatch = 2048;                    // chunk descriptors staged in LDS per round
 
 // Diagnostic build only (-DGV_DIAG): thread 0 of every workgroup stamps the shader clock at phase
 // boundaries into a buffer nothing else reads (tools/bin_phases.py); absent from the shipped kernels.
@@ -58,7 +57,7 @@ __device__ __forceinline__ unsigned wave_incl_scan_add(unsigned v)
 
 // ------------------------------------------------------------- partition -----
 template <bool RAY, bool BBOX, bool KEEPCELL>
-__global__ void __launch_bounds__(kPartThreads) k_bin_partition(BinArgs a)
+__global__ void __launch_bounds__(kPartThreads, 8) k_bin_partition(BinArgs a)
 {
   extern __shared__ __align__(16) unsigned char smem[];
   const int T = a.n_tiles;
@@ -189,7 +188,6 @@ __global__ void __launch_bounds__(kTileThreads) k_bin_tiles(BinTileArgs a)
 {
   __shared__ unsigned hist[kBinTileCells];           // 64 KB
   __shared__ unsigned bits[2][kBinTile][4];          // [0] hit, [1] clipped end: bit x of row y
-  __shared__ unsigned seg[kSegBatch];                // start | end << 16 of a chunk's segment
   __shared__ unsigned s_scanh[kTileThreads / 64], s_scane[kTileThreads / 64];
   __shared__ int s_t, s_sp, s_slot;
   __shared__ unsigned s_ticket;
@@ -248,50 +246,56 @@ __global__ void __launch_bounds__(kTileThreads) k_bin_tiles(BinTileArgs a)
   }
 
   GV_STAMP(a.dbg, 1);   // role known
-  for (int c = tid; c < kBinTileCells; c += kTileThreads) hist[c] = 0;
-  if (tid < 2 * kBinTile * 4) (&bits[0][0][0])[tid] = 0;
-  // ---- gather: this share takes the chunks sp, sp + k, sp + 2k, ...
+  // ---- gather: this share takes the chunks sp, sp + k, sp + 2k, ...  Sixteen lanes per chunk segment; a
+  // group first fetches the (start, end) pairs of its next 16 segments, one per lane, while the LDS is being
+  // zeroed, then has the first 16 keys of up to 8 segments in flight at once: two dependent global
+  // latencies for the whole tile instead of one per barrier-separated stage.
   const uint32_t nshare = (a.n_wg > (uint32_t)sp) ? (a.n_wg - (uint32_t)sp + k - 1) / k : 0u;
   const int grp = tid >> 4, l16 = tid & 15;
+  constexpr int kGroups = kTileThreads / 16;
   const size_t rowlen = (size_t)T + 1;
-  for (uint32_t b0 = 0; b0 < nshare; b0 += kSegBatch) {
-    __syncthreads();   // hist/bits zeroed; previous batch consumed
-    const uint32_t nb = min((uint32_t)kSegBatch, nshare - b0);
-    for (uint32_t q = tid; q < nb; q += kTileThreads) {
-      const unsigned short *row = a.tab + (size_t)((uint32_t)sp + (b0 + q) * k) * rowlen;
-      seg[q] = (unsigned)row[t] | ((unsigned)row[t + 1] << 16);
-    }
-    __syncthreads();
-    GV_STAMP(a.dbg, 2);   // descriptors staged (last batch)
-    // 16 lanes per segment, four segments in flight per group
-    for (uint32_t q = grp; q < nb; q += 4 * (kTileThreads / 16)) {
-      unsigned key[4];
-      unsigned sg[4];
-      const unsigned short *kp[4];
+  auto fetch_desc = [&](uint32_t round) -> unsigned {   // segment q = grp + kGroups * (16 * round + l16)
+    const uint32_t q = (uint32_t)grp + (uint32_t)kGroups * (16u * round + (uint32_t)l16);
+    if (q >= nshare) return 0u;
+    const unsigned short *row = a.tab + (size_t)((uint32_t)sp + q * k) * rowlen;
+    return (unsigned)row[t] | ((unsigned)row[t + 1] << 16);
+  };
+  unsigned desc = fetch_desc(0);
+  for (int c = tid; c < kBinTileCells / 4; c += kTileThreads) reinterpret_cast<uint4 *>(hist)[c] = make_uint4(0, 0, 0, 0);
+  if (tid < 2 * kBinTile * 4) (&bits[0][0][0])[tid] = 0;
+  __syncthreads();
+  GV_STAMP(a.dbg, 2);   // LDS zeroed, first descriptors on their way
+  auto add_key = [&](unsigned kk) {
+    const unsigned local = kk & (kBinTileCells - 1);
+    if (kk & kKeyClip) atomicOr(&bits[1][local >> kBinTileLog][(local & (kBinTile - 1)) >> 5], 1u << (local & 31u));
+    else atomicAdd(&hist[local], 1u);
+  };
+  const uint32_t nrounds = (nshare + 16u * kGroups - 1) / (16u * kGroups);
+  for (uint32_t round = 0; round < nrounds; ++round) {
+    const unsigned next = (round + 1 < nrounds) ? fetch_desc(round + 1) : 0u;
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const uint32_t qq = q + u * (kTileThreads / 16);
-        sg[u] = (qq < nb) ? seg[qq] : 0u;
-        kp[u] = a.keys + (size_t)((uint32_t)sp + (b0 + qq) * k) * a.chunk;
-        const unsigned s = sg[u] & 0xFFFFu, e = sg[u] >> 16;
-        key[u] = (s + l16 < e) ? (unsigned)kp[u][s + l16] : 0xFFFFu;
+    for (int half = 0; half < 2; ++half) {
+      unsigned sg[8], key[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        sg[u] = (unsigned)__shfl((int)desc, half * 8 + u, 16);
+        const unsigned s0 = sg[u] & 0xFFFFu, e0 = sg[u] >> 16;
+        const uint32_t q = (uint32_t)grp + (uint32_t)kGroups * (16u * round + (uint32_t)(half * 8 + u));
+        const unsigned short *kp = a.keys + (size_t)((uint32_t)sp + q * k) * a.chunk;   // not dereferenced when the segment is empty
+        key[u] = (s0 + (unsigned)l16 < e0) ? (unsigned)kp[s0 + l16] : 0xFFFFu;
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const unsigned s = sg[u] & 0xFFFFu, e = sg[u] >> 16;
-        unsigned kk = key[u];
-        for (unsigned jj = s + l16;;) {
-          if (kk != 0xFFFFu) {
-            const unsigned local = kk & (kBinTileCells - 1);
-            if (kk & kKeyClip) atomicOr(&bits[1][local >> kBinTileLog][(local & (kBinTile - 1)) >> 5], 1u << (local & 31u));
-            else atomicAdd(&hist[local], 1u);
-          }
-          jj += 16;
-          if (jj >= e) break;
-          kk = kp[u][jj];
+      for (int u = 0; u < 8; ++u) {
+        if (key[u] != 0xFFFFu) add_key(key[u]);
+        const unsigned s0 = sg[u] & 0xFFFFu, e0 = sg[u] >> 16;
+        if (e0 - s0 > 16u) {   // a long segment (crowded tile): the rest of it, 16 keys per step
+          const uint32_t q = (uint32_t)grp + (uint32_t)kGroups * (16u * round + (uint32_t)(half * 8 + u));
+          const unsigned short *kp = a.keys + (size_t)((uint32_t)sp + q * k) * a.chunk;
+          for (unsigned jj = s0 + 16u + (unsigned)l16; jj < e0; jj += 16u) add_key((unsigned)kp[jj]);
         }
       }
     }
+    desc = next;
   }
   __syncthreads();
   GV_STAMP(a.dbg, 3);   // keys histogrammed
@@ -335,22 +339,25 @@ __global__ void __launch_bounds__(kTileThreads) k_bin_tiles(BinTileArgs a)
     __syncthreads();
   }
 
-  // ---- write-out: the tile of hits[] (plain coalesced stores) and the hit bits of every row
+  // ---- write-out: the tile of hits[] (plain coalesced 16-byte stores) and the hit bits of every row.
+  // A lane takes 4 consecutive cells; 8 lanes make one 32-bit word of the row's hit bits: the lane's
+  // nibble is shifted into place and OR-reduced over the 8 lanes with DPP-free shuffles.
   const int x0 = (t % a.tiles_x) << kBinTileLog, y0 = (t / a.tiles_x) << kBinTileLog;
-#pragma unroll 4
-  for (int it = 0; it < kBinTileCells / kTileThreads; ++it) {
-    const int c = it * kTileThreads + tid;
-    const int ly = c >> kBinTileLog, lx = c & (kBinTile - 1);
-    const unsigned v = hist[c];
+#pragma unroll
+  for (int it = 0; it < kBinTileCells / 4 / kTileThreads; ++it) {
+    const int c4 = it * kTileThreads + tid;          // 4-cell group: row c4 >> 5, cells 4 * (c4 & 31) ..
+    const int ly = c4 >> 5, lx = (c4 & 31) << 2;
+    const uint4 v = reinterpret_cast<const uint4 *>(hist)[c4];
     if (WRITE_HITS) {
       const int x = x0 + lx, y = y0 + ly;
-      if (x < a.nx && y < a.ny) a.hits[(size_t)y * a.nx + x] = (int32_t)v;
+      if (x < a.nx && y < a.ny) *reinterpret_cast<uint4 *>(a.hits + (size_t)y * a.nx + x) = v;   // nx % 4 == 0 on the tile path
     }
-    const unsigned long long m = __ballot(v > 0u);
-    if (lane == 0) {
-      bits[0][ly][(lx >> 5) + 0] = (unsigned)m;
-      bits[0][ly][(lx >> 5) + 1] = (unsigned)(m >> 32);
-    }
+    unsigned nib = (v.x ? 1u : 0u) | (v.y ? 2u : 0u) | (v.z ? 4u : 0u) | (v.w ? 8u : 0u);
+    nib <<= 4 * (tid & 7);
+    nib |= (unsigned)__shfl_xor((int)nib, 1);
+    nib |= (unsigned)__shfl_xor((int)nib, 2);
+    nib |= (unsigned)__shfl_xor((int)nib, 4);
+    if ((tid & 7) == 0) bits[0][ly][lx >> 5] = nib;
   }
   __syncthreads();
   GV_STAMP(a.dbg, 4);   // hits[] written

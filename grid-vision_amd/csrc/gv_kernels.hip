@@ -492,16 +492,19 @@ __global__ void __launch_bounds__(64) k_vision(const float *__restrict__ orient,
   const float interval = (float)(2.0f * 3.14159265358979323846 / 2);
   const float bin = (argmax ? interval : 0.0f) + interval / 2.0f;
   // computeAlpha :260-275
-  float alpha = atan2f(os[argmax * 2 + 1], os[argmax * 2 + 0]);
+  // The float trig of the device library differs from glibc's by ulps; each one is evaluated in fp64 and
+  // rounded once instead, which is the correctly rounded float result (what glibc returns except for its
+  // own rare last-bit misses), so alpha / theta_ray / R agree with the host and the 64 residuals with them.
+  float alpha = (float)atan2((double)os[argmax * 2 + 1], (double)os[argmax * 2 + 0]);
   alpha += bin;
   alpha -= (float)3.14159265358979323846;
   // computeThetaRay :277-292
-  const float fovx = 2.0f * atanf(cam.orig_w / (2.0f * cam.fx));
+  const float fovx = 2.0f * (float)atan((double)(cam.orig_w / (2.0f * cam.fx)));
   const float box_center_x = (float)((bb.x_min + bb.x_max) / 2.0f);
   float ddx = box_center_x - (cam.orig_w / 2.0f);
   const float sign = (ddx < 0) ? -1.0f : 1.0f;
   ddx = fabsf(ddx);
-  float theta_ray = atanf((2.0f * ddx * tanf(fovx / 2.0f)) / cam.orig_w);
+  float theta_ray = (float)atan((double)((2.0f * ddx * (float)tan((double)(fovx / 2.0f))) / cam.orig_w));
   theta_ray *= sign;
   // class averages  include/grid_vision/vision_orientation.hpp:58-69, dims :472-495
   float al = 0, aw = 0, ah = 0;
@@ -516,7 +519,7 @@ __global__ void __launch_bounds__(64) k_vision(const float *__restrict__ orient,
   const float len = ds[2] + al, wid = ds[0] + aw, hgt = ds[1] + ah;
   // calcLocation :294-447
   const float orient_f = alpha + theta_ray;
-  const float c = cosf(orient_f), s = sinf(orient_f);
+  const float c = (float)cos((double)orient_f), s = (float)sin((double)orient_f);
   const float Rm[9] = {c, 0, s, 0, 1, 0, -s, 0, c};
   const float box[4] = {(float)bb.x_min, (float)bb.y_min, (float)bb.x_max, (float)bb.y_max};
   const float hx = (float)((double)len / 2.0f);

@@ -187,6 +187,9 @@ float gvo_compute_theta_ray(const gvo_cam *cam, const gvo_bbox *b);      /* :277
 /* calcLocation :294-447 ; dims = (length,width,height) as passed at :501-503 */
 void  gvo_calc_location(const gvo_cam *cam, const double dims[3], const gvo_bbox *b,
                         float alpha, float theta_ray, double pose_out[7], float *best_err);
+/* the same, reporting every one of the 64 constraint sets (loop order of :363-374) */
+void  gvo_calc_location_all(const gvo_cam *cam, const double dims[3], const gvo_bbox *b,
+                            float alpha, float theta_ray, float all_loc[192], float all_err[64]);
 /* postProcessOutputs :449-510 ; returns number of poses written */
 int32_t gvo_post_process(const gvo_cam *cam, const float *orient, const float *conf,
                          const float *dims, const gvo_bbox *bboxes, int32_t nb,

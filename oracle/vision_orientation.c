@@ -151,9 +151,12 @@ static void qr_solve_4x3(const float Ain[12], const float bin[4], float x[3])
   for (int i = 0; i < rank; ++i) x[perm[i]] = y[i];
 }
 
-/* calcLocation  :294-447 */
-void gvo_calc_location(const gvo_cam *cam, const double dimension[3], const gvo_bbox *bbox,
-                       float alpha, float theta_ray, double pose_out[7], float *best_err_out)
+/* calcLocation  :294-447.  all_loc / all_err (optional, 64 x 3 / 64 floats): the solution and the
+ * residual of every constraint set in the reference's loop order -- the parity tests use them to prove
+ * that a different arg-min on the device was a near-tie. */
+static void calc_location_impl(const gvo_cam *cam, const double dimension[3], const gvo_bbox *bbox,
+                               float alpha, float theta_ray, double pose_out[7], float *best_err_out,
+                               float *all_loc, float *all_err)
 {
   const float orient = alpha + theta_ray;                      /* :298 */
   const float c = cosf(orient), s = sinf(orient);              /* rotationMatrix :512-519 */
@@ -231,6 +234,11 @@ void gvo_calc_location(const gvo_cam *cam, const double dimension[3], const gvo_
             const float rr = ((A[row * 3] * loc[0] + A[row * 3 + 1] * loc[1]) + A[row * 3 + 2] * loc[2]) - bb[row];
             err += rr * rr;
           }
+          {
+            const int id = ((l * 4 + t) * 2 + r) * 4 + b;
+            if (all_loc) { all_loc[id * 3] = loc[0]; all_loc[id * 3 + 1] = loc[1]; all_loc[id * 3 + 2] = loc[2]; }
+            if (all_err) all_err[id] = err;
+          }
           if (err < best_error) {                              /* :424-429 */
             best_error = err;
             best_loc[0] = loc[0]; best_loc[1] = loc[1]; best_loc[2] = loc[2];
@@ -239,6 +247,19 @@ void gvo_calc_location(const gvo_cam *cam, const double dimension[3], const gvo_
   pose_out[0] = best_loc[0]; pose_out[1] = best_loc[1]; pose_out[2] = best_loc[2];   /* :434-436 */
   gvo_set_rpy(0, -orient, 0, &pose_out[3]);                    /* :440 */
   if (best_err_out) *best_err_out = best_error;
+}
+
+void gvo_calc_location(const gvo_cam *cam, const double dimension[3], const gvo_bbox *bbox,
+                       float alpha, float theta_ray, double pose_out[7], float *best_err_out)
+{
+  calc_location_impl(cam, dimension, bbox, alpha, theta_ray, pose_out, best_err_out, NULL, NULL);
+}
+
+void gvo_calc_location_all(const gvo_cam *cam, const double dimension[3], const gvo_bbox *bbox,
+                           float alpha, float theta_ray, float all_loc[192], float all_err[64])
+{
+  double pose[7];
+  calc_location_impl(cam, dimension, bbox, alpha, theta_ray, pose, NULL, all_loc, all_err);
 }
 
 /* postProcessOutputs  :449-510 ; class averages include/grid_vision/vision_orientation.hpp:58-69 */

@@ -330,6 +330,17 @@ def calc_location(cam: Cam, dims3, bbox, alpha, theta_ray):
     return pose, err.value
 
 
+def calc_location_all(cam: Cam, dims3, bbox, alpha, theta_ray):
+    """(64, 3) solutions and (64,) residuals of every constraint set of calcLocation"""
+    b = np.ascontiguousarray(bbox, dtype=BBOX_DTYPE).reshape(1)
+    d = np.ascontiguousarray(dims3, dtype=np.float64)
+    loc = np.zeros((64, 3), dtype=np.float32)
+    err = np.zeros(64, dtype=np.float32)
+    lib().gvo_calc_location_all(C.byref(cam), _p(d, C.c_double), b.ctypes.data_as(C.c_void_p), C.c_float(alpha),
+                                C.c_float(theta_ray), _p(loc, C.c_float), _p(err, C.c_float))
+    return loc, err
+
+
 def post_process(cam: Cam, orient, conf, dims, bboxes):
     orient, conf, dims = f32(orient), f32(conf), f32(dims)
     b = np.ascontiguousarray(bboxes, dtype=BBOX_DTYPE)

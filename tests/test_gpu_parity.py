@@ -271,10 +271,11 @@ def test_pointcloud2_ingest(gvamd):
 
 
 def test_vision_post_process_tolerance(gvamd):
-    """A13/A14: 64-combination least squares per bbox, one wavefront each.
-    Tolerance 1e-4 relative on the location: device libm and
-    reduction order differ from the host's by ulps; near-tied constraint sets
-    may flip, so the residual is compared too."""
+    """A13/A14: 64-combination least squares per bbox, one wavefront each.  SURVEY 8(a) A14: location
+    within 1e-4 (absolute + relative).  The device evaluates the float trig in fp64 rounded once and runs
+    the oracle's QR operation order, so normally every box agrees to the last bits.  A box may pick another
+    of the 64 constraint sets only if that was a proven near-tie: the oracle's own residual of the set the
+    device chose must be within 1e-6 (relative) of the oracle's minimum."""
     h, tfs = make_handle(gvamd, 2)
     nb = 50
     bboxes = synth.detections(3, nb)
@@ -283,18 +284,34 @@ def test_vision_post_process_tolerance(gvamd):
     exp = ol.post_process(cam, orient, conf, dims, bboxes)
     got = h.vision_post_process(orient, conf, dims, bboxes)
     assert len(got) == len(exp) > 0
-    n_close = 0
-    for gpose, epose in zip(got, exp):
+    # oracle-side inputs of calcLocation per emitted pose (unknown classes are skipped, :496-499)
+    bins = ol.generate_bins(2)
+    kept = [i for i in range(nb) if int(bboxes[i]["label"]) in (9, 0, 1, 2)]
+    assert len(kept) == len(exp)
+    n_exact, n_ties, worst = 0, 0, 0.0
+    for (gpose, epose), i in zip(zip(got, exp), kept):
         for k in ("length", "width", "height"):
             assert gpose[k] == epose[k]
         gl = np.array([gpose["px"], gpose["py"], gpose["pz"]])
         el = np.array([epose["px"], epose["py"], epose["pz"]])
-        if np.allclose(gl, el, rtol=1e-3, atol=1e-3):
-            n_close += 1
         gq = np.array([gpose[q] for q in ("qx", "qy", "qz", "qw")])
         eq = np.array([epose[q] for q in ("qx", "qy", "qz", "qw")])
         assert np.allclose(gq, eq, atol=1e-6)
-    assert n_close >= len(exp) - 2, f"only {n_close}/{len(exp)} locations agree"
+        if np.allclose(gl, el, rtol=1e-4, atol=1e-4):
+            n_exact += 1
+            worst = max(worst, float(np.max(np.abs(gl - el))))
+            continue
+        argmax = 1 if conf[i][1] > conf[i][0] else 0
+        alpha = ol.compute_alpha(orient[i], argmax, bins)
+        theta = ol.compute_theta_ray(cam, bboxes[i])
+        loc64, err64 = ol.calc_location_all(cam, [epose["length"], epose["width"], epose["height"]], bboxes[i], alpha, theta)
+        k = int(np.argmin(np.max(np.abs(loc64 - gl.astype(np.float32)), axis=1)))
+        assert np.allclose(loc64[k], gl, rtol=1e-4, atol=1e-4), f"box {i}: device location is none of the 64 candidates"
+        best = float(err64.min())
+        assert float(err64[k]) - best <= 1e-6 * max(best, 1e-30), f"box {i}: set {k} residual {err64[k]} vs best {best} is no tie"
+        n_ties += 1
+    assert n_exact + n_ties == len(exp)
+    print(f"A14: {n_exact}/{len(exp)} within 1e-4 (max abs diff {worst:.3g}), {n_ties} proven ties")
     # base-frame transform of the poses (A15) is host fp64: exact vs oracle
     tb = h.transform_lshape_objects(exp)
     for i, e in enumerate(exp):

@@ -23,8 +23,8 @@ h.set_detections(gvamd.FRAME_BIN | gvamd.FRAME_RAYMARCH | gvamd.FRAME_BBOX_TEST,
 for _ in range(5):
     h.enqueue_frame()
 h.synchronize()
-names = {0: ["init", "points", "clip", "scan+row", "scatter", "write"],
-         1: ["role", "zero+desc", "gather", "hist", "hits out", "bitmaps"]}
+names = {0: ["points", "clip", "scan+row", "scatter", "write"],
+         1: ["role", "zero LDS", "gather+hist", "hits out", "bitmaps"]}
 for which, label in ((0, "k_bin_partition"), (1, "k_bin_tiles")):
     nwg = 8192
     buf = np.zeros((nwg, 16), np.uint64)
@@ -36,7 +36,7 @@ for which, label in ((0, "k_bin_partition"), (1, "k_bin_tiles")):
     print(label, "workgroups", int(live.sum()), "kernel span", int(t[:, 5].max() - t[:, 0].min()), "ticks; first start spread",
           int(t[:, 0].max() - t[:, 0].min()))
     d = np.diff(t[:, :6], axis=1)
-    for k, nme in enumerate(names[which][1:]):
+    for k, nme in enumerate(names[which]):
         print(f"  {nme:10s} mean {d[:, k].mean():9.0f}  p50 {np.median(d[:, k]):9.0f}  max {d[:, k].max():9.0f}")
     tot = t[:, 5] - t[:, 0]
     print(f"  total      mean {tot.mean():9.0f}  max {tot.max():9.0f}")

@@ -1,6 +1,7 @@
 """Device timeline of the pipelined frames (timing events around every kernel; diagnostic)."""
 import ctypes as C, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+os.environ.setdefault("GV_LIB_AB", os.path.join(ROOT, "gpurun_out", "libgv_diag.so"))   # -DGV_DIAG build: tools/build_diag.sh
 sys.path.insert(0, os.path.join(ROOT, "grid-vision_amd"))
 import numpy as np
 import gvamd
@@ -22,7 +23,7 @@ out = np.zeros(F * 10, np.float32)
 rc = h._lib.gv_debug_pipeline_trace(h._h, C.c_int32(F), out.ctypes.data_as(C.c_void_p))
 assert rc == 0, rc
 t = out.reshape(F, 5, 2)
-names = ["rects", "points", "bitmaps", "sectors", "gridpass"]
+names = ["rects", "binning", "-", "sectors", "gridpass"]
 print("frame period (sectors start to start):", np.diff(t[10:, 3, 0]).mean().round(1), "us")
 print("mean durations:", {n: round(float((t[10:, k, 1] - t[10:, k, 0]).mean()), 1) for k, n in enumerate(names)})
 b = t[20, 0, 0]
