@@ -1,24 +1,34 @@
 #!/usr/bin/env python3
 """bench.py -- frames/sec of the grid-vision per-frame hot path on MI355X.
 
-A "step" is one frame: points pass (transform + bin + ray ends + bbox test),
-Bresenham free-space ray-march, and the grid pass (decay, rectangles, hit/miss,
-clamp, sigmoid, int8 pack) over one synthetic cloud that is already resident in
-HBM when the timed region starts.
+A "step" is one contract-complete frame: points pass (transform + cell index + ray ends + bbox test),
+int32 hit counts per cell, Bresenham free-space ray stage, and the grid pass (decay, rectangles,
+hit/miss, clamp, sigmoid, int8 pack) over one synthetic cloud that is already resident in HBM when the
+timed region starts.
 
-N=1   BASELINE.json configs[2]: 1M-point cloud, 2000x2000 @ 0.1 m grid, 50
-      bboxes + 50 poses.
-N>1   configs[3]: one independent 1M-point frame stream per GPU (no data-path
-      collective; torch.distributed only for the barrier and the max-over-ranks).
+N=1   BASELINE.json configs[2]: 1M-point cloud, 2000x2000 @ 0.1 m grid, 50 bboxes + 50 poses.
+N>1   configs[3]: one independent 1M-point frame stream per GPU (no data-path collective;
+      torch.distributed only for the barrier and the max-over-ranks).  Run plainly (no torchrun
+      environment) with --gpus N, the script launches the N ranks itself; it never reports fewer GPUs
+      than it was asked for.
 
-Prints ONE JSON line on rank 0.
+Prints ONE JSON line on rank 0.  Besides the headline the line carries (N=1): per-kernel times and
+rooflines, `with_h2d` (a fresh cloud + fresh detections every frame, host->device copy included),
+`lidar_like`, `beyond_l3` (config 5 on one GPU: working set past the 256 MiB Infinity Cache), PMC
+traffic measured in this very run (rocprofv3 child passes) and the CPU baselines.
 """
 from __future__ import annotations
 
 import argparse
+import csv
+import glob
 import json
 import os
+import shutil
+import socket
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -26,7 +36,14 @@ sys.path.insert(0, os.path.join(ROOT, "grid-vision_amd"))
 
 import numpy as np  # noqa: E402
 
-HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+HBM_PEAK_GBPS = 8000.0            # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+# VALU issue peak (MI355X_MICROARCH.md: 256 CUs x 4 SIMD-32, a wave64 VALU instruction issues over 2
+# cycles with >= 2 waves per SIMD, 2.4 GHz): 1024 x 2.4e9 / 2 wave-instructions per second
+VALU_PEAK_GWIPS = 1024 * 2.4 / 2.0
+PCIE_SPEC_GBPS = 63.0             # PCIe Gen5 x16 (MI355X_MICROARCH.md)
+
+KERNEL_OF = {"detections": "k_rects_from_poses", "points": "k_bin_partition", "ray_ends": "k_bin_tiles",
+             "ray_march": "k_ray_sectors", "finalize": "k_finalize_tiles"}
 
 
 def parse():
@@ -34,18 +51,22 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--config", type=int, default=0, help="0 = 3 at N=1 / 4 at N>1")
+    ap.add_argument("--config", type=int, default=0, help="0 = 3 at N=1 / 4 at N>1; 5 = one sharded 10M-point frame")
     ap.add_argument("--cloud", choices=["uniform", "lidar"], default="uniform")
+    ap.add_argument("--plain", action="store_true", help="headline + stage times only (profiling runs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-hit-counts", action="store_true", help="skip the second measurement with int32 hit counts (profiling runs)")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 child passes (traffic = null)")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--rehearsal", action="store_true",
+                    help="allow more ranks than GPUs (ranks share devices, gloo barrier): reported as rehearsal")
     return ap.parse_args()
 
 
+# --------------------------------------------------------------------------- CPU baselines --
 def cpu_baseline(config, cloud_fn, tfs, bboxes, poses, budget_s):
-    """The CPU oracle (a port: the reference itself cannot be built here) timed on
-    this box's host cores, single thread like the reference node, on a bounded
-    sample: whole frames of the same workload until ~budget_s have elapsed."""
+    """The CPU oracle (a port: the reference itself cannot be built here) timed on this box's host
+    cores, single thread like the reference node, on a bounded sample: whole frames of the same
+    workload until ~budget_s have elapsed."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as ol
     from gvamd import synth
@@ -74,7 +95,7 @@ def cpu_baseline(config, cloud_fn, tfs, bboxes, poses, budget_s):
             break
     dt = time.perf_counter() - t0
     return {"value": n / dt, "unit": "frames/s", "cores": 1, "kind": "port",
-            "sample": f"{n} whole frames of the same workload (per-point Bresenham, no dedupe), {dt:.1f} s"}
+            "sample": f"{n} whole frames of the same workload (per-point Bresenham, 1M rays, no de-duplication), {dt:.1f} s"}
 
 
 def cpu_baseline_all_cores(config, cloud_fn, tfs, bboxes, poses, budget_s):
@@ -148,8 +169,159 @@ def measured_copy_rate(torch):
     return 2.0 * n / (ms * 1e-3) / 1e9
 
 
+# ------------------------------------------------------------------------- extra GPU legs --
+def timed_frames(h, steps, warmup):
+    for _ in range(warmup):
+        h.enqueue_frame()
+    h.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        h.enqueue_frame()
+    h.synchronize()
+    return time.perf_counter() - t0
+
+
+def leg_with_h2d(gvamd, synth, g, tfs, config, flags, local_rank, steps):
+    """host-to-device copy INCLUDED.  grid_vision_node.cpp:103-106,108-244: a new cloud and
+    new detections arrive for every frame.  Six distinct clouds sit in pinned host memory; every frame
+    does gv_cloud_upload_xyz_async + gv_frame_set_detections_async + gv_frame_enqueue with no host wait
+    (double-buffered resident clouds, copy stream).  The copy rate alone is measured next to it."""
+    n_sets = 6
+    pins, dets = [], []
+    for f in range(n_sets):
+        x, y, z, _ = synth.cloud_uniform(config, seed_extra=100 + f)
+        p3 = tuple(gvamd.PinnedF32(len(x)) for _ in range(3))
+        p3[0].array[:], p3[1].array[:], p3[2].array[:] = x, y, z
+        pins.append(p3)
+        dets.append((synth.detections(config, seed_extra=f), synth.lshape_poses(config, seed_extra=f)))
+    h = gvamd.GridVisionHIP(g.grid_x, g.grid_y, g.resolution, device=local_rank)
+    h.set_transforms(tfs["cam_lidar"], tfs["base_cam"], tfs["base_lidar"])
+    n = len(pins[0][0].array)
+
+    def one(f):
+        px, py, pz = pins[f % n_sets]
+        h.upload_xyz_async(px.array, py.array, pz.array)
+        h.set_detections_async(flags, bboxes=dets[f % n_sets][0], poses=dets[f % n_sets][1])
+        h.enqueue_frame()
+
+    for f in range(12):
+        one(f)
+    h.synchronize()
+    t0 = time.perf_counter()
+    for f in range(steps):
+        one(f)
+    h.synchronize()
+    dt = time.perf_counter() - t0
+    # copy rate alone: the same uploads without frames
+    t1 = time.perf_counter()
+    for f in range(steps):
+        px, py, pz = pins[f % n_sets]
+        h.upload_xyz_async(px.array, py.array, pz.array)
+    h.synchronize()
+    dtc = time.perf_counter() - t1
+    h.close()
+    for p3 in pins:
+        for p in p3:
+            p.close()
+    h2d_gbps = 12.0 * n * steps / dtc / 1e9
+    bound_fps = h2d_gbps * 1e9 / (12.0 * n)
+    return {"value": steps / dt, "unit": "frames/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
+            "h2d_GBps_measured": h2d_gbps, "h2d_GBps_spec": PCIE_SPEC_GBPS,
+            "copy_bound_frames_per_s": bound_fps, "frac_of_copy_bound": (steps / dt) / bound_fps,
+            "note": "fresh 1M-point cloud (12 MB, pinned host memory) + fresh detections every frame, async "
+                    "double-buffered ingest on a copy stream, no host wait between frames; never the headline"}
+
+
+def leg_cloud(gvamd, synth, g, tfs, config, flags, bboxes, poses, local_rank, steps, cloud_fn, n=None):
+    x, y, z, _ = cloud_fn(config) if n is None else cloud_fn(config, n)
+    h = gvamd.GridVisionHIP(g.grid_x, g.grid_y, g.resolution, device=local_rank)
+    h.set_transforms(tfs["cam_lidar"], tfs["base_cam"], tfs["base_lidar"])
+    h.upload_xyz(x, y, z)
+    h.set_detections(flags, bboxes=bboxes, poses=poses)
+    dt = timed_frames(h, steps, 10)
+    stages = h.time_frame_stages(10)
+    h.close()
+    return {"value": steps / dt, "unit": "frames/s", "ms_per_step": dt / steps * 1e3, "steps": steps, "stage_ms": stages,
+            "points": len(x)}
+
+
+def pmc_child_passes(config, budget_note):
+    """HBM traffic and issue counters of every kernel, measured in THIS run: the script runs itself
+    (--plain, serial frame so that dispatches do not overlap) under `rocprofv3 --pmc`, one counter group
+    per pass and no trace domain (MI355X_MICROARCH.md, rocprofv3 PMC slots / HBM).  FETCH_SIZE is in KB
+    and is doubled: gfx950 tallies 128-byte read requests at 64 bytes."""
+    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rocprof):
+        return None, "rocprofv3 not found"
+    groups = ["FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES",
+              "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY"]
+    res = {}
+    tmp = tempfile.mkdtemp(prefix="gv_pmc_", dir="/tmp")
+    env = dict(os.environ, GV_PIPELINE="0", TMPDIR="/tmp")
+    env.pop("WORLD_SIZE", None)
+    errs = []
+    try:
+        for k, grp in enumerate(groups):
+            d = os.path.join(tmp, f"p{k}")
+            cmd = [rocprof, "--pmc", *grp.split(), "--output-format", "csv", "-d", d, "--", sys.executable,
+                   os.path.join(ROOT, "bench.py"), "--plain", "--steps", "10", "--warmup", "3", "--config", str(config)]
+            try:
+                p = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=150)
+            except subprocess.TimeoutExpired:
+                errs.append(f"pass {grp}: timeout")
+                continue
+            if p.returncode != 0:
+                errs.append(f"pass {grp}: rc {p.returncode}: {p.stderr.decode(errors='replace')[-200:]}")
+                continue
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                acc = {}
+                for r in csv.DictReader(open(f)):
+                    name = r["Kernel_Name"]
+                    if "gv::" not in name:
+                        continue
+                    short = name.split("gv::")[1].split("(")[0].split("<")[0]
+                    acc.setdefault((short, r["Counter_Name"]), []).append(float(r["Counter_Value"]))
+                for (short, c), v in acc.items():
+                    res.setdefault(short, {})[c] = sum(v) / len(v)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    for cs in res.values():
+        if "FETCH_SIZE" in cs:
+            cs["fetch_bytes"] = cs["FETCH_SIZE"] * 1024 * 2
+        if "WRITE_SIZE" in cs:
+            cs["write_bytes"] = cs["WRITE_SIZE"] * 1024
+        if "fetch_bytes" in cs and "write_bytes" in cs:
+            cs["hbm_bytes"] = cs["fetch_bytes"] + cs["write_bytes"]
+    return (res or None), ("; ".join(errs) if errs else None)
+
+
+# ------------------------------------------------------------------------------ launcher --
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def spawn_ranks(a):
+    """--gpus N without a torchrun environment: this parent (which has not touched the GPU) starts the
+    N ranks and relays their single JSON line; it never falls back to one GPU."""
+    import torch
+    ndev = torch.cuda.device_count()   # does not initialise the GPU
+    if ndev < a.gpus and not a.rehearsal:
+        print(f"bench.py: --gpus {a.gpus} but only {ndev} GPU(s) visible; refusing to report a smaller job "
+              f"(use --rehearsal to share devices)", file=sys.stderr)
+        return 2
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__), *sys.argv[1:]]
+    return subprocess.call(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")))
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(a))
     # RCCL (and some HIP runtime paths) print banners on stdout; the contract is ONE JSON line
     # there, so everything incidental goes to stderr and the result line to the real stdout.
     sys.stdout.flush()
@@ -158,14 +330,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    n_gpus = max(a.gpus, 1)
+    if world != max(a.gpus, 1):
+        print(f"bench.py: --gpus {a.gpus} does not match WORLD_SIZE {world}", file=sys.stderr)
+        sys.exit(2)
     import torch
     dist = None
     ndev = torch.cuda.device_count()
-    on_gpu_collectives = ndev >= world
+    rehearsal = ndev < world
+    if rehearsal and not a.rehearsal:
+        print(f"bench.py: {world} ranks but only {ndev} GPU(s) visible (use --rehearsal to share devices)", file=sys.stderr)
+        sys.exit(2)
     if world > 1:
         import torch.distributed as dist
-        if on_gpu_collectives:
+        if not rehearsal:
             torch.cuda.set_device(local_rank)
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))   # nccl == RCCL
         else:
@@ -179,20 +356,21 @@ def main():
 
     import gvamd
     from gvamd import synth
-    config = a.config or (3 if n_gpus == 1 else 4)
+    config = a.config or (3 if world == 1 else 4)
     cfg = synth.CONFIGS[config]
     g = cfg["grid"]
     cloud_fn = synth.cloud_uniform if a.cloud == "uniform" else synth.cloud_lidar_like
     tfs = synth.transforms(perturbed=True)
     bboxes = synth.detections(config)
     poses = synth.lshape_poses(config)
-    sharded = (config == 5)
-    if sharded:
-        # configs[4]: ONE 10M-point frame, points partitioned N/world per rank, RCCL reduce inside the library
+    sharded = (config == 5 and world > 1)
+    if config == 5:
+        # configs[4]: ONE 10M-point frame (half lidar-like, half uniform); with world > 1 the points are
+        # partitioned N/world per rank and the exchange happens inside the library (RCCL)
         xa, ya, za, _ = synth.cloud_lidar_like(config, cfg["n"] // 2)
         xb, yb, zb, _ = synth.cloud_uniform(config, cfg["n"] - cfg["n"] // 2)
         xf, yf, zf = np.concatenate([xa, xb]), np.concatenate([ya, yb]), np.concatenate([za, zb])
-        lo_i, hi_i = len(xf) * rank // world, len(xf) * (rank + 1) // world
+        lo_i, hi_i = (len(xf) * rank // world, len(xf) * (rank + 1) // world) if sharded else (0, len(xf))
         x, y, z = xf[lo_i:hi_i], yf[lo_i:hi_i], zf[lo_i:hi_i]
         N_total = len(xf)
     else:
@@ -207,8 +385,7 @@ def main():
     h.set_detections(flags, bboxes=bboxes, poses=poses)
     if sharded:
         uid = [gvamd.GridVisionHIP.comm_unique_id() if rank == 0 else None]
-        if dist is not None:
-            dist.broadcast_object_list(uid, src=0)
+        dist.broadcast_object_list(uid, src=0)
         h.comm_init(uid[0], rank, world)
 
     def barrier():
@@ -233,7 +410,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if on_gpu_collectives else "cpu")
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     frames = a.steps if sharded else a.steps * world   # sharded: all ranks work on the same frame
@@ -241,65 +418,104 @@ def main():
 
     out = None
     if rank == 0:
-        # per-kernel device time, HIP events on the handle's own stream (gv_time_frame_stages)
+        # per-kernel device time: HIP events recorded between the kernels on the stream they are launched
+        # on (gv_time_frame_stages, serial frame).  Read ~3 us per stage higher than rocprofv3's kernel
+        # durations (profiles/): the event records are in the interval.
         stages = h.time_frame_stages(max(10, min(a.steps, 50)))
         n_rays, n_visits = h.ray_stats()
-        frame_ms = sum(stages.values())
         bytes_frame = 12.0 * N + 13.0 * G
-        # Algorithmic bytes per launch (DESIGN.md "Kernels"): SURVEY 8(d) counts 12 B/point
-        # (x,y,z read) and 13 B/cell (log-odds r+w, occupancy w, int8 w); the count grids the
-        # ray stage works on are implementation traffic there.  For the ray kernels the
-        # minimum any implementation of that stage moves is used instead: end flags in
-        # (2 bits/cell in both orientations = G/2 B) and one miss byte per cell out.
-        alg = {"points": 12.0 * N, "ray_ends": 5.0 * G, "ray_march": 1.5 * G, "finalize": 13.0 * G,
+        # Algorithmic bytes per launch.  SURVEY 8(d): 12 B/point in, 13 B/cell
+        # grid traffic; the int32 hit counts are row X1's output (4 B/cell).  The ray stage moves no
+        # algorithmic bytes: it is priced against the VALU issue rate instead.
+        alg = {"points": 12.0 * N, "ray_ends": 4.0 * G, "finalize": 13.0 * G, "ray_march": 0.0,
                "detections": 120.0 * (len(bboxes) + len(poses))}
-        kern = {"points": "k_bin_partition", "ray_ends": "k_bin_tiles", "ray_march": "k_ray_sectors",
-                "finalize": "k_finalize_tiles", "detections": "k_rects_from_poses"}
-        dom = max(stages, key=stages.get)
-        kernels = [{"stage": k, "kernel": kern[k], "ms": stages[k], "algorithmic_bytes": alg[k],
-                    "GBps": alg[k] / (stages[k] * 1e-3) / 1e9 if stages[k] > 0 else None,
-                    "frac_hbm_peak": alg[k] / (stages[k] * 1e-3) / 1e9 / HBM_PEAK_GBPS if stages[k] > 0 else None}
-                   for k in stages]
-        dom_s = stages[dom] * 1e-3
-        traffic = None
-        tf = os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")
-        if os.path.exists(tf):
-            try:
-                traffic = json.load(open(tf)).get(kern[dom])
-            except Exception:
-                traffic = None
-        roof = {"bound": "hbm", "kernel": kern[dom], "achieved": alg[dom] / dom_s / 1e9, "peak": HBM_PEAK_GBPS,
-                "unit": "GB/s", "frac": alg[dom] / dom_s / 1e9 / HBM_PEAK_GBPS, "traffic": traffic,
-                "algorithmic_bytes": alg[dom], "kernel_ms": stages[dom],
-                "note": "the dominant kernel is the sector ray-march: LDS/latency bound, not HBM bound; "
-                        "see kernels[] for the HBM-bound passes (points 12N, finalize 13G)"}
         out = {
             "metric": f"frames/sec into grid ({N_total // 1000000}M-pt cloud / {g.nx}x{g.ny} @ {g.resolution} m grid)",
-            "value": fps, "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "value": fps, "unit": "frames/s", "n_gpus": world if not rehearsal else min(world, max(ndev, 1)),
+            "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "strong" if sharded else "weak",
             "vs_baseline": None, "dtype": "i32 hit counts / f64 cell index / f32 log-odds", "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[{config - 1}]: {N}-point {a.cloud} cloud per GPU, "
+            "config": {"workload": f"BASELINE configs[{config - 1}]: {N}-point {a.cloud if config != 5 else 'lidar-like + uniform'} cloud per GPU, "
                                    f"{g.nx}x{g.ny} @ {g.resolution} m grid, {len(bboxes)} bboxes + {len(poses)} poses, "
-                                   "bin (int32 hit counts) + ray-march + bbox test + grid pass",
-                       "points": N, "cells": G, "parallelism": (f"points-sharded x{world} + RCCL reduce-scatter" if sharded else f"frame-per-gpu x{world}"),
+                                   "bin (int32 hit counts) + ray-march + bbox test + grid pass, inputs resident in HBM",
+                       "points": N, "cells": G,
+                       "parallelism": (f"points-sharded x{world} + RCCL bitmap OR-exchange" if sharded else f"frame-per-gpu x{world}"),
                        "devices_visible": ndev},
             "mpoints_per_s": N_total * fps / 1e6,
             "frame_roofline": {"algorithmic_bytes": bytes_frame, "achieved_GBps": bytes_frame * fps / world / 1e9,
                                "frac_of_hbm_peak": bytes_frame * fps / world / 1e9 / HBM_PEAK_GBPS},
-            "stage_ms": stages, "stage_ms_sum": frame_ms, "kernels": kernels,
+            "stage_ms": stages, "stage_ms_sum": sum(stages.values()),
             "ray_march": {"rays": n_rays, "equivalent_cell_visits": n_visits,
                           "mcell_visits_per_s": (n_visits / (stages["ray_march"] * 1e-3) / 1e6) if stages["ray_march"] > 0 else None},
-            "roofline": roof,
         }
-        try:
-            copy_gbps = measured_copy_rate(torch)
-            out["frame_roofline"]["measured_copy_GBps"] = copy_gbps
-            out["frame_roofline"]["frac_of_measured_copy"] = bytes_frame * fps / world / 1e9 / copy_gbps
-            roof["peak_measured_copy"] = copy_gbps
-        except Exception as e:   # never fail the bench line over the auxiliary peak
-            out["frame_roofline"]["measured_copy_GBps"] = None
-            print("copy-rate measurement failed:", e, file=sys.stderr)
-        if not a.no_cpu_baseline and world == 1:
+        if rehearsal:
+            out["rehearsal"] = True
+        pmc, pmc_err = (None, "skipped")
+        if not a.plain and not a.no_pmc and world == 1:
+            h.synchronize()
+            pmc, pmc_err = pmc_child_passes(config, "")
+        kernels = []
+        for st, ms in stages.items():
+            kn = KERNEL_OF[st]
+            c = (pmc or {}).get(kn, {})
+            e = {"stage": st, "kernel": kn, "ms": ms, "traffic": c.get("hbm_bytes"),
+                 "fetch_bytes": c.get("fetch_bytes"), "write_bytes": c.get("write_bytes")}
+            if st == "ray_march":
+                # LDS / issue / latency kernel: no algorithmic HBM bytes; fraction of the VALU issue peak
+                iv = c.get("SQ_INSTS_VALU")
+                e.update({"bound": "valu-issue/lds", "unit": "Gwave-instr/s", "peak": VALU_PEAK_GWIPS,
+                          "achieved": (iv / (ms * 1e-3) / 1e9) if iv and ms > 0 else None,
+                          "valu_wave_instructions": iv,
+                          "lds_bank_conflict_ratio": (c["SQ_LDS_BANK_CONFLICT"] / c["SQ_LDS_IDX_ACTIVE"])
+                          if c.get("SQ_LDS_IDX_ACTIVE") else None,
+                          "mcell_visits_per_s": out["ray_march"]["mcell_visits_per_s"]})
+            else:
+                e.update({"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBPS, "algorithmic_bytes": alg[st],
+                          "achieved": alg[st] / (ms * 1e-3) / 1e9 if ms > 0 else None})
+            e["frac"] = (e["achieved"] / e["peak"]) if e.get("achieved") else None
+            kernels.append(e)
+        out["kernels"] = kernels
+        dom = max(kernels, key=lambda k: k["ms"])
+        out["roofline"] = {k: dom.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic")}
+        out["roofline"]["kernel_ms"] = dom["ms"]
+        out["roofline"]["note"] = ("dominant kernel by HIP-event time; traffic = PMC HBM bytes per launch measured in this run "
+                                   "(rocprofv3 child passes, FETCH_SIZE doubled)" + (f"; pmc: {pmc_err}" if pmc_err else ""))
+        hbm = [k for k in kernels if k["bound"] == "hbm" and k["stage"] != "detections"]
+        dom_hbm = max(hbm, key=lambda k: k["ms"])
+        out["roofline_hbm"] = {k: dom_hbm.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic")}
+        out["roofline_hbm"]["kernel_ms"] = dom_hbm["ms"]
+        out["roofline_hbm"]["algorithmic_bytes"] = dom_hbm["algorithmic_bytes"]
+        if not a.plain:
+            try:
+                copy_gbps = measured_copy_rate(torch)
+                out["frame_roofline"]["measured_copy_GBps"] = copy_gbps
+                out["frame_roofline"]["frac_of_measured_copy"] = bytes_frame * fps / world / 1e9 / copy_gbps
+            except Exception as e:   # never fail the bench line over the auxiliary peak
+                print("copy-rate measurement failed:", e, file=sys.stderr)
+        if not a.plain and world == 1 and config == 3:
+            try:
+                out["with_h2d"] = leg_with_h2d(gvamd, synth, g, tfs, config, flags, local_rank, min(a.steps, 100))
+            except Exception as e:
+                out["with_h2d"] = {"error": str(e)}
+            try:
+                out["lidar_like"] = leg_cloud(gvamd, synth, g, tfs, config, flags, bboxes, poses, local_rank,
+                                              min(a.steps, 200), synth.cloud_lidar_like)
+                out["lidar_like"]["note"] = "SURVEY 8(d) config 3(b): range ~ Exp(15 m), 64 rings: hundreds of hits per cell near the sensor"
+            except Exception as e:
+                out["lidar_like"] = {"error": str(e)}
+            try:
+                c5 = synth.CONFIGS[5]
+                leg = leg_cloud(gvamd, synth, c5["grid"], tfs, 5, gvamd.FRAME_BIN | gvamd.FRAME_RAYMARCH, None, None,
+                                local_rank, 20, synth.cloud_uniform)
+                b5 = 12.0 * leg["points"] + 13.0 * c5["grid"].nx * c5["grid"].ny
+                leg.update({"algorithmic_bytes": b5, "achieved_GBps": b5 * leg["value"] / 1e9,
+                            "frac_of_hbm_peak": b5 * leg["value"] / 1e9 / HBM_PEAK_GBPS,
+                            "note": "BASELINE configs[4] workload on ONE GPU (10M uniform points, 4000x4000 grid): ~0.5 GB touched "
+                                    "per frame, past the 256 MiB Infinity Cache"})
+                out["beyond_l3"] = leg
+            except Exception as e:
+                out["beyond_l3"] = {"error": str(e)}
+        if not a.plain and not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(config, cloud_fn, tfs, bboxes, poses, a.cpu_seconds)
             out["gpu_over_cpu"] = fps / out["cpu_baseline"]["value"]
             out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(config, cloud_fn, tfs, bboxes, poses, a.cpu_seconds)

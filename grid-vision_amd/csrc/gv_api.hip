@@ -26,7 +26,7 @@ struct CloudSet {
   uint8_t *raw = nullptr;       // PointCloud2 bytes before the de-interleave
   size_t raw_cap = 0;
   hipEvent_t ready = nullptr;   // copy stream: upload complete
-  hipEvent_t used = nullptr;    // stream A: last frame that reads this set has passed its points pass
+  int release_set = -1;         // ev_build[release_set]: the last frame that reads this set has passed its points pass
 };
 
 // Per-frame detection inputs (bboxes, poses / network outputs) and what the device derives from them.
@@ -46,7 +46,8 @@ struct DetSet {
   bool valid = false;           // a gv_frame_set_detections* call has filled this set
   uint8_t *stage = nullptr;     // pinned host copy of the caller's arrays (free to reuse on return)
   size_t stage_cap = 0;
-  hipEvent_t ready = nullptr, used = nullptr;
+  hipEvent_t ready = nullptr;
+  int release_set = -1;         // as CloudSet::release_set
 };
 
 }  // namespace
@@ -70,6 +71,7 @@ struct gv_context {
   uint8_t *miss8 = nullptr;       // generic path only: byte miss grid of the literal march
   unsigned long long *x_stats[kSets]{};
   int last_set = 0;
+  int last_frame_set = -1;        // buffer set of the most recently enqueued frame (its ev_build marks "inputs consumed")
   uint64_t frame_no = 0;
   int since_drain = 0;            // pipelined frames enqueued since every stream was last idle
   bool pipe_busy = false;
@@ -279,7 +281,7 @@ int ensure_scratch_i32(gv_context *h, size_t n)
 int ensure_det(gv_context *h, DetSet &d, int32_t n)
 {
   if (n <= d.cap) return GV_OK;
-  if (d.used) GV_HIP(hipEventSynchronize(d.used));     // frames that read this set are past it
+  if (d.release_set >= 0) GV_HIP(hipEventSynchronize(h->ev_build[d.release_set]));   // frames that read this set are past it
   if (d.ready) GV_HIP(hipEventSynchronize(d.ready));
   const int32_t want = std::max(n + n / 4, 64);
   auto re = [&](auto *&p, size_t bytes) -> int {
@@ -664,7 +666,7 @@ int enqueue_frame_tiles(gv_context *h, bool pipelined, bool stage_events, bool s
   if (sharded && (!do_bin || !h->comm)) return GV_ERR_STATE;
   const int p = pipelined ? (int)(h->frame_no % (unsigned)h->n_sets) : 0;
   hipStream_t sA = h->stream, sB = pipelined ? h->stream2 : sA, sC = pipelined ? h->stream3 : sA;
-  CloudSet &CS = h->cloud[h->cloud_cur];
+  const CloudSet &CS = h->cloud[h->cloud_cur];
 #ifdef GV_DIAG
   auto mark = [&](hipStream_t st) {   // device timeline of the pipelined frame (gv_debug_pipeline_trace)
     if (!h->trace) return;
@@ -712,13 +714,12 @@ int enqueue_frame_tiles(gv_context *h, bool pipelined, bool stage_events, bool s
   }
   mark(sA);
   mark(sA); mark(sA);   // (trace slot of the former bitmap kernel: the tile pass is part of the binning pair)
-  GV_HIP(hipEventRecord(CS.used, sA));   // the other cloud / detection set may be refilled from here on
-  GV_HIP(hipEventRecord(D.used, sA));
   if (stage_events) GV_HIP(hipEventRecord(h->ev[kStageRayCompact + 1], sA));
-  if (pipelined) {
-    GV_HIP(hipEventRecord(h->ev_build[p], sA));
-    GV_HIP(hipStreamWaitEvent(sB, h->ev_build[p], 0));
-  }
+  // cloud and detections of this frame are consumed: the other cloud / detection set may be refilled
+  // once this event has passed (begin_cloud_upload, set_detections)
+  GV_HIP(hipEventRecord(h->ev_build[p], sA));
+  h->last_frame_set = p;
+  if (pipelined) GV_HIP(hipStreamWaitEvent(sB, h->ev_build[p], 0));
   h->last_set = p;
   h->have_cell_idx = do_bin && keep_cell;
   h->have_bbox_id = do_bbox;
@@ -782,6 +783,8 @@ int enqueue_frame_generic(gv_context *h, bool stage_events)
     a.do_bin = do_bin; a.do_ray = do_ray; a.do_bbox = do_bbox;
     launch_points(a, s);
   }
+  GV_HIP(hipEventRecord(h->ev_build[0], s));   // cloud and detections consumed
+  h->last_frame_set = 0;
   if (stage_events) GV_HIP(hipEventRecord(h->ev[kStagePoints + 1], s));
   if (do_ray && h->org.valid) {
     GV_HIP(hipMemsetAsync(h->ray_count, 0, sizeof(uint32_t), s));
@@ -1022,14 +1025,8 @@ int gv_create(gv_handle *out, uint8_t grid_x, uint8_t grid_y, double resolution,
     GV_C(hipEventCreateWithFlags(&h->ev_sec[i], hipEventDisableTiming));
   }
   for (auto &e : h->ev_join) GV_C(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-  for (auto &c : h->cloud) {
-    GV_C(hipEventCreateWithFlags(&c.ready, hipEventDisableTiming));
-    GV_C(hipEventCreateWithFlags(&c.used, hipEventDisableTiming));
-  }
-  for (auto &d : h->det) {
-    GV_C(hipEventCreateWithFlags(&d.ready, hipEventDisableTiming));
-    GV_C(hipEventCreateWithFlags(&d.used, hipEventDisableTiming));
-  }
+  for (auto &c : h->cloud) GV_C(hipEventCreateWithFlags(&c.ready, hipEventDisableTiming));
+  for (auto &d : h->det) GV_C(hipEventCreateWithFlags(&d.ready, hipEventDisableTiming));
   const size_t G = (size_t)g.G;
   GV_C(hipMalloc(reinterpret_cast<void **>(&h->log_odds), G * sizeof(float)));
   GV_C(hipMalloc(reinterpret_cast<void **>(&h->occupancy), G * sizeof(float)));
@@ -1162,14 +1159,12 @@ int gv_destroy(gv_handle h)
     for (void *p : {(void *)c.x, (void *)c.y, (void *)c.z, (void *)c.raw})
       if (p) (void)hipFree(p);
     if (c.ready) (void)hipEventDestroy(c.ready);
-    if (c.used) (void)hipEventDestroy(c.used);
   }
   for (auto &d : h->det) {
     for (void *p : {(void *)d.bboxes, (void *)d.poses, (void *)d.orient, (void *)d.conf, (void *)d.dims, (void *)d.bbox_f, (void *)d.tile_mask})
       if (p) (void)hipFree(p);
     if (d.stage) (void)hipHostFree(d.stage);
     if (d.ready) (void)hipEventDestroy(d.ready);
-    if (d.used) (void)hipEventDestroy(d.used);
   }
   for (auto &e : h->ev)
     if (e) (void)hipEventDestroy(e);
@@ -1254,7 +1249,7 @@ int begin_cloud_upload(gv_context *h, size_t n, int &target)
   target = h->cloud_cur ^ 1;
   CloudSet &c = h->cloud[target];
   if (n > c.cap) {
-    GV_HIP(hipEventSynchronize(c.used));
+    if (c.release_set >= 0) GV_HIP(hipEventSynchronize(h->ev_build[c.release_set]));
     GV_HIP(hipEventSynchronize(c.ready));
     for (float **p : {&c.x, &c.y, &c.z}) {
       if (*p) GV_HIP(hipFree(*p));
@@ -1267,7 +1262,8 @@ int begin_cloud_upload(gv_context *h, size_t n, int &target)
     GV_HIP(hipMalloc(reinterpret_cast<void **>(&c.z), want * sizeof(float)));
     c.cap = want;
   }
-  GV_HIP(hipStreamWaitEvent(h->stream_copy, c.used, 0));
+  // ordered after the last frame that reads this set (a later re-record of the event only waits longer)
+  if (c.release_set >= 0) GV_HIP(hipStreamWaitEvent(h->stream_copy, h->ev_build[c.release_set], 0));
   return GV_OK;
 }
 
@@ -1275,6 +1271,7 @@ int end_cloud_upload(gv_context *h, int target, size_t n)
 {
   CloudSet &c = h->cloud[target];
   GV_HIP(hipEventRecord(c.ready, h->stream_copy));
+  h->cloud[h->cloud_cur].release_set = h->last_frame_set;   // frames enqueued so far are its last readers
   h->cloud_cur = target;
   h->cx = c.x; h->cy = c.y; h->cz = c.z;
   h->n = n;
@@ -1336,13 +1333,15 @@ int set_detections(gv_context *h, const gv_frame_desc *d, bool wait)
   // shared rectangle / vision buffers may have to grow (drains); do it before ordering the copy stream
   if ((rc = ensure_det_shared(h, std::max(d->n_bboxes, d->n_poses)))) return rc;
   if ((rc = ensure_det(h, D, std::max(d->n_bboxes, d->n_poses)))) return rc;
-  GV_HIP(hipStreamWaitEvent(h->stream_copy, D.used, 0));   // frames that read this set are past their points pass
+  if (D.release_set >= 0)   // frames that read this set are past their points pass
+    GV_HIP(hipStreamWaitEvent(h->stream_copy, h->ev_build[D.release_set], 0));
   const bool net = vision && d->n_bboxes;
   if ((rc = upload_det(h, D, d->bboxes, d->n_bboxes, vision ? nullptr : d->poses, vision ? 0 : d->n_poses,
                        net ? d->orient : nullptr, net ? d->conf : nullptr, net ? d->dims : nullptr, h->stream_copy)))
     return rc;
   D.flags = d->flags;
   GV_HIP(hipEventRecord(D.ready, h->stream_copy));
+  h->det[h->det_cur].release_set = h->last_frame_set;
   h->det_cur = target;
   h->det_wait = true;
   if (wait) GV_HIP(hipEventSynchronize(D.ready));

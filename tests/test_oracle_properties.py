@@ -259,3 +259,16 @@ def test_host_side_entry_points_match_oracle():
     assert lib.gv_extract_bboxes(None, None, C.c_int32(5), C.c_int32(10), C.c_double(0.5), C.c_double(0.5),
                                  C.c_int32(640), C.c_int32(480), C.c_int32(416), None, None) == 1   # GV_ERR_BAD_ARG
     assert lib.gv_destroy(None) == 1 and lib.gv_update_map(None) == 1
+
+
+def test_bench_refuses_to_shrink_a_multi_gpu_job():
+    """bench.py --gpus N without a torchrun environment launches the ranks itself; with fewer GPUs
+    visible than asked for it must fail loudly instead of reporting n_gpus: 1 (no GPU here: exit 2)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, timeout=120)
+    assert p.returncode != 0
+    assert b'"n_gpus"' not in p.stdout
+    assert b"refusing" in p.stderr
