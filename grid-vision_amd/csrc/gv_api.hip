@@ -1018,7 +1018,13 @@ int gv_create(gv_handle *out, uint8_t grid_x, uint8_t grid_y, double resolution,
   GV_C(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
   GV_C(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
   GV_C(hipStreamCreateWithFlags(&h->stream3, hipStreamNonBlocking));
-  GV_C(hipStreamCreateWithFlags(&h->stream_copy, hipStreamNonBlocking));
+  {
+    // the H2D copies of the next cloud must not queue behind the frame's kernels (they are the longest
+    // stage of a streaming frame: 12 MB over PCIe): highest priority for the copy stream
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+    GV_C(hipStreamCreateWithPriority(&h->stream_copy, hipStreamNonBlocking, hi));
+  }
   for (int i = 0; i < gv_context::kSets; ++i) {
     GV_C(hipEventCreateWithFlags(&h->ev_build[i], hipEventDisableTiming));
     GV_C(hipEventCreateWithFlags(&h->ev_fin[i], hipEventDisableTiming));

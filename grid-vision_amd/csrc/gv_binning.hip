@@ -189,6 +189,7 @@ __global__ void __launch_bounds__(kTileThreads) k_bin_tiles(BinTileArgs a)
   __shared__ unsigned hist[kBinTileCells];           // 64 KB
   __shared__ unsigned bits[2][kBinTile][4];          // [0] hit, [1] clipped end: bit x of row y
   __shared__ unsigned s_scanh[kTileThreads / 64], s_scane[kTileThreads / 64];
+  __shared__ unsigned s_lbase[kTileThreads], s_llen[kTileThreads], s_nlong;   // long segments of one round
   __shared__ int s_t, s_sp, s_slot;
   __shared__ unsigned s_ticket;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -263,6 +264,7 @@ __global__ void __launch_bounds__(kTileThreads) k_bin_tiles(BinTileArgs a)
   unsigned desc = fetch_desc(0);
   for (int c = tid; c < kBinTileCells / 4; c += kTileThreads) reinterpret_cast<uint4 *>(hist)[c] = make_uint4(0, 0, 0, 0);
   if (tid < 2 * kBinTile * 4) (&bits[0][0][0])[tid] = 0;
+  if (tid == 0) s_nlong = 0;
   __syncthreads();
   GV_STAMP(a.dbg, 2);   // LDS zeroed, first descriptors on their way
   auto add_key = [&](unsigned kk) {
@@ -273,6 +275,11 @@ __global__ void __launch_bounds__(kTileThreads) k_bin_tiles(BinTileArgs a)
   const uint32_t nrounds = (nshare + 16u * kGroups - 1) / (16u * kGroups);
   for (uint32_t round = 0; round < nrounds; ++round) {
     const unsigned next = (round + 1 < nrounds) ? fetch_desc(round + 1) : 0u;
+    if (round) {
+      __syncthreads();   // the long-segment list of the previous round is consumed
+      if (tid == 0) s_nlong = 0;
+      __syncthreads();
+    }
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
       unsigned sg[8], key[8];
@@ -281,21 +288,59 @@ __global__ void __launch_bounds__(kTileThreads) k_bin_tiles(BinTileArgs a)
         sg[u] = (unsigned)__shfl((int)desc, half * 8 + u, 16);
         const unsigned s0 = sg[u] & 0xFFFFu, e0 = sg[u] >> 16;
         const uint32_t q = (uint32_t)grp + (uint32_t)kGroups * (16u * round + (uint32_t)(half * 8 + u));
-        const unsigned short *kp = a.keys + (size_t)((uint32_t)sp + q * k) * a.chunk;   // not dereferenced when the segment is empty
-        key[u] = (s0 + (unsigned)l16 < e0) ? (unsigned)kp[s0 + l16] : 0xFFFFu;
-      }
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        if (key[u] != 0xFFFFu) add_key(key[u]);
-        const unsigned s0 = sg[u] & 0xFFFFu, e0 = sg[u] >> 16;
-        if (e0 - s0 > 16u) {   // a long segment (crowded tile): the rest of it, 16 keys per step
-          const uint32_t q = (uint32_t)grp + (uint32_t)kGroups * (16u * round + (uint32_t)(half * 8 + u));
-          const unsigned short *kp = a.keys + (size_t)((uint32_t)sp + q * k) * a.chunk;
-          for (unsigned jj = s0 + 16u + (unsigned)l16; jj < e0; jj += 16u) add_key((unsigned)kp[jj]);
+        const uint32_t kb = ((uint32_t)sp + q * k) * a.chunk;   // first key of the chunk (n_wg * chunk < 2^32)
+        key[u] = (s0 + (unsigned)l16 < e0) ? (unsigned)a.keys[kb + s0 + l16] : 0xFFFFu;   // not dereferenced when the segment is empty
+        // more than 16 keys (a crowded tile): the rest goes to the whole workgroup, see below
+        if (l16 == 0 && e0 - s0 > 16u) {
+          const unsigned slot = atomicAdd(&s_nlong, 1u);
+          s_lbase[slot] = kb + s0 + 16u;
+          s_llen[slot] = e0 - s0 - 16u;
         }
       }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (key[u] != 0xFFFFu) add_key(key[u]);
     }
     desc = next;
+    __syncthreads();
+    const unsigned nl = s_nlong;   // <= 1024 segments per round
+    if (nl) {
+      // Long segments: their remaining keys form one flat index space, prefix-summed over the list, that all
+      // 1024 lanes walk with independent loads (4 in flight per lane) -- the tile next to the sensor of a
+      // real lidar holds tens of thousands of keys in a few hundred segments.
+      const unsigned mine = ((unsigned)tid < nl) ? s_llen[tid] : 0u;
+      const unsigned incl = wave_incl_scan_add(mine);
+      if (lane == 63) s_scanh[wave] = incl;
+      __syncthreads();
+      unsigned excl = incl - mine, total = 0;
+#pragma unroll
+      for (int wv = 0; wv < kTileThreads / 64; ++wv) {
+        const unsigned t2 = s_scanh[wv];
+        if (wv < wave) excl += t2;
+        total += t2;
+      }
+      if ((unsigned)tid < nl) s_llen[tid] = excl;   // exclusive prefix: first flat index of segment tid
+      __syncthreads();
+      auto locate = [&](unsigned f) -> uint32_t {   // key address of flat index f
+        unsigned lo = 0, hi = nl;
+        while (hi - lo > 1u) {
+          const unsigned mid = (lo + hi) >> 1;
+          if (s_llen[mid] <= f) lo = mid; else hi = mid;
+        }
+        return s_lbase[lo] + (f - s_llen[lo]);
+      };
+      for (unsigned f0 = (unsigned)tid; f0 < total; f0 += 4u * kTileThreads) {
+        unsigned kk[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const unsigned f = f0 + (unsigned)u * kTileThreads;
+          kk[u] = (f < total) ? (unsigned)a.keys[locate(f)] : 0xFFFFu;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (kk[u] != 0xFFFFu) add_key(kk[u]);
+      }
+    }
   }
   __syncthreads();
   GV_STAMP(a.dbg, 3);   // keys histogrammed
