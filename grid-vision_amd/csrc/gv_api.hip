@@ -572,10 +572,15 @@ int enqueue_binning(gv_context *h, const DetSet &D, int p, size_t lo, size_t n, 
   a.cam = h->camk;
   a.org = h->org;
   a.bt = bbox_test_of(h, D);
+  a.nb = D.nb;
+  a.nb_pad = (D.nb + 3) & ~3;
   a.bbox_id = h->bbox_id + lo;
   a.cell_idx = keep_cell ? h->cell_idx + lo : nullptr;
   a.do_ray = do_ray;
-  a.do_bbox = do_bbox;
+  // the fused bbox test keeps its tables in LDS; a detection set too large for that (hundreds of boxes, or a
+  // large image: one mask word per 16x16-pixel tile) runs the test as a pass of its own over the cloud
+  const bool bbox_fused = do_bbox && bin_bbox_fits(D.nb, a.bt);
+  a.do_bbox = bbox_fused;
   a.chunk = chunk;
   a.n_wg = n_wg;
   a.tiles_x = h->tiles_x; a.tiles_y = h->tiles_y; a.n_tiles = h->n_tiles;
@@ -586,6 +591,18 @@ int enqueue_binning(gv_context *h, const DetSet &D, int p, size_t lo, size_t n, 
   a.dbg = h->d_bin_dbg[0];
 #endif
   launch_bin_partition(a, s);
+  if (do_bbox && !bbox_fused) {
+    PointsArgs pa{};
+    pa.x = a.x; pa.y = a.y; pa.z = a.z;
+    pa.n = a.n;
+    pa.g = h->g;
+    pa.m_cam = h->m_cam;
+    pa.cam = h->camk;
+    pa.bt = a.bt;
+    pa.bbox_id = a.bbox_id;
+    pa.do_bbox = true;
+    launch_points(pa, s);
+  }
   if (ev_points) GV_HIP(hipEventRecord(ev_points, s));
   BinTileArgs t{};
   t.nx = h->g.nx; t.ny = h->g.ny;

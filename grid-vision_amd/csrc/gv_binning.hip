@@ -73,35 +73,59 @@ __global__ void __launch_bounds__(kPartThreads, 8) k_bin_partition(BinArgs a)
   GV_STAMP(a.dbg, 0);
   for (int t = tid; t < T; t += kPartThreads) hist[t] = 0;
   if (tid == 0) s_nout = 0;
+  // bbox test: thresholds and tile candidate masks staged in LDS -- per point they are a chain of dependent
+  // look-ups (mask word -> one threshold quadruple per candidate), an LDS latency each instead of a global one
+  BBoxTest lbt = a.bt;
+  if (BBOX) {
+    const size_t off = ((size_t)a.chunk * 4 + (size_t)T * 4 + (size_t)a.chunk * 2 + 15) & ~(size_t)15;
+    float4 *l_bbox = reinterpret_cast<float4 *>(smem + off);
+    unsigned long long *l_mask = reinterpret_cast<unsigned long long *>(smem + off + (size_t)a.nb_pad * 16);
+    const int nmask = a.bt.tiles_x * a.bt.tiles_y * a.bt.mask_words;
+    for (int q = tid; q < a.nb; q += kPartThreads) l_bbox[q] = a.bt.bbox_f[q];
+    for (int q = tid; q < nmask; q += kPartThreads) l_mask[q] = a.bt.tile_mask[q];
+    lbt.bbox_f = l_bbox;
+    lbt.tile_mask = l_mask;
+  }
   __syncthreads();
 
-  for (uint32_t k = tid; k < a.chunk; k += kPartThreads) {
-    unsigned st = kStagedNone;
-    if (k < npts) {
-      const uint32_t i = base + k;
-      const float px = a.x[i], py = a.y[i], pz = a.z[i];
-      float bx, by, bz;
-      xform34(a.m_base, px, py, pz, bx, by, bz);
-      int cell = -1;
-      if (isfinite(bx) && isfinite(by) && isfinite(bz)) {
-        int ix, iy;
-        if (get_index_fast(a.g, (double)bx, (double)by, ix, iy)) {
-          cell = iy * a.g.nx + ix;
-          const unsigned tile = (unsigned)((iy >> kBinTileLog) * a.tiles_x + (ix >> kBinTileLog));
-          st = (tile << 16) | (unsigned)(((iy & (kBinTile - 1)) << kBinTileLog) | (ix & (kBinTile - 1)));
-          atomicAdd(&hist[tile], 1u);
-        } else if (RAY && a.org.valid) {
-          st = kStagedOutside;
+  // two points per lane and step, both loads issued before either is used (chunk % (2 * kPartThreads) == 0)
+  for (uint32_t k0 = tid; k0 < a.chunk; k0 += 2 * kPartThreads) {
+    float px[2], py[2], pz[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const uint32_t k = k0 + (uint32_t)u * kPartThreads;
+      px[u] = py[u] = pz[u] = 0.0f;
+      if (k < npts) { px[u] = a.x[base + k]; py[u] = a.y[base + k]; pz[u] = a.z[base + k]; }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const uint32_t k = k0 + (uint32_t)u * kPartThreads;
+      unsigned st = kStagedNone;
+      if (k < npts) {
+        const uint32_t i = base + k;
+        float bx, by, bz;
+        xform34(a.m_base, px[u], py[u], pz[u], bx, by, bz);
+        int cell = -1;
+        if (isfinite(bx) && isfinite(by) && isfinite(bz)) {
+          int ix, iy;
+          if (get_index_fast(a.g, (double)bx, (double)by, ix, iy)) {
+            cell = iy * a.g.nx + ix;
+            const unsigned tile = (unsigned)((iy >> kBinTileLog) * a.tiles_x + (ix >> kBinTileLog));
+            st = (tile << 16) | (unsigned)(((iy & (kBinTile - 1)) << kBinTileLog) | (ix & (kBinTile - 1)));
+            atomicAdd(&hist[tile], 1u);
+          } else if (RAY && a.org.valid) {
+            st = kStagedOutside;
+          }
+        }
+        if (KEEPCELL) a.cell_idx[i] = cell;
+        if (BBOX) {
+          float cx, cy, cz;
+          xform34(a.m_cam, px[u], py[u], pz[u], cx, cy, cz);
+          a.bbox_id[i] = (int16_t)first_bbox(a.cam, lbt, cx, cy, cz);
         }
       }
-      if (KEEPCELL) a.cell_idx[i] = cell;
-      if (BBOX) {
-        float cx, cy, cz;
-        xform34(a.m_cam, px, py, pz, cx, cy, cz);
-        a.bbox_id[i] = (int16_t)first_bbox(a.cam, a.bt, cx, cy, cz);
-      }
+      staged[k] = st;
     }
-    staged[k] = st;
   }
   __syncthreads();
   GV_STAMP(a.dbg, 1);   // points done
@@ -445,10 +469,18 @@ uint32_t bin_chunk_for(size_t n)
 
 size_t bin_partition_lds(uint32_t chunk, int n_tiles) { return (size_t)chunk * 4 + (size_t)n_tiles * 4 + (size_t)chunk * 2; }
 
+// LDS bytes of the bbox-test tables (thresholds + tile candidate masks)
+size_t bin_bbox_lds(int nb_pad, const BBoxTest &bt)
+{
+  return 16 + (size_t)nb_pad * 16 + (size_t)bt.tiles_x * bt.tiles_y * bt.mask_words * 8;
+}
+
+bool bin_bbox_fits(int nb, const BBoxTest &bt) { return bin_bbox_lds((nb + 3) & ~3, bt) <= kBinBBoxLdsMax; }
+
 void launch_bin_partition(const BinArgs &a, hipStream_t s)
 {
   if (a.n_wg == 0) return;
-  const size_t lds = bin_partition_lds(a.chunk, a.n_tiles);
+  const size_t lds = bin_partition_lds(a.chunk, a.n_tiles) + (a.do_bbox ? bin_bbox_lds(a.nb_pad, a.bt) : 0);
   const bool keep = a.cell_idx != nullptr;
 #define GV_BP(R, X, K) hipLaunchKernelGGL((k_bin_partition<R, X, K>), dim3(a.n_wg), dim3(kPartThreads), lds, s, a)
   if (a.do_ray && a.do_bbox && keep) GV_BP(true, true, true);

@@ -93,9 +93,10 @@ struct BinArgs {
   CamK cam;
   RayOrigin org;
   BBoxTest bt;
+  int32_t nb, nb_pad;      // bboxes of the test (do_bbox); nb rounded up to a multiple of 4
   int16_t *bbox_id;        // N (do_bbox)
   int32_t *cell_idx;       // N or null
-  bool do_ray, do_bbox;
+  bool do_ray, do_bbox;    // do_bbox needs bin_bbox_fits(): the test's tables are staged in LDS
   uint32_t chunk;          // points per partition workgroup (multiple of 256, <= 32768)
   uint32_t n_wg;           // ceil(n / chunk)
   int32_t tiles_x, tiles_y, n_tiles;
@@ -104,7 +105,9 @@ struct BinArgs {
   uint32_t *tile_total;    // [n_tiles]  keys per tile over all chunks (zero on entry)
   unsigned long long *dbg; // diagnostic build: 16 clock stamps per workgroup (null in production)
 };
+constexpr size_t kBinBBoxLdsMax = 24 * 1024;   // LDS the partition kernel may spend on the bbox-test tables
 uint32_t bin_chunk_for(size_t n);
+bool bin_bbox_fits(int nb, const BBoxTest &bt);
 void launch_bin_partition(const BinArgs &a, hipStream_t s);
 
 struct BinTileArgs {
