@@ -33,6 +33,7 @@ struct CloudSet {
 // Sets 0/1 alternate between "read by the frames in flight" and "being uploaded"; set 2 belongs to the
 // standalone entry points of the reference surface, which therefore never disturb the frame's inputs.
 struct DetSet {
+  uint8_t *block = nullptr;                  // ONE device allocation = one H2D copy per frame; the arrays below point into it
   gv_bbox *bboxes = nullptr;
   gv_lshape_pose *poses = nullptr;
   float *orient = nullptr, *conf = nullptr, *dims = nullptr;
@@ -56,10 +57,11 @@ struct gv_context {
   static constexpr int kSets = 4;
   int device = 0;
   // A: detections, partition, tile histogram of frame f+1 (and every non-frame entry point);
-  // B: sector ray stage of frame f;  C: grid pass of frame f;  copy: H2D of the next cloud / detections
-  hipStream_t stream = nullptr, stream2 = nullptr, stream3 = nullptr, stream_copy = nullptr;
+  // B: sector ray stage of frame f;  C: grid pass of frame f;  copy: H2D of the next cloud;  det: H2D of the
+  // next detections + their bbox-test tables (a stream of its own: it must not queue behind the 12 MB cloud copy)
+  hipStream_t stream = nullptr, stream2 = nullptr, stream3 = nullptr, stream_copy = nullptr, stream_det = nullptr;
   hipEvent_t ev_build[kSets]{}, ev_sec[kSets]{}, ev_fin[kSets]{};
-  hipEvent_t ev_join[3]{};
+  hipEvent_t ev_join[4]{};
   int n_sets = 3;                 // GV_PIPE_SETS (2..4): buffer sets the pipelined frames rotate through
   // per-set buffers of the frames in flight: end bitmaps, rectangles, miss grids, ray statistics
   uint32_t *x_ends[kSets]{};      // one allocation per set: [hitN | clipN | hitT | clipT], ends_words in all
@@ -206,6 +208,7 @@ int grow(gv_context *h, T *&p, size_t &cap, size_t need)
 int drain(gv_context *h)
 {
   GV_HIP(hipStreamSynchronize(h->stream_copy));
+  GV_HIP(hipStreamSynchronize(h->stream_det));
   GV_HIP(hipStreamSynchronize(h->stream));
   GV_HIP(hipStreamSynchronize(h->stream2));
   GV_HIP(hipStreamSynchronize(h->stream3));
@@ -240,7 +243,8 @@ int ensure_point_buffers(gv_context *h, size_t n)
   const bool need_idx = n > h->idx_cap || !h->cell_idx;
   const uint32_t chunk = bin_chunk_for(n);
   const size_t n_wg = (n + chunk - 1) / chunk;
-  const size_t keys_need = n_wg * chunk + 2, tab_need = n_wg * ((size_t)h->n_tiles + 1) + 2;
+  const size_t keys_need = n_wg * chunk + 64;   // + slack: the tile pass reads whole 16-byte windows
+  const size_t tab_need = n_wg * ((size_t)h->n_tiles + 1) + 2;
   const size_t slots_need = n / kBinSplitKeys + 1;
   const bool need_bin = sector_path(h) && (keys_need > h->bin_keys_cap || tab_need > h->bin_tab_cap || slots_need > h->bin_slots);
   if (!need_idx && !need_bin) return GV_OK;
@@ -278,28 +282,50 @@ int ensure_scratch_i32(gv_context *h, size_t n)
   return grow(h, h->scratch_i32, h->scratch_cap, n + n / 8);
 }
 
+// layout of a detection block for `cap` entries (host staging and device copy share it)
+struct DetLayout {
+  size_t bboxes, poses, orient, conf, dims, total;
+};
+DetLayout det_layout(int32_t cap)
+{
+  DetLayout L;
+  size_t o = 0;
+  L.bboxes = o; o += (size_t)cap * sizeof(gv_bbox);
+  L.poses = o;  o += (size_t)cap * sizeof(gv_lshape_pose);
+  L.orient = o; o += (size_t)cap * 4 * sizeof(float);
+  L.conf = o;   o += (size_t)cap * 2 * sizeof(float);
+  L.dims = o;   o += (size_t)cap * 3 * sizeof(float);
+  L.total = (o + 15) & ~(size_t)15;
+  return L;
+}
+
 int ensure_det(gv_context *h, DetSet &d, int32_t n)
 {
   if (n <= d.cap) return GV_OK;
   if (d.release_set >= 0) GV_HIP(hipEventSynchronize(h->ev_build[d.release_set]));   // frames that read this set are past it
   if (d.ready) GV_HIP(hipEventSynchronize(d.ready));
   const int32_t want = std::max(n + n / 4, 64);
-  auto re = [&](auto *&p, size_t bytes) -> int {
-    if (p) GV_HIP(hipFree(p));
-    p = nullptr;
-    GV_HIP(hipMalloc(reinterpret_cast<void **>(&p), bytes));
-    return GV_OK;
-  };
-  int rc;
+  const DetLayout L = det_layout(want);
   d.cap = 0;
-  if ((rc = re(d.bboxes, (size_t)want * sizeof(gv_bbox)))) return rc;
-  if ((rc = re(d.poses, (size_t)want * sizeof(gv_lshape_pose)))) return rc;
-  if ((rc = re(d.orient, (size_t)want * 4 * sizeof(float)))) return rc;
-  if ((rc = re(d.conf, (size_t)want * 2 * sizeof(float)))) return rc;
-  if ((rc = re(d.dims, (size_t)want * 3 * sizeof(float)))) return rc;
-  if ((rc = re(d.bbox_f, (size_t)want * sizeof(float4)))) return rc;
+  if (d.block) GV_HIP(hipFree(d.block));
+  d.block = nullptr;
+  GV_HIP(hipMalloc(reinterpret_cast<void **>(&d.block), L.total));
+  d.bboxes = reinterpret_cast<gv_bbox *>(d.block + L.bboxes);
+  d.poses = reinterpret_cast<gv_lshape_pose *>(d.block + L.poses);
+  d.orient = reinterpret_cast<float *>(d.block + L.orient);
+  d.conf = reinterpret_cast<float *>(d.block + L.conf);
+  d.dims = reinterpret_cast<float *>(d.block + L.dims);
+  if (d.bbox_f) GV_HIP(hipFree(d.bbox_f));
+  d.bbox_f = nullptr;
+  GV_HIP(hipMalloc(reinterpret_cast<void **>(&d.bbox_f), (size_t)want * sizeof(float4)));
   const size_t nmask = (size_t)h->bt_tiles_x * h->bt_tiles_y * (size_t)((want + 63) / 64);
-  if ((rc = grow(h, d.tile_mask, d.tile_mask_cap, nmask))) return rc;
+  int rc = grow(h, d.tile_mask, d.tile_mask_cap, nmask);
+  if (rc) return rc;
+  if (d.stage) GV_HIP(hipHostFree(d.stage));
+  d.stage = nullptr;
+  d.stage_cap = 0;
+  GV_HIP(hipHostMalloc(reinterpret_cast<void **>(&d.stage), L.total, hipHostMallocDefault));
+  d.stage_cap = L.total;
   d.cap = want;
   return GV_OK;
 }
@@ -362,40 +388,28 @@ BBoxTest bbox_test_of(const gv_context *h, const DetSet &d)
 }
 
 // Upload the small per-frame arrays into detection set `d` on stream `s` and derive the bbox-test
-// tables there.  The caller's arrays are copied into the set's pinned staging first, so they are free
-// on return and the H2D copies are asynchronous.
+// tables there.  The caller's arrays are copied into the set's pinned staging block first (they are
+// free on return) and the block goes to the device in ONE asynchronous copy.
 int upload_det(gv_context *h, DetSet &d, const gv_bbox *bboxes, int32_t nb, const gv_lshape_pose *poses,
                int32_t n_poses, const float *orient, const float *conf, const float *dims, hipStream_t s)
 {
   int rc = ensure_det(h, d, std::max(nb, n_poses));
   if (rc) return rc;
   if ((rc = ensure_det_shared(h, std::max(nb, n_poses)))) return rc;
-  const size_t b_bytes = (size_t)nb * sizeof(gv_bbox), p_bytes = (size_t)n_poses * sizeof(gv_lshape_pose);
-  const size_t o_bytes = orient ? (size_t)nb * 4 * sizeof(float) : 0, c_bytes = conf ? (size_t)nb * 2 * sizeof(float) : 0;
-  const size_t d_bytes = dims ? (size_t)nb * 3 * sizeof(float) : 0;
-  const size_t total = b_bytes + p_bytes + o_bytes + c_bytes + d_bytes;
   if (d.ready) GV_HIP(hipEventSynchronize(d.ready));   // the staging's previous copy has left it
-  if (total > d.stage_cap) {
-    if (d.stage) GV_HIP(hipHostFree(d.stage));
-    d.stage = nullptr;
-    d.stage_cap = 0;
-    const size_t want = total + total / 2 + 4096;
-    GV_HIP(hipHostMalloc(reinterpret_cast<void **>(&d.stage), want, hipHostMallocDefault));
-    d.stage_cap = want;
-  }
-  uint8_t *q = d.stage;
-  auto put = [&](void *dev, const void *src, size_t bytes) -> int {
-    if (!bytes) return GV_OK;
-    std::memcpy(q, src, bytes);
-    GV_HIP(hipMemcpyAsync(dev, q, bytes, hipMemcpyHostToDevice, s));
-    q += bytes;
-    return GV_OK;
+  const DetLayout L = det_layout(d.cap);
+  size_t used = 0;   // the block is copied up to the end of the last array in use
+  auto put = [&](size_t off, const void *src, size_t bytes) {
+    if (!bytes) return;
+    std::memcpy(d.stage + off, src, bytes);
+    used = std::max(used, off + bytes);
   };
-  if ((rc = put(d.bboxes, bboxes, b_bytes))) return rc;
-  if ((rc = put(d.poses, poses, p_bytes))) return rc;
-  if ((rc = put(d.orient, orient, o_bytes))) return rc;
-  if ((rc = put(d.conf, conf, c_bytes))) return rc;
-  if ((rc = put(d.dims, dims, d_bytes))) return rc;
+  put(L.bboxes, bboxes, (size_t)nb * sizeof(gv_bbox));
+  put(L.poses, poses, (size_t)n_poses * sizeof(gv_lshape_pose));
+  if (orient) put(L.orient, orient, (size_t)nb * 4 * sizeof(float));
+  if (conf) put(L.conf, conf, (size_t)nb * 2 * sizeof(float));
+  if (dims) put(L.dims, dims, (size_t)nb * 3 * sizeof(float));
+  if (used) GV_HIP(hipMemcpyAsync(d.block, d.stage, used, hipMemcpyHostToDevice, s));
   d.mask_words = std::max(1, (nb + 63) / 64);
   launch_bbox_prepare(d.bboxes, nb, h->bt_tiles_x, h->bt_tiles_y, d.mask_words, d.bbox_f, d.tile_mask, s);
   GV_HIP(hipGetLastError());
@@ -1035,13 +1049,8 @@ int gv_create(gv_handle *out, uint8_t grid_x, uint8_t grid_y, double resolution,
   GV_C(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
   GV_C(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
   GV_C(hipStreamCreateWithFlags(&h->stream3, hipStreamNonBlocking));
-  {
-    // the H2D copies of the next cloud must not queue behind the frame's kernels (they are the longest
-    // stage of a streaming frame: 12 MB over PCIe): highest priority for the copy stream
-    int lo = 0, hi = 0;
-    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-    GV_C(hipStreamCreateWithPriority(&h->stream_copy, hipStreamNonBlocking, hi));
-  }
+  GV_C(hipStreamCreateWithFlags(&h->stream_copy, hipStreamNonBlocking));
+  GV_C(hipStreamCreateWithFlags(&h->stream_det, hipStreamNonBlocking));
   for (int i = 0; i < gv_context::kSets; ++i) {
     GV_C(hipEventCreateWithFlags(&h->ev_build[i], hipEventDisableTiming));
     GV_C(hipEventCreateWithFlags(&h->ev_fin[i], hipEventDisableTiming));
@@ -1159,7 +1168,7 @@ int gv_destroy(gv_handle h)
 {
   if (!h) return GV_ERR_BAD_ARG;
   (void)hipSetDevice(h->device);
-  for (hipStream_t s : {h->stream_copy, h->stream, h->stream2, h->stream3})
+  for (hipStream_t s : {h->stream_copy, h->stream_det, h->stream, h->stream2, h->stream3})
     if (s) (void)hipStreamSynchronize(s);
   if (h->comm) { ncclCommDestroy(h->comm); h->comm = nullptr; }
   void *bufs[] = {h->log_odds, h->occupancy, h->occ_i8, h->hits, h->clip_end, h->miss8, h->sh_xchg, h->ray_list, h->ray_count, h->scratch_i32,
@@ -1184,7 +1193,7 @@ int gv_destroy(gv_handle h)
     if (c.ready) (void)hipEventDestroy(c.ready);
   }
   for (auto &d : h->det) {
-    for (void *p : {(void *)d.bboxes, (void *)d.poses, (void *)d.orient, (void *)d.conf, (void *)d.dims, (void *)d.bbox_f, (void *)d.tile_mask})
+    for (void *p : {(void *)d.block, (void *)d.bbox_f, (void *)d.tile_mask})
       if (p) (void)hipFree(p);
     if (d.stage) (void)hipHostFree(d.stage);
     if (d.ready) (void)hipEventDestroy(d.ready);
@@ -1198,7 +1207,7 @@ int gv_destroy(gv_handle h)
     if (h->ev_fin[i]) (void)hipEventDestroy(h->ev_fin[i]);
     if (h->ev_sec[i]) (void)hipEventDestroy(h->ev_sec[i]);
   }
-  for (hipStream_t s : {h->stream3, h->stream2, h->stream_copy, h->stream})
+  for (hipStream_t s : {h->stream3, h->stream2, h->stream_det, h->stream_copy, h->stream})
     if (s) (void)hipStreamDestroy(s);
   delete h;
   return GV_OK;
@@ -1357,13 +1366,13 @@ int set_detections(gv_context *h, const gv_frame_desc *d, bool wait)
   if ((rc = ensure_det_shared(h, std::max(d->n_bboxes, d->n_poses)))) return rc;
   if ((rc = ensure_det(h, D, std::max(d->n_bboxes, d->n_poses)))) return rc;
   if (D.release_set >= 0)   // frames that read this set are past their points pass
-    GV_HIP(hipStreamWaitEvent(h->stream_copy, h->ev_build[D.release_set], 0));
+    GV_HIP(hipStreamWaitEvent(h->stream_det, h->ev_build[D.release_set], 0));
   const bool net = vision && d->n_bboxes;
   if ((rc = upload_det(h, D, d->bboxes, d->n_bboxes, vision ? nullptr : d->poses, vision ? 0 : d->n_poses,
-                       net ? d->orient : nullptr, net ? d->conf : nullptr, net ? d->dims : nullptr, h->stream_copy)))
+                       net ? d->orient : nullptr, net ? d->conf : nullptr, net ? d->dims : nullptr, h->stream_det)))
     return rc;
   D.flags = d->flags;
-  GV_HIP(hipEventRecord(D.ready, h->stream_copy));
+  GV_HIP(hipEventRecord(D.ready, h->stream_det));
   h->det[h->det_cur].release_set = h->last_frame_set;
   h->det_cur = target;
   h->det_wait = true;
@@ -1749,8 +1758,8 @@ int gv_frame_fence(gv_handle h)
   int rc = set_device_only(h);
   if (rc) return rc;
   if (h->pipe_busy) {   // join streams B and C (and the copy stream) into stream A
-    hipStream_t others[3] = {h->stream2, h->stream3, h->stream_copy};
-    for (int k = 0; k < 3; ++k) {
+    hipStream_t others[4] = {h->stream2, h->stream3, h->stream_copy, h->stream_det};
+    for (int k = 0; k < 4; ++k) {
       GV_HIP(hipEventRecord(h->ev_join[k], others[k]));
       GV_HIP(hipStreamWaitEvent(h->stream, h->ev_join[k], 0));
     }

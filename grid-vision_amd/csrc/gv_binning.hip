@@ -271,21 +271,23 @@ __global__ void __launch_bounds__(kTileThreads) k_bin_tiles(BinTileArgs a)
   }
 
   GV_STAMP(a.dbg, 1);   // role known
-  // ---- gather: this share takes the chunks sp, sp + k, sp + 2k, ...  Sixteen lanes per chunk segment; a
-  // group first fetches the (start, end) pairs of its next 16 segments, one per lane, while the LDS is being
-  // zeroed, then has the first 16 keys of up to 8 segments in flight at once: two dependent global
-  // latencies for the whole tile instead of one per barrier-separated stage.
+  // ---- gather: this share takes the chunks sp, sp + k, sp + 2k, ...  One lane per chunk segment: it fetches
+  // the segment's (start, end) pair while the LDS is being zeroed, then the two aligned 16-byte windows (8 keys
+  // each) that hold the segment's first keys -- at ~7 keys per segment that is the whole segment -- so the tile
+  // costs two dependent global latencies.  What a crowded tile's segments hold beyond that goes to a list the
+  // wavefronts then stream through with 16-byte loads, 512 keys per wave instruction.
   const uint32_t nshare = (a.n_wg > (uint32_t)sp) ? (a.n_wg - (uint32_t)sp + k - 1) / k : 0u;
-  const int grp = tid >> 4, l16 = tid & 15;
-  constexpr int kGroups = kTileThreads / 16;
   const size_t rowlen = (size_t)T + 1;
-  auto fetch_desc = [&](uint32_t round) -> unsigned {   // segment q = grp + kGroups * (16 * round + l16)
-    const uint32_t q = (uint32_t)grp + (uint32_t)kGroups * (16u * round + (uint32_t)l16);
+  auto fetch_desc = [&](uint32_t q, uint32_t &kb) -> unsigned {   // segment q of this share: start | end << 16
+    kb = 0;
     if (q >= nshare) return 0u;
-    const unsigned short *row = a.tab + (size_t)((uint32_t)sp + q * k) * rowlen;
+    const uint32_t w = (uint32_t)sp + q * k;
+    kb = w * a.chunk;   // first key of the chunk (n_wg * chunk < 2^32)
+    const unsigned short *row = a.tab + (size_t)w * rowlen;
     return (unsigned)row[t] | ((unsigned)row[t + 1] << 16);
   };
-  unsigned desc = fetch_desc(0);
+  uint32_t kb0 = 0;
+  unsigned desc = fetch_desc((uint32_t)tid, kb0);
   for (int c = tid; c < kBinTileCells / 4; c += kTileThreads) reinterpret_cast<uint4 *>(hist)[c] = make_uint4(0, 0, 0, 0);
   if (tid < 2 * kBinTile * 4) (&bits[0][0][0])[tid] = 0;
   if (tid == 0) s_nlong = 0;
@@ -296,73 +298,56 @@ __global__ void __launch_bounds__(kTileThreads) k_bin_tiles(BinTileArgs a)
     if (kk & kKeyClip) atomicOr(&bits[1][local >> kBinTileLog][(local & (kBinTile - 1)) >> 5], 1u << (local & 31u));
     else atomicAdd(&hist[local], 1u);
   };
-  const uint32_t nrounds = (nshare + 16u * kGroups - 1) / (16u * kGroups);
+  // keys [lo, hi) of the aligned window at key index wb (8 keys = one uint4)
+  auto add_window = [&](const uint4 &v, uint32_t wb, uint32_t lo, uint32_t hi) {
+    const unsigned wv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const uint32_t pos = wb + (uint32_t)u;
+      if (pos >= lo && pos < hi) add_key((wv[u >> 1] >> (16 * (u & 1))) & 0xFFFFu);
+    }
+  };
+  const uint4 *keys4 = reinterpret_cast<const uint4 *>(a.keys);
+  const uint32_t nrounds = (nshare + kTileThreads - 1) / kTileThreads;
   for (uint32_t round = 0; round < nrounds; ++round) {
-    const unsigned next = (round + 1 < nrounds) ? fetch_desc(round + 1) : 0u;
+    uint32_t kbn = 0;
+    const unsigned next = (round + 1 < nrounds) ? fetch_desc((round + 1) * kTileThreads + (uint32_t)tid, kbn) : 0u;
     if (round) {
       __syncthreads();   // the long-segment list of the previous round is consumed
       if (tid == 0) s_nlong = 0;
       __syncthreads();
     }
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
-      unsigned sg[8], key[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        sg[u] = (unsigned)__shfl((int)desc, half * 8 + u, 16);
-        const unsigned s0 = sg[u] & 0xFFFFu, e0 = sg[u] >> 16;
-        const uint32_t q = (uint32_t)grp + (uint32_t)kGroups * (16u * round + (uint32_t)(half * 8 + u));
-        const uint32_t kb = ((uint32_t)sp + q * k) * a.chunk;   // first key of the chunk (n_wg * chunk < 2^32)
-        key[u] = (s0 + (unsigned)l16 < e0) ? (unsigned)a.keys[kb + s0 + l16] : 0xFFFFu;   // not dereferenced when the segment is empty
-        // more than 16 keys (a crowded tile): the rest goes to the whole workgroup, see below
-        if (l16 == 0 && e0 - s0 > 16u) {
+    {
+      const uint32_t lo = kb0 + (desc & 0xFFFFu), hi = kb0 + (desc >> 16);   // absolute key range of the segment
+      if (hi > lo) {
+        const uint32_t wb = lo & ~7u;
+        const uint4 v0 = keys4[wb >> 3];
+        uint4 v1 = make_uint4(0, 0, 0, 0);
+        if (hi > wb + 8u) v1 = keys4[(wb >> 3) + 1];   // (the buffer has a window of slack past the last chunk)
+        if (hi > wb + 16u) {
           const unsigned slot = atomicAdd(&s_nlong, 1u);
-          s_lbase[slot] = kb + s0 + 16u;
-          s_llen[slot] = e0 - s0 - 16u;
+          s_lbase[slot] = wb + 16u;
+          s_llen[slot] = hi - (wb + 16u);
         }
+        add_window(v0, wb, lo, hi);
+        if (hi > wb + 8u) add_window(v1, wb + 8u, lo, hi);
       }
-#pragma unroll
-      for (int u = 0; u < 8; ++u)
-        if (key[u] != 0xFFFFu) add_key(key[u]);
     }
     desc = next;
+    kb0 = kbn;
     __syncthreads();
-    const unsigned nl = s_nlong;   // <= 1024 segments per round
-    if (nl) {
-      // Long segments: their remaining keys form one flat index space, prefix-summed over the list, that all
-      // 1024 lanes walk with independent loads (4 in flight per lane) -- the tile next to the sensor of a
-      // real lidar holds tens of thousands of keys in a few hundred segments.
-      const unsigned mine = ((unsigned)tid < nl) ? s_llen[tid] : 0u;
-      const unsigned incl = wave_incl_scan_add(mine);
-      if (lane == 63) s_scanh[wave] = incl;
-      __syncthreads();
-      unsigned excl = incl - mine, total = 0;
-#pragma unroll
-      for (int wv = 0; wv < kTileThreads / 64; ++wv) {
-        const unsigned t2 = s_scanh[wv];
-        if (wv < wave) excl += t2;
-        total += t2;
-      }
-      if ((unsigned)tid < nl) s_llen[tid] = excl;   // exclusive prefix: first flat index of segment tid
-      __syncthreads();
-      auto locate = [&](unsigned f) -> uint32_t {   // key address of flat index f
-        unsigned lo = 0, hi = nl;
-        while (hi - lo > 1u) {
-          const unsigned mid = (lo + hi) >> 1;
-          if (s_llen[mid] <= f) lo = mid; else hi = mid;
-        }
-        return s_lbase[lo] + (f - s_llen[lo]);
-      };
-      for (unsigned f0 = (unsigned)tid; f0 < total; f0 += 4u * kTileThreads) {
-        unsigned kk[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const unsigned f = f0 + (unsigned)u * kTileThreads;
-          kk[u] = (f < total) ? (unsigned)a.keys[locate(f)] : 0xFFFFu;
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-          if (kk[u] != 0xFFFFu) add_key(kk[u]);
+    const unsigned nl = s_nlong;   // <= 1024 per round
+    // long remainders: wavefront per list entry, a lane per aligned 8-key window, two windows in flight per lane
+    for (unsigned e = (unsigned)wave; e < nl; e += kTileThreads / 64) {
+      const uint32_t lo = s_lbase[e], hi = lo + s_llen[e];   // lo is window aligned
+      const uint32_t nwin = (hi - lo + 7u) >> 3;
+      for (uint32_t w0 = (uint32_t)lane; w0 < nwin; w0 += 128u) {
+        const uint32_t w1 = w0 + 64u;
+        const uint4 v0 = keys4[(lo >> 3) + w0];
+        uint4 v1 = make_uint4(0, 0, 0, 0);
+        if (w1 < nwin) v1 = keys4[(lo >> 3) + w1];
+        add_window(v0, lo + 8u * w0, lo, hi);
+        if (w1 < nwin) add_window(v1, lo + 8u * w1, lo, hi);
       }
     }
   }
