@@ -1691,6 +1691,17 @@ int gv_to_occupancy_grid(gv_handle h, int8_t *data, gv_grid_info *info)
   GV_CATCH
 }
 
+int gv_to_occupancy_grid_async(gv_handle h, int8_t *data)
+{
+  if (!h || !data) return GV_ERR_BAD_ARG;
+  GV_TRY
+  int rc = gv_frame_fence(h);   // stream A now waits for every enqueued frame
+  if (rc) return rc;
+  GV_HIP(hipMemcpyAsync(data, h->occ_i8, (size_t)h->g.G, hipMemcpyDeviceToHost, h->stream));
+  return GV_OK;
+  GV_CATCH
+}
+
 static int copy_out(gv_context *h, void *dst, const void *src, size_t bytes)
 {
   int rc = use_device(h);

@@ -43,6 +43,7 @@ ABI_SYMBOLS = [
     "gv_process_frame_sharded", "gv_comm_band",
     "gv_cloud_upload_xyz_async", "gv_cloud_upload_pointcloud2_async", "gv_cloud_upload_wait", "gv_host_alloc",
     "gv_host_free", "gv_frame_set_detections_async", "gv_frame_fence", "gv_debug_frame_sharded_emulated",
+    "gv_to_occupancy_grid_async",
 ]
 
 
@@ -323,6 +324,11 @@ class GridVisionHIP:
         info = GridInfo()
         self._ck(self._lib.gv_to_occupancy_grid(self._h, _ptr(data), C.byref(info)), "to_occupancy_grid")
         return data, info
+
+    def to_occupancy_grid_async(self, pinned_i8):
+        """pinned_i8: int8 view of G bytes of pinned memory; complete once gv_stream has passed this point"""
+        assert pinned_i8.dtype == np.int8 and pinned_i8.size == self.G
+        self._ck(self._lib.gv_to_occupancy_grid_async(self._h, _ptr(pinned_i8)), "to_occupancy_grid_async")
 
     def log_odds(self):
         out = np.empty(self.G, np.float32)

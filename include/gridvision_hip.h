@@ -229,6 +229,10 @@ int gv_update_map_points(gv_handle h, const double *base_points_xyz, const gv_bb
  * GridMapRosConverter::toOccupancyGrid(map,"occupancy",0,1,msg)
  * (grid_vision_node.cpp:265-278): data[G] int8 in OccupancyGrid order. */
 int gv_to_occupancy_grid(gv_handle h, int8_t *data, gv_grid_info *info);
+/* The same without stalling the frame pipeline: gv_frame_fence + an asynchronous device-to-host copy
+ * of data[G] on gv_stream(h).  data should be pinned (gv_host_alloc); it is complete once an event
+ * recorded on gv_stream(h) after this call has passed, or after gv_synchronize. */
+int gv_to_occupancy_grid_async(gv_handle h, int8_t *data);
 /* Layer read-back (grid_map_["log_odds"], ["occupancy"]; occupancy_grid.hpp:22) */
 int gv_get_log_odds(gv_handle h, float *out);
 int gv_get_occupancy(gv_handle h, float *out);

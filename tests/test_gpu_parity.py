@@ -997,6 +997,40 @@ def test_streaming_ingest_matches_oracle(gvamd):
             p.close()
 
 
+def test_stream_contract_fence(gvamd):
+    """gv_stream contract: the pipelined frame finishes on internal streams, so work a caller puts on
+    gv_stream(h) is ordered after the enqueued frames only through gv_frame_fence.  Several frames are
+    enqueued, the packed grid is read back asynchronously on gv_stream (gv_to_occupancy_grid_async =
+    fence + copy) and ONLY that stream is synchronised (through torch): the bytes must equal the fully
+    drained result of an identical handle."""
+    import torch
+    config = 2
+    x, y, z, _ = synth.cloud_lidar_like(config, 90_000)
+    poses = synth.lshape_poses(config, 20)
+    flags = gvamd.FRAME_BIN | gvamd.FRAME_RAYMARCH
+    outs = []
+    pin = gvamd.PinnedF32((synth.CONFIGS[config]["grid"].nx * synth.CONFIGS[config]["grid"].ny + 3) // 4)
+    for mode in ("fence", "drain"):
+        h, tfs = make_handle(gvamd, config, perturbed=True)
+        h.upload_xyz(x, y, z)
+        h.set_detections(flags, poses=poses)
+        for _ in range(7):
+            h.enqueue_frame()
+        if mode == "fence":
+            buf = pin.array.view(np.int8)[:h.G]
+            buf[:] = 0
+            h.to_occupancy_grid_async(buf)
+            torch.cuda.ExternalStream(h.stream()).synchronize()   # stream A only: B and C are not waited for by the host
+            outs.append(buf.copy())
+            h.synchronize()
+        else:
+            h.synchronize()
+            outs.append(h.to_occupancy_grid()[0])
+        h.close()
+    pin.close()
+    assert np.array_equal(outs[0], outs[1])
+
+
 def test_standalone_calls_keep_frame_detections(gvamd):
     """The reference-surface calls (extractCloudPerBBox, updateMap(poses), ...) must not change what the
     next gv_frame_enqueue uses: set_detections(50 boxes) -> extract_cloud_per_bbox(3 other boxes) ->
