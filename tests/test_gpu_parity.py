@@ -1001,9 +1001,10 @@ def test_stream_contract_fence(gvamd):
     """gv_stream contract: the pipelined frame finishes on internal streams, so work a caller puts on
     gv_stream(h) is ordered after the enqueued frames only through gv_frame_fence.  Several frames are
     enqueued, the packed grid is read back asynchronously on gv_stream (gv_to_occupancy_grid_async =
-    fence + copy) and ONLY that stream is synchronised (through torch): the bytes must equal the fully
-    drained result of an identical handle."""
-    import torch
+    fence + copy) and ONLY that stream is synchronised (hipStreamSynchronize through ctypes): the bytes
+    must equal the fully drained result of an identical handle."""
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
     config = 2
     x, y, z, _ = synth.cloud_lidar_like(config, 90_000)
     poses = synth.lshape_poses(config, 20)
@@ -1020,7 +1021,8 @@ def test_stream_contract_fence(gvamd):
             buf = pin.array.view(np.int8)[:h.G]
             buf[:] = 0
             h.to_occupancy_grid_async(buf)
-            torch.cuda.ExternalStream(h.stream()).synchronize()   # stream A only: B and C are not waited for by the host
+            rc = hip.hipStreamSynchronize(ctypes.c_void_p(h.stream()))   # stream A only: B and C are not waited for by the host
+            assert rc == 0
             outs.append(buf.copy())
             h.synchronize()
         else:
