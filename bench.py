@@ -210,6 +210,7 @@ def leg_with_h2d(gvamd, synth, g, tfs, config, flags, local_rank, steps):
     t0 = time.perf_counter()
     for f in range(steps):
         one(f)
+    t_host = time.perf_counter() - t0   # host time to enqueue everything (no wait inside the loop)
     h.synchronize()
     dt = time.perf_counter() - t0
     # copy rate alone: the same uploads without frames
@@ -217,6 +218,7 @@ def leg_with_h2d(gvamd, synth, g, tfs, config, flags, local_rank, steps):
     for f in range(steps):
         px, py, pz = pins[f % n_sets]
         h.upload_xyz_async(px.array, py.array, pz.array)
+    t_host_c = time.perf_counter() - t1
     h.synchronize()
     dtc = time.perf_counter() - t1
     h.close()
@@ -228,6 +230,8 @@ def leg_with_h2d(gvamd, synth, g, tfs, config, flags, local_rank, steps):
     return {"value": steps / dt, "unit": "frames/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
             "h2d_GBps_measured": h2d_gbps, "h2d_GBps_spec": PCIE_SPEC_GBPS,
             "copy_bound_frames_per_s": bound_fps, "frac_of_copy_bound": (steps / dt) / bound_fps,
+            "host_us_per_frame": t_host / steps * 1e6, "host_us_per_upload_call": t_host_c / steps * 1e6,
+            "h2d_path": os.environ.get("GV_H2D", "kernel"),
             "note": "fresh 1M-point cloud (12 MB, pinned host memory) + fresh detections every frame, async "
                     "double-buffered ingest on a copy stream, no host wait between frames; never the headline"}
 
@@ -497,6 +501,13 @@ def main():
                 out["with_h2d"] = leg_with_h2d(gvamd, synth, g, tfs, config, flags, local_rank, min(a.steps, 100))
             except Exception as e:
                 out["with_h2d"] = {"error": str(e)}
+            try:   # A/B: the same leg with the pinned uploads going through hipMemcpyAsync
+                os.environ["GV_H2D"] = "memcpy"
+                out["with_h2d_memcpy"] = leg_with_h2d(gvamd, synth, g, tfs, config, flags, local_rank, min(a.steps, 100))
+            except Exception as e:
+                out["with_h2d_memcpy"] = {"error": str(e)}
+            finally:
+                os.environ.pop("GV_H2D", None)
             try:
                 out["lidar_like"] = leg_cloud(gvamd, synth, g, tfs, config, flags, bboxes, poses, local_rank,
                                               min(a.steps, 200), synth.cloud_lidar_like)

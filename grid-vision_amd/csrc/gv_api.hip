@@ -78,6 +78,7 @@ struct gv_context {
   int since_drain = 0;            // pipelined frames enqueued since every stream was last idle
   bool pipe_busy = false;
   bool no_pipeline = false;       // GV_PIPELINE=0
+  bool h2d_kernel = true;         // GV_H2D=memcpy: pinned uploads through hipMemcpyAsync too (A/B measurement)
 #ifdef GV_DIAG
   std::vector<hipEvent_t> *trace = nullptr;   // timing events around every pipelined kernel (gv_debug_pipeline_trace)
   unsigned long long *d_dbg = nullptr;        // GV_SECTOR_DBG=1: phase stamps of the sector kernel
@@ -1075,6 +1076,7 @@ int gv_create(gv_handle *out, uint8_t grid_x, uint8_t grid_y, double resolution,
     const char *impl = std::getenv("GV_RAY_IMPL");
     h->force_simple = impl && std::strcmp(impl, "simple") == 0;
     if (const char *e = std::getenv("GV_PIPELINE")) h->no_pipeline = std::atoi(e) == 0;
+    if (const char *e = std::getenv("GV_H2D")) h->h2d_kernel = std::strcmp(e, "memcpy") != 0;
     if (const char *e = std::getenv("GV_PIPE_SETS")) h->n_sets = std::min(gv_context::kSets, std::max(2, std::atoi(e)));
     if (const char *e = std::getenv("GV_LOG2S")) h->env_log2s = std::atoi(e);
     if (const char *e = std::getenv("GV_LOG2S_OCT")) {
@@ -1319,9 +1321,25 @@ int upload_xyz(gv_context *h, const float *x, const float *y, const float *z, si
   if (rc) return rc;
   CloudSet &c = h->cloud[target];
   if (n) {
-    GV_HIP(hipMemcpyAsync(c.x, x, n * sizeof(float), hipMemcpyHostToDevice, h->stream_copy));
-    GV_HIP(hipMemcpyAsync(c.y, y, n * sizeof(float), hipMemcpyHostToDevice, h->stream_copy));
-    GV_HIP(hipMemcpyAsync(c.z, z, n * sizeof(float), hipMemcpyHostToDevice, h->stream_copy));
+    // pinned, device-mapped, 16-byte aligned host arrays (gv_host_alloc): copied by a kernel whose launch
+    // returns at once; anything else goes through hipMemcpyAsync (pageable memory: staged by the runtime)
+    const float *dp[3] = {nullptr, nullptr, nullptr};
+    bool mapped = h->h2d_kernel;
+    const float *hp[3] = {x, y, z};
+    for (int k = 0; k < 3 && mapped; ++k) {
+      hipPointerAttribute_t at{};
+      if (hipPointerGetAttributes(&at, hp[k]) != hipSuccess) { (void)hipGetLastError(); mapped = false; break; }
+      if (at.type != hipMemoryTypeHost || !at.devicePointer || ((uintptr_t)at.devicePointer & 15u)) { mapped = false; break; }
+      dp[k] = static_cast<const float *>(at.devicePointer);
+    }
+    if (mapped) {
+      launch_copy_h2d_xyz(dp[0], dp[1], dp[2], c.x, c.y, c.z, n, h->stream_copy);
+      GV_HIP(hipGetLastError());
+    } else {
+      GV_HIP(hipMemcpyAsync(c.x, x, n * sizeof(float), hipMemcpyHostToDevice, h->stream_copy));
+      GV_HIP(hipMemcpyAsync(c.y, y, n * sizeof(float), hipMemcpyHostToDevice, h->stream_copy));
+      GV_HIP(hipMemcpyAsync(c.z, z, n * sizeof(float), hipMemcpyHostToDevice, h->stream_copy));
+    }
   }
   if ((rc = end_cloud_upload(h, target, n))) return rc;
   if (wait) GV_HIP(hipEventSynchronize(c.ready));

@@ -219,8 +219,15 @@ __global__ void __launch_bounds__(kTileThreads) k_bin_tiles(BinTileArgs a)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int T = a.n_tiles;
   GV_STAMP(a.dbg, 0);
-  const bool primary = (int)blockIdx.x < T;
-  int t = primary ? (int)blockIdx.x : -1, sp = 0, slot = 0;
+  // Workgroups are dealt round-robin over the 8 XCDs (blockIdx b and b + 8 share one, each with its own L2).
+  // Consecutive tiles read neighbouring bytes of every chunk (one 128-byte line of a chunk's offset row covers
+  // 64 tiles, one line of its sorted keys ~9 tiles), so each XCD takes a contiguous run of tiles: its L2 then
+  // fetches those lines once instead of every XCD fetching all of them.
+  const int per_xcd = (T + 7) >> 3;
+  const int n_primary = per_xcd << 3;
+  const bool primary = (int)blockIdx.x < n_primary;
+  int t = primary ? ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3) : -1, sp = 0, slot = 0;
+  if (primary && t >= T) return;   // T is not a multiple of 8: a few idle workgroups
   unsigned k = 1;
   if (primary) {
     k = bin_splits(a.tile_total[t], a.split_keys);
@@ -243,7 +250,7 @@ __global__ void __launch_bounds__(kTileThreads) k_bin_tiles(BinTileArgs a)
     __syncthreads();
     unsigned bh = ih - hv, be = ie - ex;
     for (int wv = 0; wv < wave; ++wv) { bh += s_scanh[wv]; be += s_scane[wv]; }
-    const unsigned j = primary ? 0u : (unsigned)((int)blockIdx.x - T);
+    const unsigned j = primary ? 0u : (unsigned)((int)blockIdx.x - n_primary);
     for (int q = q0; q < q1; ++q) {
       const unsigned kq = bin_splits(a.tile_total[q], a.split_keys);
       if (primary) {
@@ -295,8 +302,15 @@ __global__ void __launch_bounds__(kTileThreads) k_bin_tiles(BinTileArgs a)
   GV_STAMP(a.dbg, 2);   // LDS zeroed, first descriptors on their way
   auto add_key = [&](unsigned kk) {
     const unsigned local = kk & (kBinTileCells - 1);
-    if (kk & kKeyClip) atomicOr(&bits[1][local >> kBinTileLog][(local & (kBinTile - 1)) >> 5], 1u << (local & 31u));
-    else atomicAdd(&hist[local], 1u);
+    if (kk & kKeyClip) {
+      // clipped ray ends pile up on the map border (every out-of-map point ends on one of ~8000 cells): thousands of
+      // keys for the same few words.  Same-address LDS atomics serialise, plain reads broadcast: look first.
+      unsigned *wp = &bits[1][local >> kBinTileLog][(local & (kBinTile - 1)) >> 5];
+      const unsigned bit = 1u << (local & 31u);
+      if (!(*reinterpret_cast<volatile unsigned *>(wp) & bit)) atomicOr(wp, bit);
+    } else {
+      atomicAdd(&hist[local], 1u);
+    }
   };
   // keys [lo, hi) of the aligned window at key index wb (8 keys = one uint4)
   auto add_window = [&](const uint4 &v, uint32_t wb, uint32_t lo, uint32_t hi) {
@@ -481,7 +495,7 @@ void launch_bin_partition(const BinArgs &a, hipStream_t s)
 
 void launch_bin_tiles(const BinTileArgs &a, uint32_t n_helpers, hipStream_t s)
 {
-  const uint32_t grid = (uint32_t)a.n_tiles + n_helpers;
+  const uint32_t grid = (uint32_t)(((a.n_tiles + 7) >> 3) << 3) + n_helpers;   // primaries by XCD run, then the helpers
   if (a.hits) hipLaunchKernelGGL(k_bin_tiles<true>, dim3(grid), dim3(kTileThreads), 0, s, a);
   else hipLaunchKernelGGL(k_bin_tiles<false>, dim3(grid), dim3(kTileThreads), 0, s, a);
 }

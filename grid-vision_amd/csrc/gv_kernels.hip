@@ -203,6 +203,39 @@ void launch_transform_cloud(const float *x, const float *y, const float *z, uint
   hipLaunchKernelGGL(k_transform, dim3(blocks), dim3(256), 0, s, x, y, z, n, m, ox, oy, oz);
 }
 
+// Host-to-device copy of the SoA cloud as a kernel: the three arrays sit in pinned, device-mapped host
+// memory (gv_host_alloc) and a small persistent grid streams them over PCIe with 16-byte loads, four per lane in
+// flight.  Unlike hipMemcpyAsync (which on this stack occupies the calling host thread for the duration of
+// the copy) the launch returns at once, so the host goes on to enqueue the frame; the grid is small (3 x 64
+// workgroups) so that it shares the CUs with the frame's kernels.
+__global__ void __launch_bounds__(256) k_copy_h2d_xyz(const float *__restrict__ hx, const float *__restrict__ hy,
+                                                      const float *__restrict__ hz, float *__restrict__ dx,
+                                                      float *__restrict__ dy, float *__restrict__ dz, size_t n)
+{
+  const float *src = blockIdx.y == 0 ? hx : (blockIdx.y == 1 ? hy : hz);
+  float *dst = blockIdx.y == 0 ? dx : (blockIdx.y == 1 ? dy : dz);
+  const size_t n4 = n >> 2;
+  typedef unsigned v4u __attribute__((ext_vector_type(4)));   // (the nontemporal builtins want a native vector)
+  const v4u *s4 = reinterpret_cast<const v4u *>(src);       // gv_host_alloc / hipMalloc bases are 16-byte aligned
+  v4u *d4 = reinterpret_cast<v4u *>(dst);
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  for (; i + 3 * stride < n4; i += 4 * stride) {
+    const v4u a = __builtin_nontemporal_load(s4 + i), b = __builtin_nontemporal_load(s4 + i + stride);
+    const v4u c = __builtin_nontemporal_load(s4 + i + 2 * stride), d = __builtin_nontemporal_load(s4 + i + 3 * stride);
+    d4[i] = a; d4[i + stride] = b; d4[i + 2 * stride] = c; d4[i + 3 * stride] = d;
+  }
+  for (; i < n4; i += stride) d4[i] = __builtin_nontemporal_load(s4 + i);
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) dst[(n4 << 2) + threadIdx.x] = src[(n4 << 2) + threadIdx.x];
+}
+
+void launch_copy_h2d_xyz(const float *hx, const float *hy, const float *hz, float *dx, float *dy, float *dz, size_t n,
+                         hipStream_t s)
+{
+  if (!n) return;
+  hipLaunchKernelGGL(k_copy_h2d_xyz, dim3(64, 3), dim3(256), 0, s, hx, hy, hz, dx, dy, dz, n);
+}
+
 // PointCloud2 bytes -> SoA (pcl::fromROSMsg, src/grid_vision_node.cpp:105).  One
 // thread per point; fields may be unaligned inside point_step, so assemble from bytes
 // when the offsets are not 4-byte aligned.
