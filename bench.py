@@ -33,6 +33,9 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "grid-vision_amd"))
+# one hardware queue per HIP stream of the frame pipeline (A, B, C, copy) next to the default stream: with the
+# runtime's default of 4 a fifth stream shares a queue and serialises behind its neighbour
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 import numpy as np  # noqa: E402
 

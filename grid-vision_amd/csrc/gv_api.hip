@@ -47,8 +47,7 @@ struct DetSet {
   bool valid = false;           // a gv_frame_set_detections* call has filled this set
   uint8_t *stage = nullptr;     // pinned host copy of the caller's arrays (free to reuse on return)
   size_t stage_cap = 0;
-  hipEvent_t ready = nullptr;
-  int release_set = -1;         // as CloudSet::release_set
+  hipEvent_t ready = nullptr;   // stream A: the set's last upload has left its staging block
 };
 
 }  // namespace
@@ -57,11 +56,13 @@ struct gv_context {
   static constexpr int kSets = 4;
   int device = 0;
   // A: detections, partition, tile histogram of frame f+1 (and every non-frame entry point);
-  // B: sector ray stage of frame f;  C: grid pass of frame f;  copy: H2D of the next cloud;  det: H2D of the
-  // next detections + their bbox-test tables (a stream of its own: it must not queue behind the 12 MB cloud copy)
-  hipStream_t stream = nullptr, stream2 = nullptr, stream3 = nullptr, stream_copy = nullptr, stream_det = nullptr;
+  // B: sector ray stage of frame f;  C: grid pass of frame f;  copy: H2D of the next cloud.  The detections of
+  // the next frame (one ~10 KB block) go up on stream A itself, in order between the frames that read them: no
+  // more streams than the 4 hardware queues a process gets by default (a 5th stream shares a queue with one of
+  // the others and serialises behind it: measured, 0.81 -> 0.71 of the copy bound)
+  hipStream_t stream = nullptr, stream2 = nullptr, stream3 = nullptr, stream_copy = nullptr;
   hipEvent_t ev_build[kSets]{}, ev_sec[kSets]{}, ev_fin[kSets]{};
-  hipEvent_t ev_join[4]{};
+  hipEvent_t ev_join[3]{};
   int n_sets = 3;                 // GV_PIPE_SETS (2..4): buffer sets the pipelined frames rotate through
   // per-set buffers of the frames in flight: end bitmaps, rectangles, miss grids, ray statistics
   uint32_t *x_ends[kSets]{};      // one allocation per set: [hitN | clipN | hitT | clipT], ends_words in all
@@ -139,7 +140,6 @@ struct gv_context {
   // detections
   DetSet det[3];
   int det_cur = 0;
-  bool det_wait = false;
   int32_t bt_tiles_x = 1, bt_tiles_y = 1;   // 16x16-pixel tiles of the image
   VisionOut *d_vout = nullptr;
   int32_t vout_cap = 0;
@@ -209,14 +209,12 @@ int grow(gv_context *h, T *&p, size_t &cap, size_t need)
 int drain(gv_context *h)
 {
   GV_HIP(hipStreamSynchronize(h->stream_copy));
-  GV_HIP(hipStreamSynchronize(h->stream_det));
   GV_HIP(hipStreamSynchronize(h->stream));
   GV_HIP(hipStreamSynchronize(h->stream2));
   GV_HIP(hipStreamSynchronize(h->stream3));
   h->pipe_busy = false;
   h->since_drain = 0;
   h->cloud_wait = false;
-  h->det_wait = false;
   return GV_OK;
 }
 
@@ -233,7 +231,7 @@ int set_device_only(gv_context *h)
 int use_device(gv_context *h)
 {
   GV_HIP(hipSetDevice(h->device));
-  if (h->pipe_busy || h->cloud_wait || h->det_wait) return drain(h);
+  if (h->pipe_busy || h->cloud_wait) return drain(h);
   return GV_OK;
 }
 
@@ -303,8 +301,7 @@ DetLayout det_layout(int32_t cap)
 int ensure_det(gv_context *h, DetSet &d, int32_t n)
 {
   if (n <= d.cap) return GV_OK;
-  if (d.release_set >= 0) GV_HIP(hipEventSynchronize(h->ev_build[d.release_set]));   // frames that read this set are past it
-  if (d.ready) GV_HIP(hipEventSynchronize(d.ready));
+  if (d.cap) GV_HIP(hipStreamSynchronize(h->stream));   // frames that read this set are past it (rare: the count grew)
   const int32_t want = std::max(n + n / 4, 64);
   const DetLayout L = det_layout(want);
   d.cap = 0;
@@ -713,7 +710,6 @@ int enqueue_frame_tiles(gv_context *h, bool pipelined, bool stage_events, bool s
   const bool set_reused = pipelined && h->since_drain >= h->n_sets;
   if (set_reused) GV_HIP(hipStreamWaitEvent(sA, h->ev_fin[p], 0));   // set p (bitmaps, rectangles) is free again
   if (h->cloud_wait) { GV_HIP(hipStreamWaitEvent(sA, CS.ready, 0)); h->cloud_wait = false; }
-  if (h->det_wait) { GV_HIP(hipStreamWaitEvent(sA, D.ready, 0)); h->det_wait = false; }
   if (stage_events) GV_HIP(hipEventRecord(h->ev[0], sA));
 
   // --- detections -> rectangles
@@ -1051,7 +1047,6 @@ int gv_create(gv_handle *out, uint8_t grid_x, uint8_t grid_y, double resolution,
   GV_C(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
   GV_C(hipStreamCreateWithFlags(&h->stream3, hipStreamNonBlocking));
   GV_C(hipStreamCreateWithFlags(&h->stream_copy, hipStreamNonBlocking));
-  GV_C(hipStreamCreateWithFlags(&h->stream_det, hipStreamNonBlocking));
   for (int i = 0; i < gv_context::kSets; ++i) {
     GV_C(hipEventCreateWithFlags(&h->ev_build[i], hipEventDisableTiming));
     GV_C(hipEventCreateWithFlags(&h->ev_fin[i], hipEventDisableTiming));
@@ -1170,7 +1165,7 @@ int gv_destroy(gv_handle h)
 {
   if (!h) return GV_ERR_BAD_ARG;
   (void)hipSetDevice(h->device);
-  for (hipStream_t s : {h->stream_copy, h->stream_det, h->stream, h->stream2, h->stream3})
+  for (hipStream_t s : {h->stream_copy, h->stream, h->stream2, h->stream3})
     if (s) (void)hipStreamSynchronize(s);
   if (h->comm) { ncclCommDestroy(h->comm); h->comm = nullptr; }
   void *bufs[] = {h->log_odds, h->occupancy, h->occ_i8, h->hits, h->clip_end, h->miss8, h->sh_xchg, h->ray_list, h->ray_count, h->scratch_i32,
@@ -1209,7 +1204,7 @@ int gv_destroy(gv_handle h)
     if (h->ev_fin[i]) (void)hipEventDestroy(h->ev_fin[i]);
     if (h->ev_sec[i]) (void)hipEventDestroy(h->ev_sec[i]);
   }
-  for (hipStream_t s : {h->stream3, h->stream2, h->stream_det, h->stream_copy, h->stream})
+  for (hipStream_t s : {h->stream3, h->stream2, h->stream_copy, h->stream})
     if (s) (void)hipStreamDestroy(s);
   delete h;
   return GV_OK;
@@ -1368,7 +1363,7 @@ int upload_pc2(gv_context *h, const uint8_t *data, size_t n, uint32_t point_step
   return GV_OK;
 }
 
-int set_detections(gv_context *h, const gv_frame_desc *d, bool wait)
+int set_detections(gv_context *h, const gv_frame_desc *d)
 {
   if (!h || !d) return GV_ERR_BAD_ARG;
   if (d->n_bboxes < 0 || d->n_poses < 0) return GV_ERR_BAD_ARG;
@@ -1378,23 +1373,17 @@ int set_detections(gv_context *h, const gv_frame_desc *d, bool wait)
   if (!vision && d->n_poses && !d->poses) return GV_ERR_BAD_ARG;
   int rc = set_device_only(h);
   if (rc) return rc;
+  // The other detection set: frames already enqueued read the current one, and they precede this upload on
+  // stream A, as the frames that will read it follow it there -- stream order is all the ordering needed.
   const int target = h->det_cur ^ 1;
   DetSet &D = h->det[target];
-  // shared rectangle / vision buffers may have to grow (drains); do it before ordering the copy stream
-  if ((rc = ensure_det_shared(h, std::max(d->n_bboxes, d->n_poses)))) return rc;
-  if ((rc = ensure_det(h, D, std::max(d->n_bboxes, d->n_poses)))) return rc;
-  if (D.release_set >= 0)   // frames that read this set are past their points pass
-    GV_HIP(hipStreamWaitEvent(h->stream_det, h->ev_build[D.release_set], 0));
   const bool net = vision && d->n_bboxes;
   if ((rc = upload_det(h, D, d->bboxes, d->n_bboxes, vision ? nullptr : d->poses, vision ? 0 : d->n_poses,
-                       net ? d->orient : nullptr, net ? d->conf : nullptr, net ? d->dims : nullptr, h->stream_det)))
+                       net ? d->orient : nullptr, net ? d->conf : nullptr, net ? d->dims : nullptr, h->stream)))
     return rc;
   D.flags = d->flags;
-  GV_HIP(hipEventRecord(D.ready, h->stream_det));
-  h->det[h->det_cur].release_set = h->last_frame_set;
+  GV_HIP(hipEventRecord(D.ready, h->stream));   // (only guards the reuse of the set's pinned staging block)
   h->det_cur = target;
-  h->det_wait = true;
-  if (wait) GV_HIP(hipEventSynchronize(D.ready));
   return GV_OK;
 }
 
@@ -1754,14 +1743,14 @@ int gv_set_log_odds(gv_handle h, const float *in)
 int gv_frame_set_detections(gv_handle h, const gv_frame_desc *d)
 {
   GV_TRY
-  return set_detections(h, d, true);
+  return set_detections(h, d);
   GV_CATCH
 }
 
 int gv_frame_set_detections_async(gv_handle h, const gv_frame_desc *d)
 {
   GV_TRY
-  return set_detections(h, d, false);
+  return set_detections(h, d);
   GV_CATCH
 }
 
@@ -1787,8 +1776,8 @@ int gv_frame_fence(gv_handle h)
   int rc = set_device_only(h);
   if (rc) return rc;
   if (h->pipe_busy) {   // join streams B and C (and the copy stream) into stream A
-    hipStream_t others[4] = {h->stream2, h->stream3, h->stream_copy, h->stream_det};
-    for (int k = 0; k < 4; ++k) {
+    hipStream_t others[3] = {h->stream2, h->stream3, h->stream_copy};
+    for (int k = 0; k < 3; ++k) {
       GV_HIP(hipEventRecord(h->ev_join[k], others[k]));
       GV_HIP(hipStreamWaitEvent(h->stream, h->ev_join[k], 0));
     }

@@ -334,34 +334,44 @@ __global__ void __launch_bounds__(kTileThreads) k_bin_tiles(BinTileArgs a)
     {
       const uint32_t lo = kb0 + (desc & 0xFFFFu), hi = kb0 + (desc >> 16);   // absolute key range of the segment
       if (hi > lo) {
+        // up to four aligned windows (>= 25 keys) per lane, all loads issued before the first key is used:
+        // covers every segment of an evenly filled tile and of the map-border tiles (clipped ray ends double
+        // their segments); only a crowded tile's segments leave a remainder for the list
         const uint32_t wb = lo & ~7u;
-        const uint4 v0 = keys4[wb >> 3];
-        uint4 v1 = make_uint4(0, 0, 0, 0);
-        if (hi > wb + 8u) v1 = keys4[(wb >> 3) + 1];   // (the buffer has a window of slack past the last chunk)
-        if (hi > wb + 16u) {
-          const unsigned slot = atomicAdd(&s_nlong, 1u);
-          s_lbase[slot] = wb + 16u;
-          s_llen[slot] = hi - (wb + 16u);
+        uint4 v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          v[q] = make_uint4(0, 0, 0, 0);
+          if (hi > wb + 8u * (uint32_t)q) v[q] = keys4[(wb >> 3) + (uint32_t)q];   // (the buffer has slack past the last chunk)
         }
-        add_window(v0, wb, lo, hi);
-        if (hi > wb + 8u) add_window(v1, wb + 8u, lo, hi);
+        if (hi > wb + 32u) {
+          const unsigned slot = atomicAdd(&s_nlong, 1u);
+          s_lbase[slot] = wb + 32u;
+          s_llen[slot] = hi - (wb + 32u);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (hi > wb + 8u * (uint32_t)q) add_window(v[q], wb + 8u * (uint32_t)q, lo, hi);
       }
     }
     desc = next;
     kb0 = kbn;
     __syncthreads();
     const unsigned nl = s_nlong;   // <= 1024 per round
-    // long remainders: wavefront per list entry, a lane per aligned 8-key window, two windows in flight per lane
+    // long remainders: wavefront per list entry, a lane per aligned 8-key window, four windows in flight per lane
     for (unsigned e = (unsigned)wave; e < nl; e += kTileThreads / 64) {
       const uint32_t lo = s_lbase[e], hi = lo + s_llen[e];   // lo is window aligned
       const uint32_t nwin = (hi - lo + 7u) >> 3;
-      for (uint32_t w0 = (uint32_t)lane; w0 < nwin; w0 += 128u) {
-        const uint32_t w1 = w0 + 64u;
-        const uint4 v0 = keys4[(lo >> 3) + w0];
-        uint4 v1 = make_uint4(0, 0, 0, 0);
-        if (w1 < nwin) v1 = keys4[(lo >> 3) + w1];
-        add_window(v0, lo + 8u * w0, lo, hi);
-        if (w1 < nwin) add_window(v1, lo + 8u * w1, lo, hi);
+      for (uint32_t w0 = (uint32_t)lane; w0 < nwin; w0 += 256u) {
+        uint4 v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          v[q] = make_uint4(0, 0, 0, 0);
+          if (w0 + 64u * (uint32_t)q < nwin) v[q] = keys4[(lo >> 3) + w0 + 64u * (uint32_t)q];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (w0 + 64u * (uint32_t)q < nwin) add_window(v[q], lo + 8u * (w0 + 64u * (uint32_t)q), lo, hi);
       }
     }
   }

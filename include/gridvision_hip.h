@@ -261,13 +261,14 @@ typedef struct {
   int32_t n_poses;
   const float *orient, *conf, *dims;  /* GV_FRAME_VISION_ORIENT: nb*4, nb*2, nb*3 */
 } gv_frame_desc;
-/* Upload the small per-frame detection inputs (bboxes, poses / net outputs).  Two sets
- * alternate like the clouds do: the arrays are copied to pinned staging (the caller's arrays
- * are free on return), uploaded on the copy stream and turned into the bbox-test tables on
- * the device; frames enqueued afterwards use them.  The _async form returns without waiting
- * for the copy; neither form drains the frame pipeline.  The standalone entry points above
- * (gv_extract_cloud_per_bbox, gv_update_map_poses, ...) keep their inputs in a set of their
- * own and never change what gv_frame_enqueue uses. */
+/* Upload the small per-frame detection inputs (bboxes, poses / net outputs).  Two sets alternate like
+ * the clouds do: the arrays are copied into pinned staging (the caller's arrays are free on return), go
+ * to the device in one copy on the frame's first stream -- in order between the frames that read the
+ * previous set and those that will read this one -- and are turned into the bbox-test tables there.
+ * Neither form waits for the copy or drains the frame pipeline (the _async name is kept for symmetry
+ * with the cloud uploads).  The standalone entry points above (gv_extract_cloud_per_bbox,
+ * gv_update_map_poses, ...) keep their inputs in a set of their own and never change what
+ * gv_frame_enqueue uses. */
 int gv_frame_set_detections(gv_handle h, const gv_frame_desc *desc);
 int gv_frame_set_detections_async(gv_handle h, const gv_frame_desc *desc);
 /* Enqueue one frame using the resident cloud and the last detections set; returns without
