@@ -1,0 +1,31 @@
+"""Streaming frames (fresh pinned cloud + detections every frame) for a kernel-trace: run under
+   rocprofv3 --kernel-trace --output-format csv -d <dir> -- python3 tools/stream_run.py [frames]"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "grid-vision_amd"))
+import numpy as np
+import gvamd
+from gvamd import synth
+config = 3
+frames = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+g = synth.CONFIGS[config]["grid"]
+tfs = synth.transforms(True)
+pins, dets = [], []
+for f in range(3):
+    x, y, z, _ = synth.cloud_uniform(config, seed_extra=100 + f)
+    p3 = tuple(gvamd.PinnedF32(len(x)) for _ in range(3))
+    p3[0].array[:], p3[1].array[:], p3[2].array[:] = x, y, z
+    pins.append(p3)
+    dets.append((synth.detections(config, seed_extra=f), synth.lshape_poses(config, seed_extra=f)))
+h = gvamd.GridVisionHIP(g.grid_x, g.grid_y, g.resolution)
+h.set_transforms(tfs["cam_lidar"], tfs["base_cam"], tfs["base_lidar"])
+flags = gvamd.FRAME_BIN | gvamd.FRAME_RAYMARCH | gvamd.FRAME_BBOX_TEST
+t0 = time.perf_counter()
+for f in range(frames):
+    px, py, pz = pins[f % 3]
+    h.upload_xyz_async(px.array, py.array, pz.array)
+    h.set_detections_async(flags, bboxes=dets[f % 3][0], poses=dets[f % 3][1])
+    h.enqueue_frame()
+h.synchronize()
+print("us/frame", (time.perf_counter() - t0) / frames * 1e6)
+h.close()

@@ -1,0 +1,11 @@
+"""Print the device timeline of the last frames from a rocprofv3 kernel_trace.csv"""
+import csv, glob, sys
+f = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
+rows = [r for r in csv.DictReader(open(f))]
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+t0 = int(rows[0]["Start_Timestamp"])
+sel = rows[-int(sys.argv[2]) if len(sys.argv) > 2 else -40:]
+for r in sel:
+    n = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("gv::", "")[:28]
+    s, e = (int(r["Start_Timestamp"]) - t0) / 1e3, (int(r["End_Timestamp"]) - t0) / 1e3
+    print(f"{s:10.1f} {e:10.1f} {e - s:8.1f}  q{r.get('Queue_Id', '?'):>3}  {n}")
