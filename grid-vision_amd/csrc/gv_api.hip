@@ -21,7 +21,8 @@ namespace {
 // One of the two resident clouds: frames read the current one on stream A while the copy stream
 // fills the other (cloudCallback / timerCallback overlap, src/grid_vision_node.cpp:103-106,108-244).
 struct CloudSet {
-  float *x = nullptr, *y = nullptr, *z = nullptr;
+  float *base = nullptr;        // one allocation of 3 * cap floats
+  float *x = nullptr, *y = nullptr, *z = nullptr;   // base, base + n, base + 2n of the cloud it holds (SoA, back to back)
   size_t cap = 0;
   uint8_t *raw = nullptr;       // PointCloud2 bytes before the de-interleave
   size_t raw_cap = 0;
@@ -79,7 +80,6 @@ struct gv_context {
   int since_drain = 0;            // pipelined frames enqueued since every stream was last idle
   bool pipe_busy = false;
   bool no_pipeline = false;       // GV_PIPELINE=0
-  bool h2d_kernel = true;         // GV_H2D=memcpy: pinned uploads through hipMemcpyAsync too (A/B measurement)
 #ifdef GV_DIAG
   std::vector<hipEvent_t> *trace = nullptr;   // timing events around every pipelined kernel (gv_debug_pipeline_trace)
   unsigned long long *d_dbg = nullptr;        // GV_SECTOR_DBG=1: phase stamps of the sector kernel
@@ -1071,7 +1071,6 @@ int gv_create(gv_handle *out, uint8_t grid_x, uint8_t grid_y, double resolution,
     const char *impl = std::getenv("GV_RAY_IMPL");
     h->force_simple = impl && std::strcmp(impl, "simple") == 0;
     if (const char *e = std::getenv("GV_PIPELINE")) h->no_pipeline = std::atoi(e) == 0;
-    if (const char *e = std::getenv("GV_H2D")) h->h2d_kernel = std::strcmp(e, "memcpy") != 0;
     if (const char *e = std::getenv("GV_PIPE_SETS")) h->n_sets = std::min(gv_context::kSets, std::max(2, std::atoi(e)));
     if (const char *e = std::getenv("GV_LOG2S")) h->env_log2s = std::atoi(e);
     if (const char *e = std::getenv("GV_LOG2S_OCT")) {
@@ -1185,7 +1184,7 @@ int gv_destroy(gv_handle h)
       if (p) (void)hipFree(p);
   }
   for (auto &c : h->cloud) {
-    for (void *p : {(void *)c.x, (void *)c.y, (void *)c.z, (void *)c.raw})
+    for (void *p : {(void *)c.base, (void *)c.raw})
       if (p) (void)hipFree(p);
     if (c.ready) (void)hipEventDestroy(c.ready);
   }
@@ -1280,17 +1279,17 @@ int begin_cloud_upload(gv_context *h, size_t n, int &target)
   if (n > c.cap) {
     if (c.release_set >= 0) GV_HIP(hipEventSynchronize(h->ev_build[c.release_set]));
     GV_HIP(hipEventSynchronize(c.ready));
-    for (float **p : {&c.x, &c.y, &c.z}) {
-      if (*p) GV_HIP(hipFree(*p));
-      *p = nullptr;
-    }
+    if (c.base) GV_HIP(hipFree(c.base));
+    c.base = nullptr;
     c.cap = 0;
     const size_t want = n + n / 8 + 1024;
-    GV_HIP(hipMalloc(reinterpret_cast<void **>(&c.x), want * sizeof(float)));
-    GV_HIP(hipMalloc(reinterpret_cast<void **>(&c.y), want * sizeof(float)));
-    GV_HIP(hipMalloc(reinterpret_cast<void **>(&c.z), want * sizeof(float)));
+    GV_HIP(hipMalloc(reinterpret_cast<void **>(&c.base), 3 * want * sizeof(float)));
     c.cap = want;
   }
+  const size_t n4 = (n + 3) & ~(size_t)3;   // 16-byte aligned arrays
+  c.x = c.base;
+  c.y = c.base + n4;
+  c.z = c.base + 2 * n4;
   // ordered after the last frame that reads this set (a later re-record of the event only waits longer)
   if (c.release_set >= 0) GV_HIP(hipStreamWaitEvent(h->stream_copy, h->ev_build[c.release_set], 0));
   return GV_OK;
@@ -1316,20 +1315,10 @@ int upload_xyz(gv_context *h, const float *x, const float *y, const float *z, si
   if (rc) return rc;
   CloudSet &c = h->cloud[target];
   if (n) {
-    // pinned, device-mapped, 16-byte aligned host arrays (gv_host_alloc): copied by a kernel whose launch
-    // returns at once; anything else goes through hipMemcpyAsync (pageable memory: staged by the runtime)
-    const float *dp[3] = {nullptr, nullptr, nullptr};
-    bool mapped = h->h2d_kernel;
-    const float *hp[3] = {x, y, z};
-    for (int k = 0; k < 3 && mapped; ++k) {
-      hipPointerAttribute_t at{};
-      if (hipPointerGetAttributes(&at, hp[k]) != hipSuccess) { (void)hipGetLastError(); mapped = false; break; }
-      if (at.type != hipMemoryTypeHost || !at.devicePointer || ((uintptr_t)at.devicePointer & 15u)) { mapped = false; break; }
-      dp[k] = static_cast<const float *>(at.devicePointer);
-    }
-    if (mapped) {
-      launch_copy_h2d_xyz(dp[0], dp[1], dp[2], c.x, c.y, c.z, n, h->stream_copy);
-      GV_HIP(hipGetLastError());
+    // the copy engine does ~54 GB/s inside a copy and leaves ~10 us between copies: x, y, z laid out back to
+    // back in one (pinned) block go up in a single copy
+    if (y == x + n && z == y + n && (n & 3) == 0) {
+      GV_HIP(hipMemcpyAsync(c.x, x, 3 * n * sizeof(float), hipMemcpyHostToDevice, h->stream_copy));
     } else {
       GV_HIP(hipMemcpyAsync(c.x, x, n * sizeof(float), hipMemcpyHostToDevice, h->stream_copy));
       GV_HIP(hipMemcpyAsync(c.y, y, n * sizeof(float), hipMemcpyHostToDevice, h->stream_copy));

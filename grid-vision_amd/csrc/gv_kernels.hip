@@ -138,43 +138,49 @@ void launch_points(const PointsArgs &a, hipStream_t s)
 // array: (double)u >= x_min <=> u >= (smallest float >= x_min), (double)u <= x_max <=> u <= (largest
 // float <= x_max) for every float u (NaN bounds stay NaN: always false), and per 16x16-pixel tile the
 // mask of boxes whose float range can contain a pixel of that tile (a superset is enough: the mask
-// only prunes).  One thread per (tile, 64-box word); the first nb threads also store the thresholds.
+// only prunes).  One thread per (tile, 64-box word); every workgroup first converts the boxes of its
+// words once into LDS (the first workgroup also stores them), so a thread's loop reads LDS only.
+constexpr int kPrepBoxes = 256;   // boxes staged per round
 __global__ void __launch_bounds__(256) k_bbox_prepare(const gv_bbox *__restrict__ bb, int32_t nb, int32_t tiles_x,
                                                       int32_t tiles_y, int32_t mask_words, float4 *__restrict__ bbox_f,
                                                       unsigned long long *__restrict__ tile_mask)
 {
+  __shared__ float4 s_f[kPrepBoxes];
   const int gid = blockIdx.x * blockDim.x + threadIdx.x;
-  if (gid < nb) {
-    const gv_bbox b = bb[gid];
-    bbox_f[gid] = make_float4(__double2float_ru(b.x_min), __double2float_ru(b.y_min), __double2float_rd(b.x_max),
-                              __double2float_rd(b.y_max));
-  }
   const int nwords = tiles_x * tiles_y * mask_words;
-  if (gid >= nwords) return;
-  const int wd = gid % mask_words, tile = gid / mask_words;
+  const int wd = (gid < nwords) ? gid % mask_words : 0, tile = (gid < nwords) ? gid / mask_words : 0;
   const int tx = tile % tiles_x, ty = tile / tiles_x;
   unsigned long long m = 0ull;
-  const int b1 = min(nb, 64 * wd + 64);
-  for (int i = 64 * wd; i < b1; ++i) {
-    const gv_bbox b = bb[i];
-    const float fx = __double2float_ru(b.x_min), fy = __double2float_ru(b.y_min);
-    const float fz = __double2float_rd(b.x_max), fw = __double2float_rd(b.y_max);
-    if (!(fx <= fz && fy <= fw)) continue;   // empty or NaN box never matches
-    // tiles whose pixel range [16t, 16t+16) can contain a u in [fx, fz]
-    int tx0 = (int)floorf(fmaxf(fx, 0.0f) / 16.0f), tx1 = (int)floorf(fminf(fz, 16.0f * tiles_x - 1.0f) / 16.0f);
-    int ty0 = (int)floorf(fmaxf(fy, 0.0f) / 16.0f), ty1 = (int)floorf(fminf(fw, 16.0f * tiles_y - 1.0f) / 16.0f);
-    tx0 = max(tx0, 0); ty0 = max(ty0, 0);
-    tx1 = min(tx1, tiles_x - 1); ty1 = min(ty1, tiles_y - 1);
-    if (tx >= tx0 && tx <= tx1 && ty >= ty0 && ty <= ty1) m |= 1ull << (i & 63);
+  for (int b0 = 0; b0 < nb; b0 += kPrepBoxes) {
+    __syncthreads();
+    const int i = b0 + (int)threadIdx.x;
+    if (i < nb) {
+      const gv_bbox b = bb[i];
+      const float4 f = make_float4(__double2float_ru(b.x_min), __double2float_ru(b.y_min), __double2float_rd(b.x_max),
+                                   __double2float_rd(b.y_max));
+      s_f[threadIdx.x] = f;
+      if (blockIdx.x == 0) bbox_f[i] = f;
+    }
+    __syncthreads();
+    const int lo = max(b0, 64 * wd), hi = min(min(nb, b0 + kPrepBoxes), 64 * wd + 64);
+    for (int q = lo; q < hi; ++q) {
+      const float4 f = s_f[q - b0];
+      if (!(f.x <= f.z && f.y <= f.w)) continue;   // empty or NaN box never matches
+      // tiles whose pixel range [16t, 16t+16) can contain a u in [f.x, f.z]
+      int tx0 = (int)floorf(fmaxf(f.x, 0.0f) / 16.0f), tx1 = (int)floorf(fminf(f.z, 16.0f * tiles_x - 1.0f) / 16.0f);
+      int ty0 = (int)floorf(fmaxf(f.y, 0.0f) / 16.0f), ty1 = (int)floorf(fminf(f.w, 16.0f * tiles_y - 1.0f) / 16.0f);
+      tx0 = max(tx0, 0); ty0 = max(ty0, 0);
+      tx1 = min(tx1, tiles_x - 1); ty1 = min(ty1, tiles_y - 1);
+      if (tx >= tx0 && tx <= tx1 && ty >= ty0 && ty <= ty1) m |= 1ull << (q & 63);
+    }
   }
-  tile_mask[gid] = m;
+  if (gid < nwords) tile_mask[gid] = m;
 }
 
 void launch_bbox_prepare(const gv_bbox *bboxes, int32_t nb, int32_t tiles_x, int32_t tiles_y, int32_t mask_words,
                          float4 *bbox_f, unsigned long long *tile_mask, hipStream_t s)
 {
-  const int n = std::max(nb, tiles_x * tiles_y * mask_words);
-  if (n <= 0) return;
+  const int n = std::max(tiles_x * tiles_y * mask_words, 1);   // (>= 1 workgroup: it also stores the thresholds)
   hipLaunchKernelGGL(k_bbox_prepare, dim3((n + 255) / 256), dim3(256), 0, s, bboxes, nb, tiles_x, tiles_y, mask_words,
                      bbox_f, tile_mask);
 }
@@ -201,39 +207,6 @@ void launch_transform_cloud(const float *x, const float *y, const float *z, uint
   if (!n) return;
   const uint32_t blocks = (uint32_t)std::min<uint64_t>(((uint64_t)n + 255) / 256, (uint64_t)4096);
   hipLaunchKernelGGL(k_transform, dim3(blocks), dim3(256), 0, s, x, y, z, n, m, ox, oy, oz);
-}
-
-// Host-to-device copy of the SoA cloud as a kernel: the three arrays sit in pinned, device-mapped host
-// memory (gv_host_alloc) and a small persistent grid streams them over PCIe with 16-byte loads, four per lane in
-// flight.  Unlike hipMemcpyAsync (which on this stack occupies the calling host thread for the duration of
-// the copy) the launch returns at once, so the host goes on to enqueue the frame; the grid is small (3 x 64
-// workgroups) so that it shares the CUs with the frame's kernels.
-__global__ void __launch_bounds__(256) k_copy_h2d_xyz(const float *__restrict__ hx, const float *__restrict__ hy,
-                                                      const float *__restrict__ hz, float *__restrict__ dx,
-                                                      float *__restrict__ dy, float *__restrict__ dz, size_t n)
-{
-  const float *src = blockIdx.y == 0 ? hx : (blockIdx.y == 1 ? hy : hz);
-  float *dst = blockIdx.y == 0 ? dx : (blockIdx.y == 1 ? dy : dz);
-  const size_t n4 = n >> 2;
-  typedef unsigned v4u __attribute__((ext_vector_type(4)));   // (the nontemporal builtins want a native vector)
-  const v4u *s4 = reinterpret_cast<const v4u *>(src);       // gv_host_alloc / hipMalloc bases are 16-byte aligned
-  v4u *d4 = reinterpret_cast<v4u *>(dst);
-  const size_t stride = (size_t)gridDim.x * blockDim.x;
-  size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-  for (; i + 3 * stride < n4; i += 4 * stride) {
-    const v4u a = __builtin_nontemporal_load(s4 + i), b = __builtin_nontemporal_load(s4 + i + stride);
-    const v4u c = __builtin_nontemporal_load(s4 + i + 2 * stride), d = __builtin_nontemporal_load(s4 + i + 3 * stride);
-    d4[i] = a; d4[i + stride] = b; d4[i + 2 * stride] = c; d4[i + 3 * stride] = d;
-  }
-  for (; i < n4; i += stride) d4[i] = __builtin_nontemporal_load(s4 + i);
-  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) dst[(n4 << 2) + threadIdx.x] = src[(n4 << 2) + threadIdx.x];
-}
-
-void launch_copy_h2d_xyz(const float *hx, const float *hy, const float *hz, float *dx, float *dy, float *dz, size_t n,
-                         hipStream_t s)
-{
-  if (!n) return;
-  hipLaunchKernelGGL(k_copy_h2d_xyz, dim3(64, 3), dim3(256), 0, s, hx, hy, hz, dx, dy, dz, n);
 }
 
 // PointCloud2 bytes -> SoA (pcl::fromROSMsg, src/grid_vision_node.cpp:105).  One

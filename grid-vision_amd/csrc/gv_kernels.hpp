@@ -38,9 +38,6 @@ void launch_bbox_prepare(const gv_bbox *bboxes, int32_t nb, int32_t tiles_x, int
 
 void launch_transform_cloud(const float *x, const float *y, const float *z, uint32_t n, const Mat34f &m,
                             float *ox, float *oy, float *oz, hipStream_t s);
-// x/y/z in pinned, device-mapped host memory (16-byte aligned) -> device SoA, as a kernel on stream s
-void launch_copy_h2d_xyz(const float *hx, const float *hy, const float *hz, float *dx, float *dy, float *dz, size_t n,
-                         hipStream_t s);
 void launch_deinterleave(const uint8_t *data, uint32_t n, uint32_t point_step, uint32_t off_x,
                          uint32_t off_y, uint32_t off_z, float *x, float *y, float *z, hipStream_t s);
 
