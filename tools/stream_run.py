@@ -7,23 +7,29 @@ import numpy as np
 import gvamd
 from gvamd import synth
 config = 3
-frames = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+frames = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 30
 g = synth.CONFIGS[config]["grid"]
 tfs = synth.transforms(True)
 pins, dets = [], []
 for f in range(3):
     x, y, z, _ = synth.cloud_uniform(config, seed_extra=100 + f)
-    p3 = tuple(gvamd.PinnedF32(len(x)) for _ in range(3))
-    p3[0].array[:], p3[1].array[:], p3[2].array[:] = x, y, z
-    pins.append(p3)
+    n0 = len(x)
+    if "split" in sys.argv:
+        p3 = tuple(gvamd.PinnedF32(n0) for _ in range(3))
+        p3[0].array[:], p3[1].array[:], p3[2].array[:] = x, y, z
+        pins.append(tuple(p.array for p in p3) + (p3,))
+    else:
+        blk = gvamd.PinnedF32(3 * n0)   # one block, one DMA
+        blk.array[:n0], blk.array[n0:2 * n0], blk.array[2 * n0:] = x, y, z
+        pins.append((blk.array[:n0], blk.array[n0:2 * n0], blk.array[2 * n0:], blk))
     dets.append((synth.detections(config, seed_extra=f), synth.lshape_poses(config, seed_extra=f)))
 h = gvamd.GridVisionHIP(g.grid_x, g.grid_y, g.resolution)
 h.set_transforms(tfs["cam_lidar"], tfs["base_cam"], tfs["base_lidar"])
 flags = gvamd.FRAME_BIN | gvamd.FRAME_RAYMARCH | gvamd.FRAME_BBOX_TEST
 t0 = time.perf_counter()
 for f in range(frames):
-    px, py, pz = pins[f % 3]
-    h.upload_xyz_async(px.array, py.array, pz.array)
+    px, py, pz, _keep = pins[f % 3]
+    h.upload_xyz_async(px, py, pz)
     h.set_detections_async(flags, bboxes=dets[f % 3][0], poses=dets[f % 3][1])
     h.enqueue_frame()
 h.synchronize()

@@ -9,3 +9,11 @@ for r in sel:
     n = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("gv::", "")[:28]
     s, e = (int(r["Start_Timestamp"]) - t0) / 1e3, (int(r["End_Timestamp"]) - t0) / 1e3
     print(f"{s:10.1f} {e:10.1f} {e - s:8.1f}  q{r.get('Queue_Id', '?'):>3}  {n}")
+
+mf = glob.glob(sys.argv[1] + "/**/*memory_copy_trace.csv", recursive=True)
+if mf:
+    m = sorted(csv.DictReader(open(mf[0])), key=lambda r: int(r["Start_Timestamp"]))
+    print("memory copies (last 12):")
+    for r in m[-12:]:
+        s, e = (int(r["Start_Timestamp"]) - t0) / 1e3, (int(r["End_Timestamp"]) - t0) / 1e3
+        print(f"{s:10.1f} {e:10.1f} {e - s:8.1f}  {r['Direction']}")
