@@ -26,12 +26,18 @@ for f in range(3):
 h = gvamd.GridVisionHIP(g.grid_x, g.grid_y, g.resolution)
 h.set_transforms(tfs["cam_lidar"], tfs["base_cam"], tfs["base_lidar"])
 flags = gvamd.FRAME_BIN | gvamd.FRAME_RAYMARCH | gvamd.FRAME_BBOX_TEST
-t0 = time.perf_counter()
-for f in range(frames):
-    px, py, pz, _keep = pins[f % 3]
-    h.upload_xyz_async(px, py, pz)
-    h.set_detections_async(flags, bboxes=dets[f % 3][0], poses=dets[f % 3][1])
-    h.enqueue_frame()
-h.synchronize()
-print("us/frame", (time.perf_counter() - t0) / frames * 1e6)
+per = []
+done = 0
+while done < frames:
+    nchunk = min(100, frames - done)
+    t0 = time.perf_counter()
+    for f in range(done, done + nchunk):
+        px, py, pz, _keep = pins[f % 3]
+        h.upload_xyz_async(px, py, pz)
+        h.set_detections_async(flags, bboxes=dets[f % 3][0], poses=dets[f % 3][1])
+        h.enqueue_frame()
+    h.synchronize()
+    per.append(round((time.perf_counter() - t0) / nchunk * 1e6, 1))
+    done += nchunk
+print("us/frame per chunk of 100:", per)
 h.close()
