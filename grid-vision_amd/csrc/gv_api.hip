@@ -151,8 +151,13 @@ struct gv_context {
   int32_t *d_idx = nullptr, *d_segof = nullptr, *d_segstart = nullptr; size_t seg_cap = 0, segstart_cap = 0;
   float *gx = nullptr, *gy = nullptr, *gz = nullptr; uint8_t *d_keep = nullptr; size_t gcap = 0;
   float4 *d_planes = nullptr; unsigned *d_plane_counts = nullptr; size_t planes_cap = 0;
-  uint8_t *d_ground = nullptr; size_t ground_cap = 0;
-  std::vector<uint8_t> ground_mask;   // last gv_segment_ground_plane result (host copy)
+  uint8_t *d_ground = nullptr; size_t ground_cap = 0;   // last ground mask (device resident)
+  size_t ground_n = 0;
+  double *d_rscratch = nullptr; size_t rscratch_cap = 0;   // tree-sum partials of the plane refinement
+  RansacState *d_rstate = nullptr;
+  uint32_t *d_blockcnt = nullptr; size_t blockcnt_cap = 0;   // per (1024-point block, bbox) counts of the cloud split
+  gv_lshape_pose *d_pose_out = nullptr; size_t pose_out_cap = 0;
+  uint8_t *d_pose_valid = nullptr; size_t pose_valid_cap = 0;
 
   bool counts_dirty = false;   // generic path: hits/miss/clip_end hold a kept frame
   bool have_hits = false, have_miss = false, have_cell_idx = false, have_bbox_id = false;
@@ -1171,7 +1176,7 @@ int gv_destroy(gv_handle h)
                   h->bin_keys, h->bin_tab, h->bin_total[0], h->bin_total[1], h->bin_done, h->bin_scratch,
                   h->tx, h->ty, h->tz, h->cell_idx, h->bbox_id, h->d_vout, h->d_pts, h->knn_partial, h->d_depths,
                   h->d_knn_d2, h->d_idx, h->d_segof, h->d_segstart, h->gx, h->gy, h->gz, h->d_keep, h->d_planes,
-                  h->d_plane_counts, h->d_ground};
+                  h->d_plane_counts, h->d_ground, h->d_rscratch, h->d_rstate, h->d_blockcnt, h->d_pose_out, h->d_pose_valid};
   for (void *p : bufs)
     if (p) (void)hipFree(p);
 #ifdef GV_DIAG
@@ -1979,10 +1984,12 @@ int gv_compute_depth_for_bboxes(gv_handle h, const gv_bbox *bboxes, int32_t nb, 
   GV_CATCH
 }
 
+// extractCloudPerBBox -> RadiusOutlierRemoval -> centroid + PCA rectangle, all on the device; only the nb
+// poses come back.  skip (device, n bytes or null): points removed before the split (ground).
 static int compute_bbox_pose_impl(gv_handle h, const gv_bbox *bboxes, int32_t nb, gv_lshape_pose *poses_out,
-                                  uint8_t *valid, const uint8_t *skip)
+                                  uint8_t *valid, const uint8_t *d_skip)
 {
-  if (!h || nb < 0 || (nb && (!bboxes || !poses_out || !valid))) return GV_ERR_BAD_ARG;
+  if (!h || nb < 0 || nb > 32767 || (nb && (!bboxes || !poses_out || !valid))) return GV_ERR_BAD_ARG;
   if (!h->has_cl) return GV_ERR_TF;
   GV_TRY
   if (nb == 0) return GV_OK;
@@ -1992,84 +1999,53 @@ static int compute_bbox_pose_impl(gv_handle h, const gv_bbox *bboxes, int32_t nb
   for (int32_t b = 0; b < nb; ++b) { valid[b] = 0; poses_out[b] = gv_lshape_pose{}; }
   if (n == 0) return GV_OK;
   if ((rc = upload_scratch_bboxes(h, bboxes, nb))) return rc;
-  if ((rc = ensure_tbuf(h, n))) return rc;
-  // extractCloudPerBBox (cloud_detections.cpp:250-298): first-match bbox id per point,
-  // and the camera-frame cloud the per-bbox clouds are cut from
+  // extractCloudPerBBox (cloud_detections.cpp:250-298): first-match bbox id per point
   {
     PointsArgs a{};
     bbox_points_args(h, a);
     launch_points(a, h->stream);
-    launch_transform_cloud(h->cx, h->cy, h->cz, (uint32_t)n, h->m_cam, h->tx, h->ty, h->tz, h->stream);
     GV_HIP(hipGetLastError());
   }
-  std::vector<int16_t> ids(n);
-  GV_HIP(hipMemcpyAsync(ids.data(), h->bbox_id, n * sizeof(int16_t), hipMemcpyDeviceToHost, h->stream));
-  GV_HIP(hipStreamSynchronize(h->stream));
   h->have_bbox_id = true;
-  // per-bbox point lists in cloud order (the reference appends in cloud order, :286)
-  std::vector<int32_t> seg_start((size_t)nb + 1, 0);
-  if (skip)   // ground points were removed before extractCloudPerBBox (cloud_detections.cpp:306-314)
-    for (size_t i = 0; i < n; ++i)
-      if (skip[i]) ids[i] = -1;
-  for (size_t i = 0; i < n; ++i)
-    if (ids[i] >= 0) seg_start[(size_t)ids[i] + 1]++;
-  for (int32_t b = 0; b < nb; ++b) seg_start[b + 1] += seg_start[b];
-  const int32_t m = seg_start[nb];
-  if (m == 0) return GV_OK;
-  std::vector<int32_t> idx((size_t)m), seg_of((size_t)m), cur(seg_start.begin(), seg_start.end() - 1);
-  for (size_t i = 0; i < n; ++i)
-    if (ids[i] >= 0) {
-      const int32_t p = cur[ids[i]]++;
-      idx[p] = (int32_t)i;
-      seg_of[p] = ids[i];
-    }
-  if ((size_t)m > h->gcap) {
+  // per-bbox point lists in cloud order (the reference appends in cloud order, :286): stable device split
+  const size_t nblocks = (n + 1023) / 1024;
+  if ((rc = grow(h, h->d_blockcnt, h->blockcnt_cap, nblocks * (size_t)nb + 16))) return rc;
+  if ((rc = grow(h, h->d_segstart, h->segstart_cap, (size_t)nb + 2))) return rc;
+  if (n > h->seg_cap) {
+    if (h->d_idx) { GV_HIP(hipFree(h->d_idx)); h->d_idx = nullptr; }
+    if (h->d_segof) { GV_HIP(hipFree(h->d_segof)); h->d_segof = nullptr; }
+    h->seg_cap = 0;
+    const size_t want = n + n / 8 + 1024;
+    GV_HIP(hipMalloc(reinterpret_cast<void **>(&h->d_idx), want * sizeof(int32_t)));
+    GV_HIP(hipMalloc(reinterpret_cast<void **>(&h->d_segof), want * sizeof(int32_t)));
+    h->seg_cap = want;
+  }
+  if (n > h->gcap) {
     for (float **p : {&h->gx, &h->gy, &h->gz})
       if (*p) { GV_HIP(hipFree(*p)); *p = nullptr; }
     if (h->d_keep) { GV_HIP(hipFree(h->d_keep)); h->d_keep = nullptr; }
     h->gcap = 0;
-    const size_t want = (size_t)m + (size_t)m / 4 + 1024;
+    const size_t want = n + n / 8 + 1024;
     GV_HIP(hipMalloc(reinterpret_cast<void **>(&h->gx), want * sizeof(float)));
     GV_HIP(hipMalloc(reinterpret_cast<void **>(&h->gy), want * sizeof(float)));
     GV_HIP(hipMalloc(reinterpret_cast<void **>(&h->gz), want * sizeof(float)));
     GV_HIP(hipMalloc(reinterpret_cast<void **>(&h->d_keep), want));
     h->gcap = want;
   }
-  if ((size_t)m > h->seg_cap) {
-    if (h->d_idx) { GV_HIP(hipFree(h->d_idx)); h->d_idx = nullptr; }
-    if (h->d_segof) { GV_HIP(hipFree(h->d_segof)); h->d_segof = nullptr; }
-    h->seg_cap = 0;
-    const size_t want = (size_t)m + (size_t)m / 4 + 1024;
-    GV_HIP(hipMalloc(reinterpret_cast<void **>(&h->d_idx), want * sizeof(int32_t)));
-    GV_HIP(hipMalloc(reinterpret_cast<void **>(&h->d_segof), want * sizeof(int32_t)));
-    h->seg_cap = want;
-  }
-  if ((rc = grow(h, h->d_segstart, h->segstart_cap, (size_t)nb + 1))) return rc;
-  GV_HIP(hipMemcpyAsync(h->d_idx, idx.data(), (size_t)m * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
-  GV_HIP(hipMemcpyAsync(h->d_segof, seg_of.data(), (size_t)m * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
-  GV_HIP(hipMemcpyAsync(h->d_segstart, seg_start.data(), ((size_t)nb + 1) * sizeof(int32_t), hipMemcpyHostToDevice,
-                        h->stream));
-  launch_gather_xyz(h->tx, h->ty, h->tz, h->d_idx, m, h->gx, h->gy, h->gz, h->stream);
+  if ((rc = grow(h, h->d_pose_out, h->pose_out_cap, (size_t)nb))) return rc;
+  if ((rc = grow(h, h->d_pose_valid, h->pose_valid_cap, (size_t)nb))) return rc;
+  launch_split_by_bbox(h->bbox_id, d_skip, (uint32_t)n, nb, h->d_blockcnt, h->d_segstart, h->d_idx, h->d_segof, h->stream);
+  launch_gather_cam(h->cx, h->cy, h->cz, h->m_cam, h->d_idx, h->d_segstart, nb, (uint32_t)n, h->gx, h->gy, h->gz, h->stream);
   // RadiusOutlierRemoval(0.4, 10)  (cloud_detections.cpp:150-154)
   const double radius = 0.4;
-  launch_radius_count(h->gx, h->gy, h->gz, h->d_segof, h->d_segstart, m, host::floor_to_float(radius * radius), 10,
-                      h->d_keep, h->stream);
-  GV_HIP(hipGetLastError());
-  std::vector<float> px((size_t)m), py((size_t)m), pz((size_t)m);
-  std::vector<uint8_t> keep((size_t)m);
-  GV_HIP(hipMemcpyAsync(px.data(), h->gx, (size_t)m * sizeof(float), hipMemcpyDeviceToHost, h->stream));
-  GV_HIP(hipMemcpyAsync(py.data(), h->gy, (size_t)m * sizeof(float), hipMemcpyDeviceToHost, h->stream));
-  GV_HIP(hipMemcpyAsync(pz.data(), h->gz, (size_t)m * sizeof(float), hipMemcpyDeviceToHost, h->stream));
-  GV_HIP(hipMemcpyAsync(keep.data(), h->d_keep, (size_t)m, hipMemcpyDeviceToHost, h->stream));
-  GV_HIP(hipStreamSynchronize(h->stream));
+  launch_radius_count(h->gx, h->gy, h->gz, h->d_segof, h->d_segstart, (int32_t)n, h->d_segstart + nb,
+                      host::floor_to_float(radius * radius), 10, h->d_keep, h->stream);
   // centroid + PCA rectangle per bbox on the filtered points, reference order (:156-247)
-  std::vector<float> fx, fy, fz;
-  for (int32_t b = 0; b < nb; ++b) {
-    fx.clear(); fy.clear(); fz.clear();
-    for (int32_t p = seg_start[b]; p < seg_start[b + 1]; ++p)
-      if (keep[p]) { fx.push_back(px[p]); fy.push_back(py[p]); fz.push_back(pz[p]); }
-    valid[b] = host::pca_bbox(fx.data(), fy.data(), fz.data(), fx.size(), poses_out[b]) ? 1 : 0;
-  }
+  launch_pca_bbox(h->gx, h->gy, h->gz, h->d_keep, h->d_segstart, nb, h->d_pose_out, h->d_pose_valid, h->stream);
+  GV_HIP(hipGetLastError());
+  GV_HIP(hipMemcpyAsync(poses_out, h->d_pose_out, (size_t)nb * sizeof(gv_lshape_pose), hipMemcpyDeviceToHost, h->stream));
+  GV_HIP(hipMemcpyAsync(valid, h->d_pose_valid, (size_t)nb, hipMemcpyDeviceToHost, h->stream));
+  GV_HIP(hipStreamSynchronize(h->stream));
   return GV_OK;
   GV_CATCH
 }
@@ -2077,6 +2053,35 @@ static int compute_bbox_pose_impl(gv_handle h, const gv_bbox *bboxes, int32_t nb
 int gv_compute_bbox_pose(gv_handle h, const gv_bbox *bboxes, int32_t nb, gv_lshape_pose *poses_out, uint8_t *valid)
 {
   return compute_bbox_pose_impl(h, bboxes, nb, poses_out, valid, nullptr);
+}
+
+// segmentGroundPlane on the device; state (plane, inlier count) comes back, the mask stays resident
+static int segment_ground_device(gv_context *h, double threshold, int32_t iterations, uint64_t seed, RansacState &st)
+{
+  const size_t n = h->n;
+  st = RansacState{};
+  h->ground_n = 0;
+  if (n < 3) return GV_OK;
+  int rc;
+  if ((size_t)iterations > h->planes_cap) {
+    if (h->d_planes) { GV_HIP(hipFree(h->d_planes)); h->d_planes = nullptr; }
+    if (h->d_plane_counts) { GV_HIP(hipFree(h->d_plane_counts)); h->d_plane_counts = nullptr; }
+    h->planes_cap = 0;
+    GV_HIP(hipMalloc(reinterpret_cast<void **>(&h->d_planes), (size_t)iterations * sizeof(float4)));
+    GV_HIP(hipMalloc(reinterpret_cast<void **>(&h->d_plane_counts), (size_t)iterations * sizeof(unsigned)));
+    h->planes_cap = (size_t)iterations;
+  }
+  if ((rc = grow(h, h->d_ground, h->ground_cap, n))) return rc;
+  if ((rc = grow(h, h->d_rscratch, h->rscratch_cap, ransac_scratch_doubles(n)))) return rc;
+  if (!h->d_rstate) GV_HIP(hipMalloc(reinterpret_cast<void **>(&h->d_rstate), sizeof(RansacState)));
+  // camera-frame cloud (the reference segments transformed_cloud, grid_vision_node.cpp:215-216): transformed on the fly
+  launch_ransac(h->cx, h->cy, h->cz, (uint32_t)n, h->m_cam, threshold, iterations, seed, h->d_planes, h->d_plane_counts,
+                h->d_rscratch, h->d_rstate, h->d_ground, h->stream);
+  GV_HIP(hipGetLastError());
+  GV_HIP(hipMemcpyAsync(&st, h->d_rstate, sizeof(RansacState), hipMemcpyDeviceToHost, h->stream));
+  GV_HIP(hipStreamSynchronize(h->stream));
+  h->ground_n = n;
+  return GV_OK;
 }
 
 int gv_segment_ground_plane(gv_handle h, double threshold, int32_t iterations, uint64_t seed, uint8_t *is_ground,
@@ -2087,69 +2092,18 @@ int gv_segment_ground_plane(gv_handle h, double threshold, int32_t iterations, u
   GV_TRY
   int rc = use_device(h);
   if (rc) return rc;
-  const size_t n = h->n;
-  h->ground_mask.assign(n, 0);
   if (coeff) coeff[0] = coeff[1] = coeff[2] = coeff[3] = 0.0f;
   if (n_inliers) *n_inliers = 0;
-  if (n < 3) return GV_OK;
-  if ((rc = ensure_tbuf(h, n))) return rc;
-  // camera-frame cloud (the reference segments transformed_cloud, grid_vision_node.cpp:215-216)
-  launch_transform_cloud(h->cx, h->cy, h->cz, (uint32_t)n, h->m_cam, h->tx, h->ty, h->tz, h->stream);
-  GV_HIP(hipGetLastError());
-  std::vector<float> px(n), py(n), pz(n);
-  GV_HIP(hipMemcpyAsync(px.data(), h->tx, n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
-  GV_HIP(hipMemcpyAsync(py.data(), h->ty, n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
-  GV_HIP(hipMemcpyAsync(pz.data(), h->tz, n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
-  GV_HIP(hipStreamSynchronize(h->stream));
-  // hypotheses: three counter-based draws each (specified by outcome, not PCL's RNG)
-  std::vector<float4> planes;
-  std::vector<int32_t> hyp_of;
-  for (int32_t t = 0; t < iterations; ++t) {
-    size_t id[3];
-    for (int k = 0; k < 3; ++k) id[k] = (size_t)(host::splitmix64(seed + 3ull * (uint64_t)t + (uint64_t)k) % (uint64_t)n);
-    const float p0[3] = {px[id[0]], py[id[0]], pz[id[0]]}, p1[3] = {px[id[1]], py[id[1]], pz[id[1]]},
-                p2[3] = {px[id[2]], py[id[2]], pz[id[2]]};
-    float c[4];
-    if (!host::plane_from_sample(p0, p1, p2, c)) continue;
-    planes.push_back(make_float4(c[0], c[1], c[2], c[3]));
-    hyp_of.push_back(t);
+  if (is_ground && h->n) std::memset(is_ground, 0, h->n);
+  RansacState st;
+  if ((rc = segment_ground_device(h, threshold, iterations, seed, st))) return rc;
+  if (!st.best_count) return GV_OK;   // "Could not estimate a planar model" (:122-126)
+  if (is_ground) {   // the caller asked for the per-point mask: the only O(N) transfer of this call
+    GV_HIP(hipMemcpyAsync(is_ground, h->d_ground, h->n, hipMemcpyDeviceToHost, h->stream));
+    GV_HIP(hipStreamSynchronize(h->stream));
   }
-  if (planes.empty()) return GV_OK;
-  const size_t nh = planes.size();
-  if (nh > h->planes_cap) {
-    if (h->d_planes) { GV_HIP(hipFree(h->d_planes)); h->d_planes = nullptr; }
-    if (h->d_plane_counts) { GV_HIP(hipFree(h->d_plane_counts)); h->d_plane_counts = nullptr; }
-    h->planes_cap = 0;
-    GV_HIP(hipMalloc(reinterpret_cast<void **>(&h->d_planes), nh * sizeof(float4)));
-    GV_HIP(hipMalloc(reinterpret_cast<void **>(&h->d_plane_counts), nh * sizeof(unsigned)));
-    h->planes_cap = nh;
-  }
-  if ((rc = grow(h, h->d_ground, h->ground_cap, n))) return rc;
-  GV_HIP(hipMemcpyAsync(h->d_planes, planes.data(), nh * sizeof(float4), hipMemcpyHostToDevice, h->stream));
-  GV_HIP(hipMemsetAsync(h->d_plane_counts, 0, nh * sizeof(unsigned), h->stream));
-  launch_plane_count(h->tx, h->ty, h->tz, (uint32_t)n, h->d_planes, (int)nh, threshold, h->d_plane_counts, h->stream);
-  GV_HIP(hipGetLastError());
-  std::vector<unsigned> counts(nh);
-  GV_HIP(hipMemcpyAsync(counts.data(), h->d_plane_counts, nh * sizeof(unsigned), hipMemcpyDeviceToHost, h->stream));
-  GV_HIP(hipStreamSynchronize(h->stream));
-  size_t best = 0;
-  unsigned bestc = 0;
-  for (size_t k = 0; k < nh; ++k)
-    if (counts[k] > bestc) { bestc = counts[k]; best = k; }   // first wins ties
-  if (bestc == 0) return GV_OK;   // "Could not estimate a planar model" (:122-126)
-  const float c0[4] = {planes[best].x, planes[best].y, planes[best].z, planes[best].w};
-  float refined[4];
-  host::refine_plane(px.data(), py.data(), pz.data(), n, c0, threshold, refined);   // optimizeCoefficients
-  launch_plane_mask(h->tx, h->ty, h->tz, (uint32_t)n, make_float4(refined[0], refined[1], refined[2], refined[3]),
-                    threshold, h->d_ground, h->stream);
-  GV_HIP(hipGetLastError());
-  GV_HIP(hipMemcpyAsync(h->ground_mask.data(), h->d_ground, n, hipMemcpyDeviceToHost, h->stream));
-  GV_HIP(hipStreamSynchronize(h->stream));
-  int64_t m = 0;
-  for (size_t i = 0; i < n; ++i) m += h->ground_mask[i];
-  if (is_ground) std::memcpy(is_ground, h->ground_mask.data(), n);
-  if (coeff) std::memcpy(coeff, refined, sizeof(refined));
-  if (n_inliers) *n_inliers = m;
+  if (coeff) { coeff[0] = st.refined.x; coeff[1] = st.refined.y; coeff[2] = st.refined.z; coeff[3] = st.refined.w; }
+  if (n_inliers) *n_inliers = (int64_t)st.n_inliers;
   return GV_OK;
   GV_CATCH
 }
@@ -2158,21 +2112,26 @@ int gv_compute_bbox_pose_ground_removed(gv_handle h, const gv_bbox *bboxes, int3
                                         uint8_t *valid, int32_t *n_poses_or_fail)
 {
   if (!h || nb < 0 || (nb && (!bboxes || !poses_out || !valid))) return GV_ERR_BAD_ARG;
+  if (!h->has_cl) return GV_ERR_TF;
+  GV_TRY
   // computeBBoxPose (cloud_detections.cpp:300-321): segmentGroundPlane -> extractCloudPerBBox -> PCA
-  int64_t m = 0;
-  int rc = gv_segment_ground_plane(h, 0.04, 50, 12345ull, nullptr, nullptr, &m);
+  int rc = use_device(h);
   if (rc) return rc;
+  RansacState st;
+  if ((rc = segment_ground_device(h, 0.04, 50, 12345ull, st))) return rc;
+  const uint64_t m = st.best_count ? st.n_inliers : 0;
   if (n_poses_or_fail) *n_poses_or_fail = 0;
   if (m == 0 || (size_t)m == h->n) {   // empty segmented cloud -> the reference returns {} (:307-309)
     for (int32_t b = 0; b < nb; ++b) valid[b] = 0;
     if (n_poses_or_fail) *n_poses_or_fail = -1;
     return GV_OK;
   }
-  rc = compute_bbox_pose_impl(h, bboxes, nb, poses_out, valid, h->ground_mask.data());
+  rc = compute_bbox_pose_impl(h, bboxes, nb, poses_out, valid, h->d_ground);
   if (rc) return rc;
   if (n_poses_or_fail)
     for (int32_t b = 0; b < nb; ++b) *n_poses_or_fail += valid[b];
   return GV_OK;
+  GV_CATCH
 }
 
 int gv_comm_unique_id(uint8_t id_out[128])

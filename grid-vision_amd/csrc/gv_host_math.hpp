@@ -212,163 +212,6 @@ inline float floor_to_float(double v)
   return f;
 }
 
-// bboxPoseEstimation :156-181 + computePCABoundingBox :187-247 for one (already filtered)
-// bbox cloud, in the reference's order: pcl::compute3DCentroid (fp32 running sum / n),
-// cv::PCA(DATA_AS_ROW, CV_32F) on rows (z, x): fp32 mean, fp64 covariance of the
-// fp32-centred samples scaled by 1/n and stored fp32, eigenvectors of the symmetric 2x2,
-// projections min/max.  The eigenvector sign is arbitrary upstream; major.x >= 0 here.
-inline bool pca_bbox(const float *x, const float *y, const float *z, size_t n, gv_lshape_pose &out)
-{
-  out = gv_lshape_pose{};
-  if (n == 0) return false;   // :174-175
-  float cy = 0.0f;
-  for (size_t i = 0; i < n; ++i) cy += y[i];
-  cy /= (float)n;
-  float m0 = 0.0f, m1 = 0.0f;
-  for (size_t i = 0; i < n; ++i) { m0 += z[i]; m1 += x[i]; }
-  m0 = m0 * (float)(1.0 / (double)n);
-  m1 = m1 * (float)(1.0 / (double)n);
-  double c00 = 0, c01 = 0, c11 = 0;
-  for (size_t i = 0; i < n; ++i) {
-    const float a = z[i] - m0, b = x[i] - m1;
-    c00 += (double)a * a; c01 += (double)a * b; c11 += (double)b * b;
-  }
-  const double sc = 1.0 / (double)n;
-  const double a = (double)(float)(c00 * sc), b = (double)(float)(c01 * sc), d = (double)(float)(c11 * sc);
-  double mjx, mjy;
-  if (b == 0.0) {
-    if (a >= d) { mjx = 1; mjy = 0; } else { mjx = 0; mjy = 1; }
-  } else {
-    const double tr = a + d, df = a - d;
-    const double root = std::sqrt(df * df + 4.0 * b * b);
-    const double l1 = 0.5 * (tr + root);
-    mjx = b; mjy = l1 - a;
-    if (std::fabs(l1 - d) > std::fabs(mjy)) { mjx = l1 - d; mjy = b; }
-    const double nn = std::sqrt(mjx * mjx + mjy * mjy);
-    mjx /= nn; mjy /= nn;
-  }
-  if (mjx < 0 || (mjx == 0 && mjy < 0)) { mjx = -mjx; mjy = -mjy; }
-  const float Mx = (float)mjx, My = (float)mjy, Nx = (float)(-mjy), Ny = (float)mjx;
-  float minL = 3.402823466e+38f, maxL = -3.402823466e+38f, minW = 3.402823466e+38f, maxW = -3.402823466e+38f;
-  for (size_t i = 0; i < n; ++i) {   // :203-216
-    const float dx = z[i] - m0, dy = x[i] - m1;
-    const float pl = dx * Mx + dy * My, pw = dx * Nx + dy * Ny;
-    minL = std::min(minL, pl); maxL = std::max(maxL, pl);
-    minW = std::min(minW, pw); maxW = std::max(maxW, pw);
-  }
-  const float angle = std::atan2(My, Mx) * 180.0f / (float)3.14159265358979323846;   // :227 (degrees)
-  out.px = m1;    // :230 center.y
-  out.py = cy;    // :231 then :181
-  out.pz = m0;    // :232 center.x
-  const Quat q = quat_from_rpy(0, -angle, 0);   // :236 (degrees passed as radians, as the reference does)
-  out.qx = q.x; out.qy = q.y; out.qz = q.z; out.qw = q.w;
-  out.length = maxL - minL;   // :218,:243
-  out.width = maxW - minW;    // :219,:244
-  out.height = 0.0;           // never set on this path in the reference
-  return true;
-}
-
-// ---- RANSAC ground plane, host half (segmentGroundPlane, cloud_detections.cpp:105-138) ----
-inline uint64_t splitmix64(uint64_t z)
-{
-  z += 0x9E3779B97F4A7C15ull;
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-  return z ^ (z >> 31);
-}
-
-// SampleConsensusModelPlane::isSampleGood + computeModelCoefficients (fp32)
-inline bool plane_from_sample(const float p0[3], const float p1[3], const float p2[3], float c[4])
-{
-  for (int k = 0; k < 3; ++k)
-    if (!std::isfinite(p0[k]) || !std::isfinite(p1[k]) || !std::isfinite(p2[k])) return false;
-  const float a[3] = {p1[0] - p0[0], p1[1] - p0[1], p1[2] - p0[2]};
-  const float b[3] = {p2[0] - p0[0], p2[1] - p0[1], p2[2] - p0[2]};
-  const float r0 = a[0] / b[0], r1 = a[1] / b[1], r2 = a[2] / b[2];
-  if (!((r0 != r1) || (r2 != r1))) return false;
-  float n[3] = {a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]};
-  const float len = std::sqrt((n[0] * n[0] + n[1] * n[1]) + n[2] * n[2]);
-  if (!(len > 0.0f) || !std::isfinite(len)) return false;
-  n[0] /= len; n[1] /= len; n[2] /= len;
-  c[0] = n[0]; c[1] = n[1]; c[2] = n[2];
-  c[3] = -1.0f * (((n[0] * p0[0]) + n[1] * p0[1]) + n[2] * p0[2]);
-  return true;
-}
-
-inline bool plane_inlier(const float c[4], float x, float y, float z, double thr)
-{
-  const float d = (((c[0] * x) + c[1] * y) + c[2] * z) + c[3];
-  return (double)std::fabs(d) < thr;
-}
-
-// unit eigenvector of the smallest eigenvalue of a symmetric 3x3 (cyclic Jacobi, fp64)
-inline void smallest_eigenvector3(const double cov[6], double v[3])
-{
-  double a[3][3] = {{cov[0], cov[1], cov[2]}, {cov[1], cov[3], cov[4]}, {cov[2], cov[4], cov[5]}};
-  double e[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
-  for (int sweep = 0; sweep < 32; ++sweep) {
-    const double off = a[0][1] * a[0][1] + a[0][2] * a[0][2] + a[1][2] * a[1][2];
-    if (off < 1e-300) break;
-    for (int p = 0; p < 2; ++p)
-      for (int q = p + 1; q < 3; ++q) {
-        if (a[p][q] == 0.0) continue;
-        const double theta = (a[q][q] - a[p][p]) / (2.0 * a[p][q]);
-        const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
-        const double c = 1.0 / std::sqrt(t * t + 1.0), s = t * c;
-        for (int k = 0; k < 3; ++k) {
-          const double akp = a[k][p], akq = a[k][q];
-          a[k][p] = c * akp - s * akq;
-          a[k][q] = s * akp + c * akq;
-        }
-        for (int k = 0; k < 3; ++k) {
-          const double apk = a[p][k], aqk = a[q][k];
-          a[p][k] = c * apk - s * aqk;
-          a[q][k] = s * apk + c * aqk;
-        }
-        for (int k = 0; k < 3; ++k) {
-          const double ekp = e[k][p], ekq = e[k][q];
-          e[k][p] = c * ekp - s * ekq;
-          e[k][q] = s * ekp + c * ekq;
-        }
-      }
-  }
-  int m = 0;
-  if (a[1][1] < a[m][m]) m = 1;
-  if (a[2][2] < a[m][m]) m = 2;
-  const double n[3] = {e[0][m], e[1][m], e[2][m]};
-  const double len = std::sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
-  int big = 0;
-  if (std::fabs(n[1]) > std::fabs(n[big])) big = 1;
-  if (std::fabs(n[2]) > std::fabs(n[big])) big = 2;
-  const double sg = (n[big] < 0) ? -1.0 / len : 1.0 / len;
-  v[0] = n[0] * sg; v[1] = n[1] * sg; v[2] = n[2] * sg;
-}
-
-// optimizeModelCoefficients: least-squares plane of the inliers of c (cloud order, fp64)
-inline size_t refine_plane(const float *x, const float *y, const float *z, size_t n, const float c[4], double thr,
-                           float refined[4])
-{
-  double sx = 0, sy = 0, sz = 0;
-  size_t m = 0;
-  for (size_t i = 0; i < n; ++i)
-    if (plane_inlier(c, x[i], y[i], z[i], thr)) { sx += x[i]; sy += y[i]; sz += z[i]; ++m; }
-  for (int k = 0; k < 4; ++k) refined[k] = c[k];
-  if (m < 3) return m;
-  const double cx = sx / (double)m, cy = sy / (double)m, cz = sz / (double)m;
-  double cov[6] = {0, 0, 0, 0, 0, 0};
-  for (size_t i = 0; i < n; ++i)
-    if (plane_inlier(c, x[i], y[i], z[i], thr)) {
-      const double dx = x[i] - cx, dy = y[i] - cy, dz = z[i] - cz;
-      cov[0] += dx * dx; cov[1] += dx * dy; cov[2] += dx * dz;
-      cov[3] += dy * dy; cov[4] += dy * dz; cov[5] += dz * dz;
-    }
-  double nv[3];
-  smallest_eigenvector3(cov, nv);
-  refined[0] = (float)nv[0]; refined[1] = (float)nv[1]; refined[2] = (float)nv[2];
-  refined[3] = (float)(-((nv[0] * cx + nv[1] * cy) + nv[2] * cz));
-  return m;
-}
-
 // host getIndex (same arithmetic as the device one) for geometry-only queries
 inline bool get_index(const GridParams &g, double x, double y, int &ix, int &iy)
 {

@@ -188,14 +188,31 @@ void launch_project_uvd(const float *x, const float *y, const float *z, uint32_t
                         const CamK &cam, float *pu, float *pv, float *pd, hipStream_t s);
 void launch_knn(const float *pu, const float *pv, const float *pd, uint32_t n, const gv_bbox *bboxes, int nb, int k,
                 int nchunks, Cand2 *partial, float *depths, float *knn_d2, hipStream_t s);
+// keep[i] for the points [0, n) of the segment-ordered arrays; n = min(n_max, *n_dev) when n_dev is given
 void launch_radius_count(const float *x, const float *y, const float *z, const int32_t *seg_of,
-                         const int32_t *seg_start, int32_t n, float r2f, int32_t min_pts, uint8_t *keep,
-                         hipStream_t s);
-void launch_plane_count(const float *x, const float *y, const float *z, uint32_t n, const float4 *planes, int nh,
-                        double thr, unsigned *counts, hipStream_t s);
-void launch_plane_mask(const float *x, const float *y, const float *z, uint32_t n, float4 pl, double thr,
-                       uint8_t *mask, hipStream_t s);
-void launch_gather_xyz(const float *x, const float *y, const float *z, const int32_t *idx, int32_t n, float *ox,
-                       float *oy, float *oz, hipStream_t s);
+                         const int32_t *seg_start, int32_t n_max, const int32_t *n_dev, float r2f, int32_t min_pts,
+                         uint8_t *keep, hipStream_t s);
+
+// ---- device-resident RANSAC ground plane + per-bbox clouds / PCA (gv_cloudops.hip) ----
+struct RansacState {
+  float4 plane;             // best sampled plane
+  float4 refined;           // least-squares plane of its inliers (= plane when fewer than 3)
+  double centroid[3];
+  unsigned long long m;         // inliers of `plane`
+  unsigned long long n_inliers; // inliers of `refined` (the mask)
+  unsigned best_count;          // 0: could not estimate a planar model
+};
+size_t ransac_scratch_doubles(size_t n);
+// the whole of segmentGroundPlane on stream s; mask[n] and *st stay on the device
+void launch_ransac(const float *x, const float *y, const float *z, uint32_t n, const Mat34f &m_cam, double thr, int iters,
+                   unsigned long long seed, float4 *planes, unsigned *counts, double *scratch, RansacState *st,
+                   uint8_t *mask, hipStream_t s);
+// stable split of the cloud by bbox id (skip[i] != 0 drops point i): seg_start[nb + 1], idx / seg_of in segment order
+void launch_split_by_bbox(const int16_t *ids, const uint8_t *skip, uint32_t n, int nb, uint32_t *block_counts,
+                          int32_t *seg_start, int32_t *idx, int32_t *seg_of, hipStream_t s);
+void launch_gather_cam(const float *x, const float *y, const float *z, const Mat34f &m, const int32_t *idx,
+                       const int32_t *seg_start, int nb, uint32_t n_max, float *ox, float *oy, float *oz, hipStream_t s);
+void launch_pca_bbox(const float *gx, const float *gy, const float *gz, const uint8_t *keep, const int32_t *seg_start, int nb,
+                     gv_lshape_pose *poses, uint8_t *valid, hipStream_t s);
 
 }  // namespace gv

@@ -200,9 +200,12 @@ void launch_knn(const float *pu, const float *pv, const float *pd, uint32_t n, c
 __global__ void __launch_bounds__(256) k_radius_count(const float *__restrict__ x, const float *__restrict__ y,
                                                       const float *__restrict__ z,
                                                       const int32_t *__restrict__ seg_of,
-                                                      const int32_t *__restrict__ seg_start, int32_t n, float r2f,
+                                                      const int32_t *__restrict__ seg_start, int32_t n_max,
+                                                      const int32_t *__restrict__ n_dev, float r2f,
                                                       int32_t min_pts, uint8_t *__restrict__ keep)
 {
+  const int32_t n = n_dev ? min(n_max, *n_dev) : n_max;   // the number of gathered points may live on the device
+  if ((int)blockIdx.x * 256 >= n) return;
   __shared__ float sx[256], sy[256], sz[256];
   // one block per 256 consecutive points; a block may straddle segments, so each thread
   // walks its own segment in tiles of 256 shared by the block when the tile ranges agree
@@ -244,86 +247,12 @@ __global__ void __launch_bounds__(256) k_radius_count(const float *__restrict__ 
 }
 
 void launch_radius_count(const float *x, const float *y, const float *z, const int32_t *seg_of,
-                         const int32_t *seg_start, int32_t n, float r2f, int32_t min_pts, uint8_t *keep,
-                         hipStream_t s)
+                         const int32_t *seg_start, int32_t n_max, const int32_t *n_dev, float r2f, int32_t min_pts,
+                         uint8_t *keep, hipStream_t s)
 {
-  if (n <= 0) return;
-  hipLaunchKernelGGL(k_radius_count, dim3((n + 255) / 256), dim3(256), 0, s, x, y, z, seg_of, seg_start, n, r2f,
-                     min_pts, keep);
-}
-
-// ---- RANSAC ground plane (segmentGroundPlane, src/cloud_detections.cpp:105-138) -------------
-// inlier iff |n.p + d| < threshold with the fp32 distance ((a*x + b*y) + c*z) + d.
-// grid (chunks, H): block (c, h) counts the inliers of hypothesis h in its chunk of points.
-__global__ void __launch_bounds__(256) k_plane_count(const float *__restrict__ x, const float *__restrict__ y,
-                                                     const float *__restrict__ z, uint32_t n,
-                                                     const float4 *__restrict__ planes, double thr,
-                                                     unsigned *__restrict__ counts)
-{
-  __shared__ unsigned s_w[4];
-  const float4 pl = planes[blockIdx.y];
-  const uint32_t per = (n + gridDim.x - 1) / gridDim.x;
-  const uint32_t lo = blockIdx.x * per, hi = min(n, lo + per);
-  unsigned c = 0;
-  for (uint32_t i = lo + threadIdx.x; i < hi; i += 256) {
-    const float d = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(pl.x, x[i]), __fmul_rn(pl.y, y[i])), __fmul_rn(pl.z, z[i])), pl.w);
-    c += ((double)fabsf(d) < thr) ? 1u : 0u;
-  }
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off);
-  if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = c;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const unsigned t = s_w[0] + s_w[1] + s_w[2] + s_w[3];
-    if (t) atomicAdd(&counts[blockIdx.y], t);
-  }
-}
-
-__global__ void __launch_bounds__(256) k_plane_mask(const float *__restrict__ x, const float *__restrict__ y,
-                                                    const float *__restrict__ z, uint32_t n, float4 pl, double thr,
-                                                    uint8_t *__restrict__ mask)
-{
-  const uint32_t stride = gridDim.x * blockDim.x;
-  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-    const float d = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(pl.x, x[i]), __fmul_rn(pl.y, y[i])), __fmul_rn(pl.z, z[i])), pl.w);
-    mask[i] = ((double)fabsf(d) < thr) ? 1 : 0;
-  }
-}
-
-void launch_plane_count(const float *x, const float *y, const float *z, uint32_t n, const float4 *planes, int nh,
-                        double thr, unsigned *counts, hipStream_t s)
-{
-  if (!n || nh <= 0) return;
-  hipLaunchKernelGGL(k_plane_count, dim3(64, nh), dim3(256), 0, s, x, y, z, n, planes, thr, counts);
-}
-
-void launch_plane_mask(const float *x, const float *y, const float *z, uint32_t n, float4 pl, double thr,
-                       uint8_t *mask, hipStream_t s)
-{
-  if (!n) return;
-  const uint32_t blocks = (uint32_t)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
-  hipLaunchKernelGGL(k_plane_mask, dim3(blocks), dim3(256), 0, s, x, y, z, n, pl, thr, mask);
-}
-
-// gather x/y/z[idx[i]] -> compact arrays
-__global__ void __launch_bounds__(256) k_gather_xyz(const float *__restrict__ x, const float *__restrict__ y,
-                                                    const float *__restrict__ z, const int32_t *__restrict__ idx,
-                                                    int32_t n, float *__restrict__ ox, float *__restrict__ oy,
-                                                    float *__restrict__ oz)
-{
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  const int j = idx[i];
-  ox[i] = x[j];
-  oy[i] = y[j];
-  oz[i] = z[j];
-}
-
-void launch_gather_xyz(const float *x, const float *y, const float *z, const int32_t *idx, int32_t n, float *ox,
-                       float *oy, float *oz, hipStream_t s)
-{
-  if (n <= 0) return;
-  hipLaunchKernelGGL(k_gather_xyz, dim3((n + 255) / 256), dim3(256), 0, s, x, y, z, idx, n, ox, oy, oz);
+  if (n_max <= 0) return;
+  hipLaunchKernelGGL(k_radius_count, dim3((n_max + 255) / 256), dim3(256), 0, s, x, y, z, seg_of, seg_start, n_max, n_dev,
+                     r2f, min_pts, keep);
 }
 
 }  // namespace gv

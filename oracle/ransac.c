@@ -13,13 +13,15 @@
  *     SampleConsensusModelPlane::computeModelCoefficients / isSampleGood (fp32);
  *   - inlier iff |n.p + d| < threshold (fp32 distance vs fp64 threshold), best = most
  *     inliers, first wins ties;
- *   - refinement: centroid + covariance of the inliers in fp64, cloud order; normal =
- *     eigenvector of the smallest eigenvalue (cyclic Jacobi), d = -n.centroid; the final
- *     inlier set is re-selected with the refined coefficients.
+ *   - refinement: centroid + covariance of the inliers in fp64; every sum is taken by a fixed
+ *     64-ary tree over the cloud order (below), so that a parallel implementation rounds the
+ *     same way as this one; normal = eigenvector of the smallest eigenvalue (cyclic Jacobi),
+ *     d = -n.centroid; the final inlier set is re-selected with the refined coefficients.
  */
 #include "gv_oracle.h"
 
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 static uint64_t sm64(uint64_t z)
@@ -99,24 +101,57 @@ void gvo_smallest_eigenvector3(const double cov[6], double v[3])
   v[0] = n[0] * sg; v[1] = n[1] * sg; v[2] = n[2] * sg;
 }
 
-/* refined plane from the inliers of `coeff` (cloud order, fp64); returns inlier count */
+/* Sum of v[0..n) by the 64-ary tree of the definition: groups of 64 consecutive values (the last one padded
+ * with +0.0) are reduced by the butterfly  t[i] += t[i + off], off = 32, 16, 8, 4, 2, 1;  the group sums form
+ * the next level, until one value is left (at least one level is always taken).  v is overwritten. */
+static double tree_sum64(double *v, size_t n)
+{
+  if (n == 0) return 0.0;
+  do {
+    const size_t groups = (n + 63) / 64;
+    for (size_t g = 0; g < groups; ++g) {
+      double t[64];
+      for (int i = 0; i < 64; ++i) t[i] = (g * 64 + (size_t)i < n) ? v[g * 64 + (size_t)i] : 0.0;
+      for (int off = 32; off > 0; off >>= 1)
+        for (int i = 0; i < off; ++i) t[i] = t[i] + t[i + off];
+      v[g] = t[0];
+    }
+    n = groups;
+  } while (n > 1);
+  return v[0];
+}
+
+/* refined plane from the inliers of `coeff` (fp64, tree sums over the cloud order: a non-inlier
+ * contributes +0.0); returns inlier count */
 size_t gvo_refine_plane(const float *x, const float *y, const float *z, size_t n, const float coeff[4],
                         double thr, float refined[4])
 {
-  double sx = 0, sy = 0, sz = 0;
-  size_t m = 0;
-  for (size_t i = 0; i < n; ++i)
-    if (is_inlier(coeff, x[i], y[i], z[i], thr)) { sx += x[i]; sy += y[i]; sz += z[i]; ++m; }
   memcpy(refined, coeff, 4 * sizeof(float));
-  if (m < 3) return m;
-  const double cx = sx / (double)m, cy = sy / (double)m, cz = sz / (double)m;
-  double cov[6] = {0, 0, 0, 0, 0, 0};
-  for (size_t i = 0; i < n; ++i)
-    if (is_inlier(coeff, x[i], y[i], z[i], thr)) {
-      const double dx = x[i] - cx, dy = y[i] - cy, dz = z[i] - cz;
-      cov[0] += dx * dx; cov[1] += dx * dy; cov[2] += dx * dz;
-      cov[3] += dy * dy; cov[4] += dy * dz; cov[5] += dz * dz;
+  double *buf = (double *)malloc((n ? n : 1) * sizeof(double));
+  if (!buf) return 0;
+  size_t m = 0;
+  for (size_t i = 0; i < n; ++i) m += (size_t)is_inlier(coeff, x[i], y[i], z[i], thr);
+  if (m < 3) { free(buf); return m; }
+  double s[3];
+  const float *src[3] = {x, y, z};
+  for (int k = 0; k < 3; ++k) {
+    for (size_t i = 0; i < n; ++i) buf[i] = is_inlier(coeff, x[i], y[i], z[i], thr) ? (double)src[k][i] : 0.0;
+    s[k] = tree_sum64(buf, n);
+  }
+  const double cx = s[0] / (double)m, cy = s[1] / (double)m, cz = s[2] / (double)m;
+  double cov[6];
+  for (int k = 0; k < 6; ++k) {
+    for (size_t i = 0; i < n; ++i) {
+      double t = 0.0;
+      if (is_inlier(coeff, x[i], y[i], z[i], thr)) {
+        const double dx = x[i] - cx, dy = y[i] - cy, dz = z[i] - cz;
+        t = (k == 0) ? dx * dx : (k == 1) ? dx * dy : (k == 2) ? dx * dz : (k == 3) ? dy * dy : (k == 4) ? dy * dz : dz * dz;
+      }
+      buf[i] = t;
     }
+    cov[k] = tree_sum64(buf, n);
+  }
+  free(buf);
   double nv[3];
   gvo_smallest_eigenvector3(cov, nv);
   refined[0] = (float)nv[0]; refined[1] = (float)nv[1]; refined[2] = (float)nv[2];
