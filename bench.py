@@ -217,9 +217,9 @@ def leg_with_h2d(gvamd, synth, g, tfs, config, flags, local_rank, steps):
     t_host = time.perf_counter() - t0   # host time to enqueue everything (no wait inside the loop)
     h.synchronize()
     dt = time.perf_counter() - t0
-    # copy rate alone: the same uploads without frames, one at a time (an unthrottled burst of hundreds of
-    # 12 MB copies makes the runtime fall back to a slower path: measured 27 GB/s instead of 53)
-    ncopy = 60
+    # copy rate alone: the same uploads without frames, in bursts of 8 (one copy at a time lets the idle device
+    # clock down between copies -- 11 GB/s; hundreds queued at once push the runtime onto a slower path -- 27 GB/s)
+    ncopy = 64
     t_host_c = 0.0
     t1 = time.perf_counter()
     for f in range(ncopy):
@@ -227,7 +227,8 @@ def leg_with_h2d(gvamd, synth, g, tfs, config, flags, local_rank, steps):
         tc0 = time.perf_counter()
         h.upload_xyz_async(px, py, pz)
         t_host_c += time.perf_counter() - tc0
-        h.upload_wait()
+        if f % 8 == 7:
+            h.upload_wait()
     dtc = time.perf_counter() - t1
     h.close()
     pins = None
