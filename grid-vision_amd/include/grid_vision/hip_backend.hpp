@@ -16,6 +16,7 @@
 #include <stdexcept>
 #include <string>
 #include <tuple>
+#include <cstring>
 #include <vector>
 
 #include "../../../include/gridvision_hip.h"
@@ -54,7 +55,12 @@ public:
   {
     gv::check(gv_create(&h_, grid_x, grid_y, resolution, &cam, device), nullptr, "gv_create");
   }
-  ~GridVisionContext() { if (h_) gv_destroy(h_); }
+  ~GridVisionContext()
+  {
+    if (h_) gv_destroy(h_);
+    for (auto &st : stage_)
+      if (st.p) gv_host_free(st.p);
+  }
   GridVisionContext(const GridVisionContext &) = delete;
   GridVisionContext &operator=(const GridVisionContext &) = delete;
   gv_handle handle() const { return h_; }
@@ -76,9 +82,45 @@ public:
     gv::check(gv_cloud_upload_pointcloud2(h_, data, n, point_step, ox, oy, oz), h_, "gv_cloud_upload_pointcloud2");
     n_ = n;
   }
+  // Streaming form: the copy of the next cloud is enqueued on the handle's copy stream and overlaps the frames in
+  // flight (two resident clouds alternate).  The ROS message is released when the callback returns, so the
+  // bytes are staged in the context's own pinned buffers first (two, alternating); the host never waits for the
+  // device here.
+  void setCloudPointCloud2Async(const uint8_t *data, size_t n, uint32_t point_step, uint32_t ox, uint32_t oy, uint32_t oz)
+  {
+    const size_t bytes = n * (size_t)point_step;
+    Staging &st = stage_[flip_ ^= 1];
+    if (bytes > st.cap) {
+      gv::check(gv_cloud_upload_wait(h_), h_, "gv_cloud_upload_wait");   // the old buffer may still be in flight
+      if (st.p) gv_host_free(st.p);
+      st.p = nullptr;
+      gv::check(gv_host_alloc(&st.p, bytes + bytes / 8 + 4096), nullptr, "gv_host_alloc");
+      st.cap = bytes + bytes / 8 + 4096;
+    }
+    // (with two buffers in turn, the copy that last read this one was enqueued two clouds ago; at the node's
+    //  20 Hz it has long finished -- a faster producer calls gv_cloud_upload_wait here)
+    std::memcpy(st.p, data, bytes);
+    gv::check(gv_cloud_upload_pointcloud2_async(h_, static_cast<const uint8_t *>(st.p), n, point_step, ox, oy, oz), h_,
+              "gv_cloud_upload_pointcloud2_async");
+    n_ = n;
+  }
+  // the fused frame without a host wait (gv_frame_set_detections + gv_frame_enqueue); results through
+  // occupancyGridAsync / gv_synchronize
+  void enqueueFrame(const gv_frame_desc &d)
+  {
+    gv::check(gv_frame_set_detections_async(h_, &d), h_, "gv_frame_set_detections_async");
+    gv::check(gv_frame_enqueue(h_), h_, "gv_frame_enqueue");
+  }
+  void synchronize() { gv::check(gv_synchronize(h_), h_, "gv_synchronize"); }
   size_t cloudSize() const { return n_; }
 
 private:
+  struct Staging {
+    void *p = nullptr;
+    size_t cap = 0;
+  };
+  Staging stage_[2];
+  int flip_ = 0;
   gv_handle h_ = nullptr;
   size_t n_ = 0;
 };

@@ -94,8 +94,9 @@ private:
       if (f.name == "y") oy = f.offset;
       if (f.name == "z") oz = f.offset;
     }
-    // bytes go straight to the device; no pcl::fromROSMsg AoS copy
-    ctx_->setCloudPointCloud2(msg.data.data(), static_cast<size_t>(msg.width) * msg.height, msg.point_step, ox, oy, oz);
+    // bytes go straight to the device (no pcl::fromROSMsg AoS copy), asynchronously: the copy overlaps the frame
+    // the timer callback may still have in flight, and the de-interleave runs on the device
+    ctx_->setCloudPointCloud2Async(msg.data.data(), static_cast<size_t>(msg.width) * msg.height, msg.point_step, ox, oy, oz);
     have_cloud_ = true;
   }
 
