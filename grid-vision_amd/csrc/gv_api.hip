@@ -112,9 +112,6 @@ struct gv_context {
   bool force_simple = false;                // GV_RAY_IMPL=simple
   int env_reorder = 1;                      // GV_SECTOR_REORDER=0: workgroups in natural (octant, sector) order
   size_t stat_slots = 1;                    // ray statistics slots written by the last frame
-  int32_t sector_wgs = 512;                 // persistent sector workgroups: 2 per CU (GV_SECTOR_WGS)
-  unsigned *sec_queue = nullptr;            // two alternating task counters of the sector kernel
-  uint32_t sec_launches = 0;
   int32_t env_log2s_oct[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // GV_LOG2S_OCT="a,b,..." per octant index (sweeps)
   int32_t env_flat_k = 8;                   // GV_FLAT_K: exact-cell : marched-cell cost ratio (0 = always march)
   int32_t env_log2s = 0, env_cap = 0, env_log2m = 0;     // GV_LOG2S / GV_CAP / GV_LOG2M (sweeps)
@@ -543,7 +540,6 @@ int fill_sector_args(gv_context *h, SectorArgs &sa, int p)
   sa.stats = h->x_stats[p];
   sa.wg_first = 0;
   sa.wg_stride = 1;
-  sa.max_wgs = h->sector_wgs;
   h->stat_slots = (size_t)sa.wg_base[8];
   return GV_OK;
 }
@@ -661,12 +657,6 @@ int enqueue_sectors(gv_context *h, int p, int first, int stride, hipStream_t s)
   if (rc) return rc;
   sa.wg_first = first;
   sa.wg_stride = stride;
-  if (first >= (int)sa.wg_base[8]) return GV_OK;   // more ranks than sectors: nothing to run (and no counter consumed)
-  // the two task counters alternate from launch to launch: each kernel zeroes the one its successor uses
-  // (sector kernels of one handle are stream ordered: stream B when pipelined, stream A otherwise, a drain between)
-  sa.queue = h->sec_queue + (h->sec_launches & 1u);
-  sa.queue_next = h->sec_queue + ((h->sec_launches + 1u) & 1u);
-  h->sec_launches++;
   launch_ray_sectors(sa, s);
   GV_HIP(hipGetLastError());
   return GV_OK;
@@ -1152,14 +1142,6 @@ int gv_create(gv_handle *out, uint8_t grid_x, uint8_t grid_y, double resolution,
       GV_C(hipMalloc(reinterpret_cast<void **>(&h->bin_total[k]), (size_t)h->n_tiles * sizeof(uint32_t)));
       GV_C(hipMemsetAsync(h->bin_total[k], 0, (size_t)h->n_tiles * sizeof(uint32_t), h->stream));
     }
-    GV_C(hipMalloc(reinterpret_cast<void **>(&h->sec_queue), 2 * sizeof(unsigned)));
-    GV_C(hipMemsetAsync(h->sec_queue, 0, 2 * sizeof(unsigned), h->stream));
-    {
-      hipDeviceProp_t prop{};
-      if (hipGetDeviceProperties(&prop, h->device) == hipSuccess && prop.multiProcessorCount > 0)
-        h->sector_wgs = 2 * prop.multiProcessorCount;   // 112 VGPRs x 8 waves and ~53 KB of LDS: two workgroups per CU
-      if (const char *e = std::getenv("GV_SECTOR_WGS")) h->sector_wgs = std::max(1, std::atoi(e));
-    }
     GV_C(hipMalloc(reinterpret_cast<void **>(&h->bin_done), (size_t)h->n_tiles * sizeof(uint32_t)));
     GV_C(hipMemsetAsync(h->bin_done, 0, (size_t)h->n_tiles * sizeof(uint32_t), h->stream));
   } else {
@@ -1190,7 +1172,7 @@ int gv_destroy(gv_handle h)
   for (hipStream_t s : {h->stream_copy, h->stream, h->stream2, h->stream3})
     if (s) (void)hipStreamSynchronize(s);
   if (h->comm) { ncclCommDestroy(h->comm); h->comm = nullptr; }
-  void *bufs[] = {h->log_odds, h->occupancy, h->occ_i8, h->hits, h->clip_end, h->miss8, h->sh_xchg, h->sec_queue, h->ray_list, h->ray_count, h->scratch_i32,
+  void *bufs[] = {h->log_odds, h->occupancy, h->occ_i8, h->hits, h->clip_end, h->miss8, h->sh_xchg, h->ray_list, h->ray_count, h->scratch_i32,
                   h->bin_keys, h->bin_tab, h->bin_total[0], h->bin_total[1], h->bin_done, h->bin_scratch,
                   h->tx, h->ty, h->tz, h->cell_idx, h->bbox_id, h->d_vout, h->d_pts, h->knn_partial, h->d_depths,
                   h->d_knn_d2, h->d_idx, h->d_segof, h->d_segstart, h->gx, h->gy, h->gz, h->d_keep, h->d_planes,

@@ -140,14 +140,15 @@ __host__ __device__ inline SectorLds sector_lds_layout(int cap, int marks_words,
   return L;
 }
 
-// One sector of one octant: `bid` is its position in the dispatch order (longest wedges and the
-// heavy "gap" sectors first).  Runs on a whole 512-thread workgroup; every exit is workgroup uniform.
 template <int CH>
-__device__ __forceinline__ void sector_task(const SectorArgs &A, const int bid, unsigned char *smem)
+__global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(SectorArgs A)
 {
   constexpr int NT = kSecThreads;
+  extern __shared__ __align__(16) unsigned char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
+  // position in the dispatch order: a multi-GPU rank runs every wg_stride-th workgroup
+  const int bid = A.wg_first + (int)blockIdx.x * A.wg_stride;
   // Dispatch order (workgroups start roughly in blockIdx order and the launch is ~2 rounds deep):
   // octants with the longest wedges first, and inside an octant the sectors next to the slopes
   // 0, 1/2, 1 first (they run longest).  Every octant has its own sector count: a short wedge
@@ -844,30 +845,6 @@ __device__ __forceinline__ void sector_task(const SectorArgs &A, const int bid, 
   }
 }
 
-// Persistent workgroups over a queue of sector tasks.  A sector's cost varies 3x (28 k .. 69 k cycles at
-// config 3) and only two workgroups fit a CU, so one workgroup per sector ran as two rounds: 512 resident
-// sectors, then the 64 left over started when the first ones retired and alone doubled the kernel's span.
-// Here as many workgroups as the chip holds at once each take the next task (dispatch order = expected
-// cost, descending) until the queue is empty: span = total work / resident workgroups + one task, whatever
-// the sector count.  No workgroup waits for another: each leaves when its fetch runs past the last task.
-template <int CH>
-__global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(SectorArgs A)
-{
-  extern __shared__ __align__(16) unsigned char smem[];
-  __shared__ int s_task;
-  const int ntasks = ((int)A.wg_base[8] - A.wg_first + A.wg_stride - 1) / A.wg_stride;
-  // the queue counter of the NEXT launch on this stream (the two alternate; launches are stream ordered)
-  if (blockIdx.x == 0 && threadIdx.x == 0) *A.queue_next = 0u;
-  for (;;) {
-    if (threadIdx.x == 0) s_task = (int)atomicAdd(A.queue, 1u);
-    __syncthreads();
-    const int task = s_task;
-    if (task >= ntasks) break;
-    sector_task<CH>(A, A.wg_first + task * A.wg_stride, smem);
-    __syncthreads();   // LDS of the finished task is free; s_task may be rewritten
-  }
-}
-
 size_t sector_lds_bytes(int cap, int marks_words, int log2m)
 {
   return sector_lds_layout(cap, marks_words, log2m).total;
@@ -881,8 +858,7 @@ void launch_ray_sectors(const SectorArgs &a, hipStream_t s)
   // every wedge column lives in a register slot of one thread: CH * 512 >= imax
   const int total = a.wg_base[8];
   if (a.wg_first >= total) return;
-  const int ntasks = (total - a.wg_first + a.wg_stride - 1) / a.wg_stride;
-  const int grid = std::max(1, std::min(ntasks, a.max_wgs));   // persistent: no more than the chip holds at once
+  const int grid = (total - a.wg_first + a.wg_stride - 1) / a.wg_stride;
   if (imax <= 4 * kSecThreads)
     hipLaunchKernelGGL(k_ray_sectors<4>, dim3(grid), dim3(kSecThreads), lds, s, a);
   else if (imax <= 8 * kSecThreads)
