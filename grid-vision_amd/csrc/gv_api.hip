@@ -113,6 +113,7 @@ struct gv_context {
   int env_reorder = 1;                      // GV_SECTOR_REORDER=0: workgroups in natural (octant, sector) order
   size_t stat_slots = 1;                    // ray statistics slots written by the last frame
   int32_t env_log2s_oct[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // GV_LOG2S_OCT="a,b,..." per octant index (sweeps)
+  uint32_t env_march_limit = 64u * 512u;     // GV_MARCH_LIMIT
   int32_t env_flat_k = 8;                   // GV_FLAT_K: exact-cell : marched-cell cost ratio (0 = always march)
   int32_t env_log2s = 0, env_cap = 0, env_log2m = 0;     // GV_LOG2S / GV_CAP / GV_LOG2M (sweeps)
 
@@ -520,6 +521,7 @@ int fill_sector_args(gv_context *h, SectorArgs &sa, int p)
   sa.dbg = h->d_dbg;
 #endif
   sa.flat_k = h->env_flat_k;
+  sa.march_limit = h->env_march_limit;
   sa.log2m = h->env_log2m > 0 ? h->env_log2m : 9;
   sa.marks_words = (imax + 3) & ~1;   // one word per wedge column, 0..imax
   std::stable_sort(ord, ord + 8, [&](int a, int b) { return len[a] > len[b]; });
@@ -1089,6 +1091,7 @@ int gv_create(gv_handle *out, uint8_t grid_x, uint8_t grid_y, double resolution,
     if (const char *e = std::getenv("GV_SECTOR_REORDER")) h->env_reorder = std::atoi(e) != 0;
     if (const char *e = std::getenv("GV_CAP")) h->env_cap = std::atoi(e);
     if (const char *e = std::getenv("GV_FLAT_K")) h->env_flat_k = std::max(0, std::atoi(e));
+    if (const char *e = std::getenv("GV_MARCH_LIMIT")) h->env_march_limit = (uint32_t)std::max(0, std::atoi(e));
     if (const char *e = std::getenv("GV_LOG2M")) h->env_log2m = std::min(9, std::max(4, std::atoi(e)));
 #ifdef GV_DIAG
     if (const char *e = std::getenv("GV_ABLATE")) h->env_ablate = std::atoi(e);

@@ -122,9 +122,9 @@ __host__ __device__ inline SectorLds sector_lds_layout(int cap, int marks_words,
   size_t o = 0;
   L.abv = o;    o += (size_t)cap * 4;
   L.marks = o;  o += (size_t)marks_words * 4;
-  L.cnt = o;    o += M * 4;
+  L.cnt = o;    o += M * 4;      // bucket counts, then placement cursors, then (with bmax32 behind it) the long-ray list: 2M entries
+  L.bmax32 = o; o += M * 4;      // dead once the range-max tables are built
   L.bstart = o; o += (M + 2) * 4;
-  L.bmax32 = o; o += M * 4;
   // union: {staging list: raw ends + their bucket ids} is dead once the ends are placed,
   // which is before {range-max tables} are written
   L.un = o;
@@ -635,7 +635,7 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
           if (lane == 0) base = atomicAdd(&s_nlong, (unsigned)__popcll(bm));
           base = __shfl(base, 0);
           const unsigned pos = base + (unsigned)__popcll(bm & ((1ull << lane) - 1ull));
-          if (lng && pos < (unsigned)M) cnt[pos] = p;
+          if (lng && pos < 2u * (unsigned)M) cnt[pos] = p;   // the list runs on into bmax32 (dead by now)
         }
       }
       const unsigned r = wave_sum(st);
@@ -645,7 +645,7 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
 #pragma unroll
       for (int wv = 0; wv < NT / 64; ++wv) tail_steps += s_wsum[wv];
       const unsigned nlong = s_nlong;
-      march_tail = (nlong <= (unsigned)M) && (tail_steps <= 64u * NT);
+      march_tail = (nlong <= 2u * (unsigned)M) && (tail_steps <= A.march_limit);
       if (march_tail && A.flat_k > 0) {
         // marching costs ~ one wavefront step per 64 ray cells (+ a partial step per ray); evaluating every
         // cell beyond T exactly costs ~ flat_k times that per cell: take the cheaper one
