@@ -578,7 +578,7 @@ int check_frame_flags(const gv_context *h, uint32_t fl)
 // partition + tile histogram of points [lo, lo + n) of the current cloud: hits[] (or not) and the end
 // bitmaps of buffer set p; zeroes the set's free-cell bitmaps.  ev_* are stage-timing events or null.
 int enqueue_binning(gv_context *h, const DetSet &D, int p, size_t lo, size_t n, bool keep_cell, bool do_ray,
-                    bool do_bbox, bool write_hits, hipStream_t s, hipEvent_t ev_points)
+                    bool do_bbox, bool write_hits, hipStream_t s, hipEvent_t ev_points, Rect *fold_rects = nullptr)
 {
   const uint32_t chunk = bin_chunk_for(n);
   const uint32_t n_wg = (uint32_t)((n + chunk - 1) / chunk);
@@ -606,6 +606,11 @@ int enqueue_binning(gv_context *h, const DetSet &D, int p, size_t lo, size_t n, 
   a.keys = h->bin_keys;
   a.tab = h->bin_tab;
   a.tile_total = h->bin_total[h->bin_parity];
+  if (fold_rects) {   // the frame's rectangles ride the partition launch
+    a.rect_poses = D.poses;
+    a.n_rect_poses = D.n_poses;
+    a.rects_out = fold_rects;
+  }
 #ifdef GV_DIAG
   a.dbg = h->d_bin_dbg[0];
 #endif
@@ -719,10 +724,12 @@ int enqueue_frame_tiles(gv_context *h, bool pipelined, bool stage_events, bool s
   if (h->cloud_wait) { GV_HIP(hipStreamWaitEvent(sA, CS.ready, 0)); h->cloud_wait = false; }
   if (stage_events) GV_HIP(hipEventRecord(h->ev[0], sA));
 
-  // --- detections -> rectangles
+  // --- detections -> rectangles.  Base-frame poses of a binning frame ride the partition launch (one
+  // extra workgroup) instead of a launch of their own; network outputs go through the vision kernels.
   Rect *rects = h->x_rects[p];
+  const bool fold_rects = do_bin && !(fl & GV_FRAME_VISION_ORIENT) && D.n_poses > 0;
   mark(sA);
-  const int32_t n_rects = enqueue_rects(h, D, rects, sA);
+  const int32_t n_rects = fold_rects ? D.n_poses : enqueue_rects(h, D, rects, sA);
   mark(sA);
   if (stage_events) GV_HIP(hipEventRecord(h->ev[kStageDetections + 1], sA));
 
@@ -730,7 +737,7 @@ int enqueue_frame_tiles(gv_context *h, bool pipelined, bool stage_events, bool s
   mark(sA);
   if (do_bin) {
     if ((rc = enqueue_binning(h, D, p, 0, h->n, keep_cell, do_ray, do_bbox, true, sA,
-                              stage_events ? h->ev[kStagePoints + 1] : nullptr)))
+                              stage_events ? h->ev[kStagePoints + 1] : nullptr, fold_rects ? rects : nullptr)))
       return rc;
   } else {
     if (do_bbox) {

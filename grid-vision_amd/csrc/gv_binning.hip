@@ -60,6 +60,12 @@ template <bool RAY, bool BBOX, bool KEEPCELL>
 __global__ void __launch_bounds__(kPartThreads, 8) k_bin_partition(BinArgs a)
 {
   extern __shared__ __align__(16) unsigned char smem[];
+  if (blockIdx.x >= a.n_wg) {
+    // one extra workgroup: the frame's base-frame poses -> index rectangles for the grid pass (A8/A9,
+    // src/occupancy_grid.cpp:79-90,147-172).  Rides this launch instead of costing one of its own.
+    for (int q = threadIdx.x; q < a.n_rect_poses; q += kPartThreads) a.rects_out[q] = rect_from_pose(a.g, a.rect_poses[q]);
+    return;
+  }
   const int T = a.n_tiles;
   unsigned *staged = reinterpret_cast<unsigned *>(smem);                      // [chunk] tile << 16 | key
   unsigned *hist = staged + a.chunk;                                          // [T] counts, then cursors
@@ -488,10 +494,11 @@ bool bin_bbox_fits(int nb, const BBoxTest &bt) { return bin_bbox_lds((nb + 3) & 
 
 void launch_bin_partition(const BinArgs &a, hipStream_t s)
 {
-  if (a.n_wg == 0) return;
+  const uint32_t grid = a.n_wg + (a.n_rect_poses > 0 ? 1u : 0u);
+  if (grid == 0) return;
   const size_t lds = bin_partition_lds(a.chunk, a.n_tiles) + (a.do_bbox ? bin_bbox_lds(a.nb_pad, a.bt) : 0);
   const bool keep = a.cell_idx != nullptr;
-#define GV_BP(R, X, K) hipLaunchKernelGGL((k_bin_partition<R, X, K>), dim3(a.n_wg), dim3(kPartThreads), lds, s, a)
+#define GV_BP(R, X, K) hipLaunchKernelGGL((k_bin_partition<R, X, K>), dim3(grid), dim3(kPartThreads), lds, s, a)
   if (a.do_ray && a.do_bbox && keep) GV_BP(true, true, true);
   else if (a.do_ray && a.do_bbox) GV_BP(true, true, false);
   else if (a.do_ray && keep) GV_BP(true, false, true);

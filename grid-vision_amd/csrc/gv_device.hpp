@@ -124,6 +124,38 @@ __device__ __forceinline__ double krow(const double *k, int r, double x, double 
 }
 
 
+// ------------------------------------------------------------- rectangles --
+// updateMap(GridMap&, vector<LShapePose>) corners (src/occupancy_grid.cpp:79-90) and the
+// index half of updateGridCellsFast (:147-172): any corner outside -> box skipped.
+__device__ __forceinline__ Rect rect_from_corners(const GridParams &g, const double c[8])
+{
+  Rect r;
+  r.valid = 1;
+  int minx = 0, miny = 0, maxx = 0, maxy = 0;
+  for (int i = 0; i < 4; ++i) {
+    int ix, iy;
+    if (!get_index(g, c[2 * i], c[2 * i + 1], ix, iy)) { r.valid = 0; break; }
+    if (i == 0) { minx = maxx = ix; miny = maxy = iy; }
+    else {
+      minx = min(minx, ix); miny = min(miny, iy);
+      maxx = max(maxx, ix); maxy = max(maxy, iy);
+    }
+  }
+  r.x0 = minx; r.y0 = miny; r.x1 = maxx; r.y1 = maxy;
+  return r;
+}
+
+// rectangle of one base-frame pose: corners {left_back, left_front, right_front, right_back} (:79-90)
+__device__ __forceinline__ Rect rect_from_pose(const GridParams &g, const gv_lshape_pose &p)
+{
+  const double hx = p.length / 2.0, hy = p.width / 2.0;
+  const double c[8] = {p.px - hx, p.py - hy, p.px + hx, p.py - hy, p.px + hx, p.py + hy, p.px - hx, p.py + hy};
+  Rect r = rect_from_corners(g, c);
+  // a pose the vision kernel marked invalid carries length < 0
+  if (!(p.length >= 0.0)) r.valid = 0;
+  return r;
+}
+
 // extractCloudPerBBox (src/cloud_detections.cpp:264-288) for one camera-frame point: index of
 // the first bbox containing its projection, or -1.  The reference compares (double)u against
 // the double bounds; bbox_f holds the float thresholds with the identical truth table (host:

@@ -249,46 +249,19 @@ void launch_deinterleave(const uint8_t *data, uint32_t n, uint32_t point_step, u
 }
 
 // ------------------------------------------------------------- rectangles --
-// updateMap(GridMap&, vector<LShapePose>) corners (src/occupancy_grid.cpp:79-90) and the
-// index half of updateGridCellsFast (:147-172): any corner outside -> box skipped.
-__device__ __forceinline__ Rect rect_from_corners(const GridParams &g, const double c[8])
-{
-  Rect r;
-  r.valid = 1;
-  int minx = 0, miny = 0, maxx = 0, maxy = 0;
-  for (int i = 0; i < 4; ++i) {
-    int ix, iy;
-    if (!get_index(g, c[2 * i], c[2 * i + 1], ix, iy)) { r.valid = 0; break; }
-    if (i == 0) { minx = maxx = ix; miny = maxy = iy; }
-    else {
-      minx = min(minx, ix); miny = min(miny, iy);
-      maxx = max(maxx, ix); maxy = max(maxy, iy);
-    }
-  }
-  r.x0 = minx; r.y0 = miny; r.x1 = maxx; r.y1 = maxy;
-  return r;
-}
-
 __global__ void k_rects_from_poses(const gv_lshape_pose *__restrict__ poses, int32_t n, GridParams g,
                                    bool from_cam, Xform64 bc, Rect *__restrict__ rects)
 {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const gv_lshape_pose p = poses[i];
-  double px = p.px, py = p.py;
+  gv_lshape_pose p = poses[i];
   if (from_cam) {
     // tf2::doTransform(Pose): position = basis * v + origin  (grid_vision_node.cpp:370-374)
     const double vx = p.px, vy = p.py, vz = p.pz;
-    px = ((bc.b[0] * vx + bc.b[1] * vy) + bc.b[2] * vz) + bc.o[0];
-    py = ((bc.b[3] * vx + bc.b[4] * vy) + bc.b[5] * vz) + bc.o[1];
+    p.px = ((bc.b[0] * vx + bc.b[1] * vy) + bc.b[2] * vz) + bc.o[0];
+    p.py = ((bc.b[3] * vx + bc.b[4] * vy) + bc.b[5] * vz) + bc.o[1];
   }
-  const double hx = p.length / 2.0, hy = p.width / 2.0;
-  // order {left_back, left_front, right_front, right_back}  (:89-90)
-  const double c[8] = {px - hx, py - hy, px + hx, py - hy, px + hx, py + hy, px - hx, py + hy};
-  Rect r = rect_from_corners(g, c);
-  // a pose the vision kernel marked invalid carries length < 0
-  if (!(p.length >= 0.0)) r.valid = 0;
-  rects[i] = r;
+  rects[i] = rect_from_pose(g, p);
 }
 
 void launch_rects_from_poses(const gv_lshape_pose *poses, int32_t n, const GridParams &g, bool from_cam,

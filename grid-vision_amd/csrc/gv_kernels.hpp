@@ -103,6 +103,9 @@ struct BinArgs {
   uint16_t *keys;          // [n_wg][chunk]  keys of a chunk grouped by tile
   uint16_t *tab;           // [n_wg][n_tiles + 1]  start of every tile's run inside the chunk; [n_tiles] = count
   uint32_t *tile_total;    // [n_tiles]  keys per tile over all chunks (zero on entry)
+  const gv_lshape_pose *rect_poses;   // optional rider: n_rect_poses base-frame poses -> rects_out (one extra workgroup)
+  int32_t n_rect_poses;
+  Rect *rects_out;
   unsigned long long *dbg; // diagnostic build: 16 clock stamps per workgroup (null in production)
 };
 constexpr size_t kBinBBoxLdsMax = 24 * 1024;   // LDS the partition kernel may spend on the bbox-test tables
