@@ -217,18 +217,27 @@ def leg_with_h2d(gvamd, synth, g, tfs, config, flags, local_rank, steps):
     t_host = time.perf_counter() - t0   # host time to enqueue everything (no wait inside the loop)
     h.synchronize()
     dt = time.perf_counter() - t0
-    # copy rate alone: the same uploads without frames, in bursts of 8 (one copy at a time lets the idle device
-    # clock down between copies -- 11 GB/s; hundreds queued at once push the runtime onto a slower path -- 27 GB/s)
-    ncopy = 64
-    t_host_c = 0.0
-    t1 = time.perf_counter()
-    for f in range(ncopy):
+    # copy rate alone: the same streaming loop with a frame that does next to nothing (no binning, no ray stage, no
+    # bbox test: only the 14 us grid pass), so that the period is the copy engine's.  (Timing bare uploads is
+    # unreliable: one copy at a time lets the idle device clock down between copies -- 11 GB/s; unthrottled bursts
+    # block in the runtime -- 15..27 GB/s; the DMA itself takes 219 us per 12 MB, profiles/r02/h2d_notes.md.)
+    def copy_only(f):
         px, py, pz = pins[f % n_sets]
         tc0 = time.perf_counter()
         h.upload_xyz_async(px, py, pz)
-        t_host_c += time.perf_counter() - tc0
-        if f % 8 == 7:
-            h.upload_wait()
+        dtu = time.perf_counter() - tc0
+        h.set_detections_async(0)
+        h.enqueue_frame()
+        return dtu
+    for f in range(60):
+        copy_only(f)
+    h.synchronize()
+    ncopy = 200
+    t_host_c = 0.0
+    t1 = time.perf_counter()
+    for f in range(ncopy):
+        t_host_c += copy_only(f)
+    h.synchronize()
     dtc = time.perf_counter() - t1
     h.close()
     pins = None
