@@ -428,7 +428,8 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
       if (wv < wave) slot += s_wsum[wv];
       n += s_wsum[wv];
     }
-    // append: packed end + its slope bucket; bucket counts on the fly
+    // append the packed ends in scan order (a lane holds 0..32 ends of its columns: only the cheap packing runs
+    // in this lane-unbalanced loop) ...
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
       if (!((rowmask >> c) & 1u) || !mine_w) continue;
@@ -440,12 +441,17 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
         const int t = __ffs(e) - 1;
         e &= e - 1;
         const int b = (oc.smin > 0) ? blo + t : bhi - t;
-        const int bk = bucket_of_end(a, b);
-        raw[slot] = pack_ab(a, b, (int)((vcs[c] >> t) & 1u));
-        bkt[slot] = (unsigned short)bk;
-        atomicAdd(&cnt[bk], 1u);
-        ++slot;
+        raw[slot++] = pack_ab(a, b, (int)((vcs[c] >> t) & 1u));
       }
+    }
+    __syncthreads();
+    // ... then their slope buckets (an integer division each) and the bucket counts over the dense list, one end
+    // per lane and step
+    for (unsigned k = tid; k < n; k += NT) {
+      const unsigned p = raw[k];
+      const int bk = bucket_of_end(ab_a(p), ab_b(p));
+      bkt[k] = (unsigned short)bk;
+      atomicAdd(&cnt[bk], 1u);
     }
     __syncthreads();
     stamp();   // 3: staged + counted
