@@ -18,8 +18,9 @@ using namespace gv;
 
 namespace {
 
-// One of the two resident clouds: frames read the current one on stream A while the copy stream
-// fills the other (cloudCallback / timerCallback overlap, src/grid_vision_node.cpp:103-106,108-244).
+// One of the three resident clouds: frames read the current one while the copy stream fills the next
+// (cloudCallback / timerCallback overlap, src/grid_vision_node.cpp:103-106,108-244).  Three, so that the
+// set being filled was last read two uploads ago: its readers have long finished in a streaming run.
 struct CloudSet {
   float *base = nullptr;        // one allocation of 3 * cap floats
   float *x = nullptr, *y = nullptr, *z = nullptr;   // base, base + n, base + 2n of the cloud it holds (SoA, back to back)
@@ -27,7 +28,8 @@ struct CloudSet {
   uint8_t *raw = nullptr;       // PointCloud2 bytes before the de-interleave
   size_t raw_cap = 0;
   hipEvent_t ready = nullptr;   // copy stream: upload complete
-  int release_set = -1;         // ev_build[release_set]: the last frame that reads this set has passed its points pass
+  int release_slot = -1;        // ev_fin[release_slot]: the last frame that reads this set (-1: none since it was filled)
+  uint32_t seen = ~0u;          // bit k: stream k has waited for `ready` (or the upload is known complete)
 };
 
 // Per-frame detection inputs (bboxes, poses / network outputs) and what the device derives from them.
@@ -48,24 +50,39 @@ struct DetSet {
   bool valid = false;           // a gv_frame_set_detections* call has filled this set
   uint8_t *stage = nullptr;     // pinned host copy of the caller's arrays (free to reuse on return)
   size_t stage_cap = 0;
-  hipEvent_t ready = nullptr;   // stream A: the set's last upload has left its staging block
+  hipEvent_t ready = nullptr;   // the set's last upload is complete (and has left its staging block)
+  uint32_t seen = ~0u;          // bit k: stream k (0 public, 1 / 2 the lanes) is ordered after the upload
+  int release_slot = -1, release_stream = 0;   // last frame that reads this set: ev_fin[release_slot]; its points pass ran on release_stream
 };
 
 }  // namespace
 
 struct gv_context {
-  static constexpr int kSets = 4;
+  // Frames in flight run on two LANES: frame f does partition, tile pass and sector stage back to back on
+  // the in-order stream of lane f % 2, then its grid pass on the PUBLIC stream behind one event.  No event
+  // sits between the stages on a lane (a barrier packet between two kernels costs ~6 us of queue time, back
+  // to back kernels of one queue follow each other without a gap), the grid passes are one in-order
+  // sequence by construction (the log-odds grid is one sequence of updates), and everything a frame
+  // produced is visible on the public stream right behind it.  Buffer sets 1..4 rotate with the frames
+  // (set 0: serial frames and standalone calls); a set is handed to frame f+4 once the HOST has seen
+  // frame f finish -- back-pressure on the caller, at most four frames in flight, instead of a barrier
+  // on a lane.  With the copy stream that makes the 4 hardware queues a process gets by default (a 5th
+  // stream shares a queue and serialises).  Measured on config 3: one in-order stream 12.0 k frames/s;
+  // one stream per STAGE with three events per frame (round 1) 14.4 k; two lanes with the grid pass on
+  // the lane behind a cross-lane wait 16.5 k; this layout 18.6 k; three / four lanes 15.4 / 14.3 k
+  // (tools/multi_handle.py).
+  static constexpr int kSets = 5;
+  static constexpr int kRing = 8;   // event rings: one slot per frame, reused every 8 frames
   int device = 0;
-  // A: detections, partition, tile histogram of frame f+1 (and every non-frame entry point);
-  // B: sector ray stage of frame f;  C: grid pass of frame f;  copy: H2D of the next cloud.  The detections of
-  // the next frame (one ~10 KB block) go up on stream A itself, in order between the frames that read them: no
-  // more streams than the 4 hardware queues a process gets by default (a 5th stream shares a queue with one of
-  // the others and serialises behind it: measured, 0.81 -> 0.71 of the copy bound)
   hipStream_t stream = nullptr, stream2 = nullptr, stream3 = nullptr, stream_copy = nullptr;
-  hipEvent_t ev_build[kSets]{}, ev_sec[kSets]{}, ev_fin[kSets]{};
-  hipEvent_t ev_join[3]{};
-  int n_sets = 3;                 // GV_PIPE_SETS (2..4): buffer sets the pipelined frames rotate through
-  // per-set buffers of the frames in flight: end bitmaps, rectangles, miss grids, ray statistics
+  hipStream_t streams[3]{};         // = {stream (public), stream2 (lane 0), stream3 (lane 1)}
+  hipEvent_t ev_sec[kRing]{};       // lane: partition, tile pass, sector stage of frame (slot) done
+  hipEvent_t ev_fin[kRing]{};       // public stream: grid pass of frame (slot) done => that frame and every earlier one are done
+  hipEvent_t ev_join = nullptr;     // copy stream -> public stream (gv_frame_fence)
+  uint64_t lane_frames = 0;         // lane frames enqueued so far: lane = n % 2, buffer set = 1 + n % 4
+  int set_fin_slot[kSets]{-1, -1, -1, -1, -1};   // ev_fin slot of the last frame that used the set
+  int last_fin_slot = -1;           // ev_fin slot of the most recently enqueued frame (-1: idle)
+  // per-set buffers of the frames in flight: end bitmaps, rectangles, free-cell bitmaps, ray statistics
   uint32_t *x_ends[kSets]{};      // one allocation per set: [hitN | clipN | hitT | clipT], ends_words in all
   uint32_t *x_hitN[kSets]{}, *x_clipN[kSets]{}, *x_hitT[kSets]{}, *x_clipT[kSets]{};
   uint32_t *x_free[kSets]{};      // [freeN | freeT]: free-cell bitmaps of the ray stage
@@ -75,10 +92,8 @@ struct gv_context {
   uint8_t *miss8 = nullptr;       // generic path only: byte miss grid of the literal march
   unsigned long long *x_stats[kSets]{};
   int last_set = 0;
-  int last_frame_set = -1;        // buffer set of the most recently enqueued frame (its ev_build marks "inputs consumed")
   uint64_t frame_no = 0;
-  int since_drain = 0;            // pipelined frames enqueued since every stream was last idle
-  bool pipe_busy = false;
+  bool pipe_busy = false;         // lane frames enqueued since the streams were last drained
   bool no_pipeline = false;       // GV_PIPELINE=0
 #ifdef GV_DIAG
   std::vector<hipEvent_t> *trace = nullptr;   // timing events around every pipelined kernel (gv_debug_pipeline_trace)
@@ -101,7 +116,8 @@ struct gv_context {
   float *log_odds = nullptr, *occupancy = nullptr;
   int8_t *occ_i8 = nullptr;
   // per-frame count grids
-  int32_t *hits = nullptr;                  // tile path: every cell written by every BIN frame
+  int32_t *hits_s[3]{};                     // per stream (public, lane 0, lane 1); tile path: every cell written by every BIN frame
+  int32_t *hits = nullptr;                  // = hits_s[stream of the last frame]
   uint8_t *clip_end = nullptr;              // generic path only
   uint32_t *ray_list = nullptr;
   uint32_t *ray_count = nullptr;            // [0] = number of list entries
@@ -119,22 +135,24 @@ struct gv_context {
 
   // tile-path binning (gv_binning.hip)
   int32_t tiles_x = 0, tiles_y = 0, n_tiles = 0;
-  uint16_t *bin_keys = nullptr, *bin_tab = nullptr;
+  uint16_t *bin_keys[3]{}, *bin_tab[3]{};   // per stream: partition(f+1) of one lane runs beside tiles(f) of the other
   size_t bin_keys_cap = 0, bin_tab_cap = 0;
-  uint32_t *bin_total[2] = {nullptr, nullptr};
-  uint32_t *bin_done = nullptr, *bin_scratch = nullptr;
+  uint32_t *bin_total[3][2]{};
+  uint32_t *bin_done[3]{}, *bin_scratch[3]{};
   size_t bin_slots = 0;
-  int bin_parity = 0;
+  int bin_parity[3]{};
 
   // resident clouds
-  CloudSet cloud[2];
+  CloudSet cloud[3];
   int cloud_cur = 0;
-  bool cloud_wait = false;                  // stream A has not yet waited for cloud[cloud_cur].ready
+  bool cloud_wait = false;                  // an asynchronous upload may still be in flight
   float *cx = nullptr, *cy = nullptr, *cz = nullptr;   // = cloud[cloud_cur]
   size_t n = 0;
   float *tx = nullptr, *ty = nullptr, *tz = nullptr;   // transformed copy (A1 read-back)
   size_t tcap = 0;
-  int32_t *cell_idx = nullptr;
+  int32_t *cell_idx_s[3]{};                 // per-point outputs, per stream (two frames in flight write them)
+  int16_t *bbox_id_s[3]{};
+  int32_t *cell_idx = nullptr;              // = *_s[stream of the last frame]
   int16_t *bbox_id = nullptr;
   size_t idx_cap = 0;
 
@@ -142,7 +160,8 @@ struct gv_context {
   DetSet det[3];
   int det_cur = 0;
   int32_t bt_tiles_x = 1, bt_tiles_y = 1;   // 16x16-pixel tiles of the image
-  VisionOut *d_vout = nullptr;
+  VisionOut *d_vout_s[3]{};
+  VisionOut *d_vout = nullptr;              // = d_vout_s[0]
   int32_t vout_cap = 0;
   double *d_pts = nullptr;
   int32_t pts_cap = 0;
@@ -219,8 +238,11 @@ int drain(gv_context *h)
   GV_HIP(hipStreamSynchronize(h->stream2));
   GV_HIP(hipStreamSynchronize(h->stream3));
   h->pipe_busy = false;
-  h->since_drain = 0;
+  h->last_fin_slot = -1;
+  for (int &q : h->set_fin_slot) q = -1;
   h->cloud_wait = false;
+  for (auto &c : h->cloud) { c.seen = ~0u; c.release_slot = -1; }   // every upload landed, every reader finished
+  for (auto &d : h->det) { d.seen = ~0u; d.release_slot = -1; }
   return GV_OK;
 }
 
@@ -241,10 +263,11 @@ int use_device(gv_context *h)
   return GV_OK;
 }
 
-// buffers whose size follows the cloud: per-point outputs and the binning scratch.  They live on
-// stream A only, so growing them needs the frames in flight to finish first (rare: the cloud grew).
+// buffers whose size follows the cloud: per-point outputs and the binning scratch, one of each per
+// buffer set.  Growing them needs the frames in flight to finish first (rare: the cloud grew).
 int ensure_point_buffers(gv_context *h, size_t n)
 {
+  const int nsets = sector_path(h) ? 3 : 1;   // per-stream copies
   const bool need_idx = n > h->idx_cap || !h->cell_idx;
   const uint32_t chunk = bin_chunk_for(n);
   const size_t n_wg = (n + chunk - 1) / chunk;
@@ -257,26 +280,43 @@ int ensure_point_buffers(gv_context *h, size_t n)
   if (rc) return rc;
   if (need_idx) {
     const size_t want = n + n / 8 + 1024;
-    if (h->cell_idx) GV_HIP(hipFree(h->cell_idx));
-    if (h->bbox_id) GV_HIP(hipFree(h->bbox_id));
+    h->idx_cap = 0;
     h->cell_idx = nullptr;
     h->bbox_id = nullptr;
-    h->idx_cap = 0;
-    GV_HIP(hipMalloc(reinterpret_cast<void **>(&h->cell_idx), want * sizeof(int32_t)));
-    GV_HIP(hipMalloc(reinterpret_cast<void **>(&h->bbox_id), want * sizeof(int16_t)));
+    for (int k = 0; k < nsets; ++k) {
+      if (h->cell_idx_s[k]) GV_HIP(hipFree(h->cell_idx_s[k]));
+      if (h->bbox_id_s[k]) GV_HIP(hipFree(h->bbox_id_s[k]));
+      h->cell_idx_s[k] = nullptr;
+      h->bbox_id_s[k] = nullptr;
+      GV_HIP(hipMalloc(reinterpret_cast<void **>(&h->cell_idx_s[k]), want * sizeof(int32_t)));
+      GV_HIP(hipMalloc(reinterpret_cast<void **>(&h->bbox_id_s[k]), want * sizeof(int16_t)));
+    }
+    h->cell_idx = h->cell_idx_s[0];
+    h->bbox_id = h->bbox_id_s[0];
+    h->have_cell_idx = h->have_bbox_id = false;
     h->idx_cap = want;
   }
   if (need_bin) {
-    if ((rc = grow(h, h->bin_keys, h->bin_keys_cap, keys_need + keys_need / 8))) return rc;
-    if ((rc = grow(h, h->bin_tab, h->bin_tab_cap, tab_need + tab_need / 8))) return rc;
-    if (slots_need > h->bin_slots) {
-      const size_t want = slots_need + slots_need / 8;
-      if (h->bin_scratch) GV_HIP(hipFree(h->bin_scratch));
-      h->bin_scratch = nullptr;
-      h->bin_slots = 0;
-      GV_HIP(hipMalloc(reinterpret_cast<void **>(&h->bin_scratch), want * kBinSplitMax * ((size_t)kBinTileCells + 512) * sizeof(uint32_t)));
-      h->bin_slots = want;
+    const size_t keys_want = std::max(h->bin_keys_cap, keys_need + keys_need / 8);
+    const size_t tab_want = std::max(h->bin_tab_cap, tab_need + tab_need / 8);
+    const size_t slots_want = slots_need > h->bin_slots ? slots_need + slots_need / 8 : h->bin_slots;
+    const size_t keys_had = h->bin_keys_cap, tab_had = h->bin_tab_cap, slots_had = h->bin_slots;
+    h->bin_keys_cap = h->bin_tab_cap = h->bin_slots = 0;
+    for (int k = 0; k < nsets; ++k) {
+      size_t cap = keys_had;
+      if ((rc = grow(h, h->bin_keys[k], cap, keys_want))) return rc;
+      cap = tab_had;
+      if ((rc = grow(h, h->bin_tab[k], cap, tab_want))) return rc;
+      if (slots_want > slots_had) {
+        if (h->bin_scratch[k]) GV_HIP(hipFree(h->bin_scratch[k]));
+        h->bin_scratch[k] = nullptr;
+        GV_HIP(hipMalloc(reinterpret_cast<void **>(&h->bin_scratch[k]),
+                         slots_want * kBinSplitMax * ((size_t)kBinTileCells + 512) * sizeof(uint32_t)));
+      }
     }
+    h->bin_keys_cap = keys_want;
+    h->bin_tab_cap = tab_want;
+    h->bin_slots = slots_want;
   }
   return GV_OK;
 }
@@ -307,7 +347,10 @@ DetLayout det_layout(int32_t cap)
 int ensure_det(gv_context *h, DetSet &d, int32_t n)
 {
   if (n <= d.cap) return GV_OK;
-  if (d.cap) GV_HIP(hipStreamSynchronize(h->stream));   // frames that read this set are past it (rare: the count grew)
+  if (d.cap) {   // frames that read this set must be past it (rare: the count grew)
+    int rc0 = drain(h);
+    if (rc0) return rc0;
+  }
   const int32_t want = std::max(n + n / 4, 64);
   const DetLayout L = det_layout(want);
   d.cap = 0;
@@ -334,8 +377,8 @@ int ensure_det(gv_context *h, DetSet &d, int32_t n)
   return GV_OK;
 }
 
-// rectangles (all pipeline sets), vision outputs and centre points follow the detection count; they
-// are written on stream A / C by the frames in flight, hence the drain
+// rectangles and vision outputs (all buffer sets) and centre points follow the detection count; they
+// are written by the frames in flight, hence the drain
 int ensure_det_shared(gv_context *h, int32_t n)
 {
   if (n <= h->vout_cap) return GV_OK;
@@ -351,7 +394,9 @@ int ensure_det_shared(gv_context *h, int32_t n)
   h->vout_cap = 0;
   for (int k = 0; k < gv_context::kSets; ++k)
     if ((rc = re(h->x_rects[k], (size_t)want * sizeof(Rect)))) return rc;
-  if ((rc = re(h->d_vout, (size_t)want * sizeof(VisionOut)))) return rc;
+  for (int k = 0; k < 3; ++k)
+    if ((rc = re(h->d_vout_s[k], (size_t)want * sizeof(VisionOut)))) return rc;
+  h->d_vout = h->d_vout_s[0];
   if ((rc = re(h->d_pts, (size_t)want * 3 * sizeof(double)))) return rc;
   h->vout_cap = want;
   h->pts_cap = want;
@@ -547,11 +592,11 @@ int fill_sector_args(gv_context *h, SectorArgs &sa, int p)
 }
 
 // poses / network outputs of detection set D -> index rectangles on stream s
-int32_t enqueue_rects(gv_context *h, const DetSet &D, Rect *rects, hipStream_t s)
+int32_t enqueue_rects(gv_context *h, const DetSet &D, Rect *rects, VisionOut *vout, hipStream_t s)
 {
   const bool vision = D.flags & GV_FRAME_VISION_ORIENT;
   if (vision && D.nb > 0) {
-    launch_vision(D.orient, D.conf, D.dims, D.bboxes, D.nb, h->cam, h->d_vout, D.poses, s);
+    launch_vision(D.orient, D.conf, D.dims, D.bboxes, D.nb, h->cam, vout, D.poses, s);
     launch_rects_from_poses(D.poses, D.nb, h->g, true, h->x_bc, rects, s);
     return D.nb;
   }
@@ -575,11 +620,13 @@ int check_frame_flags(const gv_context *h, uint32_t fl)
 // --- building blocks of the tile-path frame (shared by the one-GPU frame, the sharded frame and its
 // one-device emulation) ---
 
-// partition + tile histogram of points [lo, lo + n) of the current cloud: hits[] (or not) and the end
-// bitmaps of buffer set p; zeroes the set's free-cell bitmaps.  ev_* are stage-timing events or null.
-int enqueue_binning(gv_context *h, const DetSet &D, int p, size_t lo, size_t n, bool keep_cell, bool do_ray,
-                    bool do_bbox, bool write_hits, hipStream_t s, hipEvent_t ev_points, Rect *fold_rects = nullptr)
+// partition + tile histogram of points [lo, lo + n) of the current cloud on stream k: that stream's hits[]
+// (or not), per-point outputs and binning scratch; the end bitmaps of buffer set p; zeroes the set's
+// free-cell bitmaps.  ev_* are stage-timing events or null.
+int enqueue_binning(gv_context *h, const DetSet &D, int p, int k, size_t lo, size_t n, bool keep_cell, bool do_ray,
+                    bool do_bbox, bool write_hits, hipEvent_t ev_points, Rect *fold_rects = nullptr)
 {
+  hipStream_t s = h->streams[k];
   const uint32_t chunk = bin_chunk_for(n);
   const uint32_t n_wg = (uint32_t)((n + chunk - 1) / chunk);
   BinArgs a{};
@@ -593,8 +640,8 @@ int enqueue_binning(gv_context *h, const DetSet &D, int p, size_t lo, size_t n, 
   a.bt = bbox_test_of(h, D);
   a.nb = D.nb;
   a.nb_pad = (D.nb + 3) & ~3;
-  a.bbox_id = h->bbox_id + lo;
-  a.cell_idx = keep_cell ? h->cell_idx + lo : nullptr;
+  a.bbox_id = h->bbox_id_s[k] + lo;
+  a.cell_idx = keep_cell ? h->cell_idx_s[k] + lo : nullptr;
   a.do_ray = do_ray;
   // the fused bbox test keeps its tables in LDS; a detection set too large for that (hundreds of boxes, or a
   // large image: one mask word per 16x16-pixel tile) runs the test as a pass of its own over the cloud
@@ -603,9 +650,9 @@ int enqueue_binning(gv_context *h, const DetSet &D, int p, size_t lo, size_t n, 
   a.chunk = chunk;
   a.n_wg = n_wg;
   a.tiles_x = h->tiles_x; a.tiles_y = h->tiles_y; a.n_tiles = h->n_tiles;
-  a.keys = h->bin_keys;
-  a.tab = h->bin_tab;
-  a.tile_total = h->bin_total[h->bin_parity];
+  a.keys = h->bin_keys[k];
+  a.tab = h->bin_tab[k];
+  a.tile_total = h->bin_total[k][h->bin_parity[k]];
   if (fold_rects) {   // the frame's rectangles ride the partition launch
     a.rect_poses = D.poses;
     a.n_rect_poses = D.n_poses;
@@ -633,15 +680,15 @@ int enqueue_binning(gv_context *h, const DetSet &D, int p, size_t lo, size_t n, 
   t.tiles_x = h->tiles_x; t.tiles_y = h->tiles_y; t.n_tiles = h->n_tiles;
   t.n_wg = n_wg;
   t.chunk = chunk;
-  t.keys = h->bin_keys;
-  t.tab = h->bin_tab;
-  t.tile_total = h->bin_total[h->bin_parity];
-  t.tile_total_next = h->bin_total[h->bin_parity ^ 1];
-  t.done = h->bin_done;
-  t.scratch = h->bin_scratch;
+  t.keys = h->bin_keys[k];
+  t.tab = h->bin_tab[k];
+  t.tile_total = h->bin_total[k][h->bin_parity[k]];
+  t.tile_total_next = h->bin_total[k][h->bin_parity[k] ^ 1];
+  t.done = h->bin_done[k];
+  t.scratch = h->bin_scratch[k];
   t.split_keys = kBinSplitKeys;
   t.max_slots = (uint32_t)h->bin_slots;
-  t.hits = write_hits ? h->hits : nullptr;
+  t.hits = write_hits ? h->hits_s[k] : nullptr;
   t.hitN = h->x_hitN[p]; t.clipN = h->x_clipN[p]; t.hitT = h->x_hitT[p]; t.clipT = h->x_clipT[p];
   t.freeN = h->x_freeN[p]; t.freeT = h->x_freeT[p];
   t.nxw = h->nxw; t.nyw = h->nyw; t.nx_pad = h->nx_pad; t.ny_pad = h->ny_pad;
@@ -649,7 +696,7 @@ int enqueue_binning(gv_context *h, const DetSet &D, int p, size_t lo, size_t n, 
   t.dbg = h->d_bin_dbg[1];
 #endif
   launch_bin_tiles(t, (uint32_t)(n / kBinSplitKeys), s);
-  h->bin_parity ^= 1;
+  h->bin_parity[k] ^= 1;
   GV_HIP(hipGetLastError());
   return GV_OK;
 }
@@ -692,10 +739,26 @@ int enqueue_grid_pass(gv_context *h, int p, const Rect *rects, int32_t n_rects, 
   return GV_OK;
 }
 
-// The tile-path frame.  pipelined: stream A = rectangles, partition, tile histogram + end bitmaps of
-// frame f; stream B = sector ray stage; stream C = grid pass, over n_sets rotating buffer sets, so that A
-// runs up to n_sets frames ahead.  Serial (GV_PIPELINE=0, stage timing, the sharded frame): the same
-// launches on stream A alone, buffer set 0.
+// Stream k (0 public, 1 / 2 the lanes) reads cloud C / detection set D: ordered after their uploads
+// (once per upload and stream)
+int wait_inputs(gv_context *h, CloudSet &C, DetSet &D, int k)
+{
+  hipStream_t s = h->streams[k];
+  if (!(C.seen >> k & 1u)) {
+    GV_HIP(hipStreamWaitEvent(s, C.ready, 0));
+    C.seen |= 1u << k;
+  }
+  if (!(D.seen >> k & 1u)) {
+    GV_HIP(hipStreamWaitEvent(s, D.ready, 0));
+    D.seen |= 1u << k;
+  }
+  return GV_OK;
+}
+
+// The tile-path frame: rectangles + partition, tile histogram + end bitmaps, sector ray stage back to
+// back on one in-order stream, then the grid pass on the public stream.  pipelined: the stream of lane
+// n % 2 and buffer set 1 + n % 4 (n = lane frames so far), the grid pass behind one event.  Serial
+// (GV_PIPELINE=0, stage timing, the sharded frame): everything on the public stream, buffer set 0.
 int enqueue_frame_tiles(gv_context *h, bool pipelined, bool stage_events, bool sharded = false)
 {
   DetSet &D = h->det[h->det_cur];
@@ -705,9 +768,12 @@ int enqueue_frame_tiles(gv_context *h, bool pipelined, bool stage_events, bool s
   int rc = check_frame_flags(h, fl);
   if (rc) return rc;
   if (sharded && (!do_bin || !h->comm)) return GV_ERR_STATE;
-  const int p = pipelined ? (int)(h->frame_no % (unsigned)h->n_sets) : 0;
-  hipStream_t sA = h->stream, sB = pipelined ? h->stream2 : sA, sC = pipelined ? h->stream3 : sA;
-  const CloudSet &CS = h->cloud[h->cloud_cur];
+  const int p = pipelined ? 1 + (int)(h->lane_frames % 4u) : 0;
+  const int k = pipelined ? 1 + (int)(h->lane_frames % 2u) : 0;
+  hipStream_t s = h->streams[k];
+  // back-pressure: the frame that last used this buffer set (four frames ago) has finished
+  if (pipelined && h->set_fin_slot[p] >= 0) GV_HIP(hipEventSynchronize(h->ev_fin[h->set_fin_slot[p]]));
+  CloudSet &CS = h->cloud[h->cloud_cur];
 #ifdef GV_DIAG
   auto mark = [&](hipStream_t st) {   // device timeline of the pipelined frame (gv_debug_pipeline_trace)
     if (!h->trace) return;
@@ -719,24 +785,22 @@ int enqueue_frame_tiles(gv_context *h, bool pipelined, bool stage_events, bool s
 #else
   auto mark = [](hipStream_t) {};
 #endif
-  const bool set_reused = pipelined && h->since_drain >= h->n_sets;
-  if (set_reused) GV_HIP(hipStreamWaitEvent(sA, h->ev_fin[p], 0));   // set p (bitmaps, rectangles) is free again
-  if (h->cloud_wait) { GV_HIP(hipStreamWaitEvent(sA, CS.ready, 0)); h->cloud_wait = false; }
-  if (stage_events) GV_HIP(hipEventRecord(h->ev[0], sA));
+  if ((rc = wait_inputs(h, CS, D, k))) return rc;
+  if (stage_events) GV_HIP(hipEventRecord(h->ev[0], s));
 
   // --- detections -> rectangles.  Base-frame poses of a binning frame ride the partition launch (one
   // extra workgroup) instead of a launch of their own; network outputs go through the vision kernels.
   Rect *rects = h->x_rects[p];
   const bool fold_rects = do_bin && !(fl & GV_FRAME_VISION_ORIENT) && D.n_poses > 0;
-  mark(sA);
-  const int32_t n_rects = fold_rects ? D.n_poses : enqueue_rects(h, D, rects, sA);
-  mark(sA);
-  if (stage_events) GV_HIP(hipEventRecord(h->ev[kStageDetections + 1], sA));
+  mark(s);
+  const int32_t n_rects = fold_rects ? D.n_poses : enqueue_rects(h, D, rects, h->d_vout_s[k], s);
+  mark(s);
+  if (stage_events) GV_HIP(hipEventRecord(h->ev[kStageDetections + 1], s));
 
   // --- points: partition by tile (+ ray ends, bbox test), then the tile histogram: hits[] + end bitmaps
-  mark(sA);
+  mark(s);
   if (do_bin) {
-    if ((rc = enqueue_binning(h, D, p, 0, h->n, keep_cell, do_ray, do_bbox, true, sA,
+    if ((rc = enqueue_binning(h, D, p, k, 0, h->n, keep_cell, do_ray, do_bbox, true,
                               stage_events ? h->ev[kStagePoints + 1] : nullptr, fold_rects ? rects : nullptr)))
       return rc;
   } else {
@@ -748,48 +812,55 @@ int enqueue_frame_tiles(gv_context *h, bool pipelined, bool stage_events, bool s
       a.m_cam = h->m_cam;
       a.cam = h->camk;
       a.bt = bbox_test_of(h, D);
-      a.bbox_id = h->bbox_id;
+      a.bbox_id = h->bbox_id_s[k];
       a.do_bbox = true;
-      launch_points(a, sA);
+      launch_points(a, s);
     }
-    if (stage_events) GV_HIP(hipEventRecord(h->ev[kStagePoints + 1], sA));
+    if (stage_events) GV_HIP(hipEventRecord(h->ev[kStagePoints + 1], s));
   }
-  mark(sA);
-  mark(sA); mark(sA);   // (trace slot of the former bitmap kernel: the tile pass is part of the binning pair)
-  if (stage_events) GV_HIP(hipEventRecord(h->ev[kStageRayCompact + 1], sA));
-  // cloud and detections of this frame are consumed: the other cloud / detection set may be refilled
-  // once this event has passed (begin_cloud_upload, set_detections)
-  GV_HIP(hipEventRecord(h->ev_build[p], sA));
-  h->last_frame_set = p;
-  if (pipelined) GV_HIP(hipStreamWaitEvent(sB, h->ev_build[p], 0));
+  mark(s);
+  mark(s); mark(s);   // (trace slot of the former bitmap kernel: the tile pass is part of the binning pair)
+  if (stage_events) GV_HIP(hipEventRecord(h->ev[kStageRayCompact + 1], s));
   h->last_set = p;
+  h->hits = h->hits_s[k];
+  h->bbox_id = h->bbox_id_s[k];
+  h->cell_idx = h->cell_idx_s[k];
   h->have_cell_idx = do_bin && keep_cell;
   h->have_bbox_id = do_bbox;
   if (sharded) return sharded_tail(h, rects, n_rects);
 
   // --- free-space ray stage
-  mark(sB);
-  if (do_ray && (rc = enqueue_sectors(h, p, 0, 1, sB))) return rc;
-  mark(sB);
-  if (stage_events) GV_HIP(hipEventRecord(h->ev[kStageRayMarch + 1], sB));
-  if (pipelined) {
-    GV_HIP(hipEventRecord(h->ev_sec[p], sB));
-    GV_HIP(hipStreamWaitEvent(sC, h->ev_sec[p], 0));
-  }
+  mark(s);
+  if (do_ray && (rc = enqueue_sectors(h, p, 0, 1, s))) return rc;
+  mark(s);
+  if (stage_events) GV_HIP(hipEventRecord(h->ev[kStageRayMarch + 1], s));
 
-  // --- grid pass
-  mark(sC);
-  if ((rc = enqueue_grid_pass(h, p, rects, n_rects, do_bin, 0, h->g.ny, sC))) return rc;
-  mark(sC);
-  if (stage_events) GV_HIP(hipEventRecord(h->ev[kStageFinalize + 1], sC));
+  // --- grid pass, on the public stream: in order behind the previous frame's and behind whatever the
+  // caller queued there (the download of the previous grid, a plain map update)
+  const int slot = (int)(h->frame_no % (uint64_t)gv_context::kRing);
   if (pipelined) {
-    GV_HIP(hipEventRecord(h->ev_fin[p], sC));
-    h->frame_no++;
-    if (h->since_drain < h->n_sets) h->since_drain++;
+    GV_HIP(hipEventRecord(h->ev_sec[slot], s));
+    GV_HIP(hipStreamWaitEvent(h->stream, h->ev_sec[slot], 0));
+    s = h->stream;
+  }
+  mark(s);
+  if ((rc = enqueue_grid_pass(h, p, rects, n_rects, do_bin, 0, h->g.ny, s))) return rc;
+  mark(s);
+  if (stage_events) GV_HIP(hipEventRecord(h->ev[kStageFinalize + 1], s));
+  // this frame done => every earlier frame done; cloud, detection set and buffer set remember their last user
+  GV_HIP(hipEventRecord(h->ev_fin[slot], s));
+  h->last_fin_slot = slot;
+  h->set_fin_slot[p] = slot;
+  CS.release_slot = slot;
+  D.release_slot = slot;
+  D.release_stream = k;
+  h->frame_no++;
+  if (pipelined) {
+    h->lane_frames++;
     h->pipe_busy = true;
   }
   h->have_hits = do_bin;
-  h->have_miss = do_bin;   // the free-cell bitmaps of set p stay until the set is reused
+  h->have_miss = do_bin;   // the free-cell bitmaps of set p stay until the set's next frame
   return GV_OK;
 }
 
@@ -805,8 +876,10 @@ int enqueue_frame_generic(gv_context *h, bool stage_events)
   if (rc) return rc;
   if (h->counts_dirty && (rc = clear_counts(h))) return rc;
   hipStream_t s = h->stream;
+  CloudSet &CS = h->cloud[h->cloud_cur];
+  if ((rc = wait_inputs(h, CS, D, 0))) return rc;
   if (stage_events) GV_HIP(hipEventRecord(h->ev[0], s));
-  const int32_t n_rects = enqueue_rects(h, D, h->x_rects[0], s);
+  const int32_t n_rects = enqueue_rects(h, D, h->x_rects[0], h->d_vout_s[0], s);
   if (stage_events) GV_HIP(hipEventRecord(h->ev[kStageDetections + 1], s));
   if (do_bin || do_bbox) {
     PointsArgs a{};
@@ -825,8 +898,6 @@ int enqueue_frame_generic(gv_context *h, bool stage_events)
     a.do_bin = do_bin; a.do_ray = do_ray; a.do_bbox = do_bbox;
     launch_points(a, s);
   }
-  GV_HIP(hipEventRecord(h->ev_build[0], s));   // cloud and detections consumed
-  h->last_frame_set = 0;
   if (stage_events) GV_HIP(hipEventRecord(h->ev[kStagePoints + 1], s));
   if (do_ray && h->org.valid) {
     GV_HIP(hipMemsetAsync(h->ray_count, 0, sizeof(uint32_t), s));
@@ -856,6 +927,13 @@ int enqueue_frame_generic(gv_context *h, bool stage_events)
   launch_finalize(f, s);
   if (stage_events) GV_HIP(hipEventRecord(h->ev[kStageFinalize + 1], s));
   GV_HIP(hipGetLastError());
+  const int slot = (int)(h->frame_no % (uint64_t)gv_context::kRing);
+  GV_HIP(hipEventRecord(h->ev_fin[slot], s));   // cloud and detection set remember their last reader
+  h->last_fin_slot = slot;
+  CS.release_slot = slot;
+  D.release_slot = slot;
+  D.release_stream = 0;
+  h->frame_no++;
   h->last_set = 0;
   h->counts_dirty = do_bin && keep_counts;
   h->have_hits = h->have_miss = do_bin && keep_counts;
@@ -1061,20 +1139,18 @@ int gv_create(gv_handle *out, uint8_t grid_x, uint8_t grid_y, double resolution,
   GV_C(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
   GV_C(hipStreamCreateWithFlags(&h->stream3, hipStreamNonBlocking));
   GV_C(hipStreamCreateWithFlags(&h->stream_copy, hipStreamNonBlocking));
-  for (int i = 0; i < gv_context::kSets; ++i) {
-    GV_C(hipEventCreateWithFlags(&h->ev_build[i], hipEventDisableTiming));
-    GV_C(hipEventCreateWithFlags(&h->ev_fin[i], hipEventDisableTiming));
-    GV_C(hipEventCreateWithFlags(&h->ev_sec[i], hipEventDisableTiming));
-  }
-  for (auto &e : h->ev_join) GV_C(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  h->streams[0] = h->stream;
+  h->streams[1] = h->stream2;
+  h->streams[2] = h->stream3;
+  for (auto &e : h->ev_fin) GV_C(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  for (auto &e : h->ev_sec) GV_C(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  GV_C(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
   for (auto &c : h->cloud) GV_C(hipEventCreateWithFlags(&c.ready, hipEventDisableTiming));
   for (auto &d : h->det) GV_C(hipEventCreateWithFlags(&d.ready, hipEventDisableTiming));
   const size_t G = (size_t)g.G;
   GV_C(hipMalloc(reinterpret_cast<void **>(&h->log_odds), G * sizeof(float)));
   GV_C(hipMalloc(reinterpret_cast<void **>(&h->occupancy), G * sizeof(float)));
   GV_C(hipMalloc(reinterpret_cast<void **>(&h->occ_i8), G));
-  GV_C(hipMalloc(reinterpret_cast<void **>(&h->hits), G * sizeof(int32_t)));
-  GV_C(hipMemsetAsync(h->hits, 0, G * sizeof(int32_t), h->stream));
   GV_C(hipMalloc(reinterpret_cast<void **>(&h->ray_count), 4 * sizeof(uint32_t)));
   GV_C(hipMemsetAsync(h->ray_count, 0, 4 * sizeof(uint32_t), h->stream));
   GV_C(hipMalloc(reinterpret_cast<void **>(&h->scratch_i32), G * sizeof(int32_t)));
@@ -1085,7 +1161,6 @@ int gv_create(gv_handle *out, uint8_t grid_x, uint8_t grid_y, double resolution,
     const char *impl = std::getenv("GV_RAY_IMPL");
     h->force_simple = impl && std::strcmp(impl, "simple") == 0;
     if (const char *e = std::getenv("GV_PIPELINE")) h->no_pipeline = std::atoi(e) == 0;
-    if (const char *e = std::getenv("GV_PIPE_SETS")) h->n_sets = std::min(gv_context::kSets, std::max(2, std::atoi(e)));
     if (const char *e = std::getenv("GV_LOG2S")) h->env_log2s = std::atoi(e);
     if (const char *e = std::getenv("GV_LOG2S_OCT")) {
       int k = 0;
@@ -1119,6 +1194,11 @@ int gv_create(gv_handle *out, uint8_t grid_x, uint8_t grid_y, double resolution,
   }
   const bool sectors = h->tile_path && !h->force_simple;
   const int nsets_alloc = sectors ? gv_context::kSets : 1;
+  for (int k = 0; k < (sectors ? 3 : 1); ++k) {
+    GV_C(hipMalloc(reinterpret_cast<void **>(&h->hits_s[k]), G * sizeof(int32_t)));
+    GV_C(hipMemsetAsync(h->hits_s[k], 0, G * sizeof(int32_t), h->stream));
+  }
+  h->hits = h->hits_s[0];
   for (int k = 0; k < nsets_alloc; ++k) {
     GV_C(hipMalloc(reinterpret_cast<void **>(&h->x_stats[k]), kMaxStatSlots * 2 * sizeof(unsigned long long)));
     GV_C(hipMemsetAsync(h->x_stats[k], 0, kMaxStatSlots * 2 * sizeof(unsigned long long), h->stream));
@@ -1148,12 +1228,14 @@ int gv_create(gv_handle *out, uint8_t grid_x, uint8_t grid_y, double resolution,
       h->x_freeN[k] = h->x_free[k];
       h->x_freeT[k] = h->x_free[k] + h->bmN_words;
     }
-    for (int k = 0; k < 2; ++k) {
-      GV_C(hipMalloc(reinterpret_cast<void **>(&h->bin_total[k]), (size_t)h->n_tiles * sizeof(uint32_t)));
-      GV_C(hipMemsetAsync(h->bin_total[k], 0, (size_t)h->n_tiles * sizeof(uint32_t), h->stream));
+    for (int q = 0; q < 3; ++q) {
+      for (int k = 0; k < 2; ++k) {
+        GV_C(hipMalloc(reinterpret_cast<void **>(&h->bin_total[q][k]), (size_t)h->n_tiles * sizeof(uint32_t)));
+        GV_C(hipMemsetAsync(h->bin_total[q][k], 0, (size_t)h->n_tiles * sizeof(uint32_t), h->stream));
+      }
+      GV_C(hipMalloc(reinterpret_cast<void **>(&h->bin_done[q]), (size_t)h->n_tiles * sizeof(uint32_t)));
+      GV_C(hipMemsetAsync(h->bin_done[q], 0, (size_t)h->n_tiles * sizeof(uint32_t), h->stream));
     }
-    GV_C(hipMalloc(reinterpret_cast<void **>(&h->bin_done), (size_t)h->n_tiles * sizeof(uint32_t)));
-    GV_C(hipMemsetAsync(h->bin_done, 0, (size_t)h->n_tiles * sizeof(uint32_t), h->stream));
   } else {
     // generic path: byte flags of clipped ray ends and of free cells + the compacted ray list
     GV_C(hipMalloc(reinterpret_cast<void **>(&h->clip_end), G + 16));
@@ -1182,9 +1264,8 @@ int gv_destroy(gv_handle h)
   for (hipStream_t s : {h->stream_copy, h->stream, h->stream2, h->stream3})
     if (s) (void)hipStreamSynchronize(s);
   if (h->comm) { ncclCommDestroy(h->comm); h->comm = nullptr; }
-  void *bufs[] = {h->log_odds, h->occupancy, h->occ_i8, h->hits, h->clip_end, h->miss8, h->sh_xchg, h->ray_list, h->ray_count, h->scratch_i32,
-                  h->bin_keys, h->bin_tab, h->bin_total[0], h->bin_total[1], h->bin_done, h->bin_scratch,
-                  h->tx, h->ty, h->tz, h->cell_idx, h->bbox_id, h->d_vout, h->d_pts, h->knn_partial, h->d_depths,
+  void *bufs[] = {h->log_odds, h->occupancy, h->occ_i8, h->clip_end, h->miss8, h->sh_xchg, h->ray_list, h->ray_count, h->scratch_i32,
+                  h->tx, h->ty, h->tz, h->d_pts, h->knn_partial, h->d_depths,
                   h->d_knn_d2, h->d_idx, h->d_segof, h->d_segstart, h->gx, h->gy, h->gz, h->d_keep, h->d_planes,
                   h->d_plane_counts, h->d_ground, h->d_rscratch, h->d_rstate, h->d_blockcnt, h->d_pose_out, h->d_pose_valid};
   for (void *p : bufs)
@@ -1195,6 +1276,12 @@ int gv_destroy(gv_handle h)
 #endif
   for (int k = 0; k < gv_context::kSets; ++k) {
     void *xs[] = {h->x_ends[k], h->x_free[k], h->x_rects[k], h->x_stats[k]};
+    for (void *p : xs)
+      if (p) (void)hipFree(p);
+  }
+  for (int k = 0; k < 3; ++k) {
+    void *xs[] = {h->hits_s[k], h->cell_idx_s[k], h->bbox_id_s[k], h->d_vout_s[k], h->bin_keys[k], h->bin_tab[k],
+                  h->bin_total[k][0], h->bin_total[k][1], h->bin_done[k], h->bin_scratch[k]};
     for (void *p : xs)
       if (p) (void)hipFree(p);
   }
@@ -1211,13 +1298,11 @@ int gv_destroy(gv_handle h)
   }
   for (auto &e : h->ev)
     if (e) (void)hipEventDestroy(e);
-  for (auto &e : h->ev_join)
+  for (auto &e : h->ev_fin)
     if (e) (void)hipEventDestroy(e);
-  for (int i = 0; i < gv_context::kSets; ++i) {
-    if (h->ev_build[i]) (void)hipEventDestroy(h->ev_build[i]);
-    if (h->ev_fin[i]) (void)hipEventDestroy(h->ev_fin[i]);
-    if (h->ev_sec[i]) (void)hipEventDestroy(h->ev_sec[i]);
-  }
+  for (auto &e : h->ev_sec)
+    if (e) (void)hipEventDestroy(e);
+  if (h->ev_join) (void)hipEventDestroy(h->ev_join);
   for (hipStream_t s : {h->stream3, h->stream2, h->stream_copy, h->stream})
     if (s) (void)hipStreamDestroy(s);
   delete h;
@@ -1282,17 +1367,17 @@ int gv_host_free(void *ptr)
 
 namespace {
 
-// The cloud set that is NOT being read by the frames in flight, grown to n points, with the copy
+// The next cloud set in rotation (read two uploads ago at the latest), grown to n points, with the copy
 // stream ordered after the last frame that read it.
 int begin_cloud_upload(gv_context *h, size_t n, int &target)
 {
   int rc = set_device_only(h);
   if (rc) return rc;
   if ((rc = ensure_point_buffers(h, n))) return rc;
-  target = h->cloud_cur ^ 1;
+  target = (h->cloud_cur + 1) % 3;
   CloudSet &c = h->cloud[target];
   if (n > c.cap) {
-    if (c.release_set >= 0) GV_HIP(hipEventSynchronize(h->ev_build[c.release_set]));
+    if (c.release_slot >= 0) GV_HIP(hipEventSynchronize(h->ev_fin[c.release_slot]));
     GV_HIP(hipEventSynchronize(c.ready));
     if (c.base) GV_HIP(hipFree(c.base));
     c.base = nullptr;
@@ -1305,8 +1390,10 @@ int begin_cloud_upload(gv_context *h, size_t n, int &target)
   c.x = c.base;
   c.y = c.base + n4;
   c.z = c.base + 2 * n4;
-  // ordered after the last frame that reads this set (a later re-record of the event only waits longer)
-  if (c.release_set >= 0) GV_HIP(hipStreamWaitEvent(h->stream_copy, h->ev_build[c.release_set], 0));
+  // ordered after the last frame that read this set (if the ring slot has been re-recorded since, that is
+  // a later frame: it only waits longer)
+  if (c.release_slot >= 0) GV_HIP(hipStreamWaitEvent(h->stream_copy, h->ev_fin[c.release_slot], 0));
+  c.release_slot = -1;
   return GV_OK;
 }
 
@@ -1314,7 +1401,7 @@ int end_cloud_upload(gv_context *h, int target, size_t n)
 {
   CloudSet &c = h->cloud[target];
   GV_HIP(hipEventRecord(c.ready, h->stream_copy));
-  h->cloud[h->cloud_cur].release_set = h->last_frame_set;   // frames enqueued so far are its last readers
+  c.seen = 0;   // every stream that reads it waits for `ready` once
   h->cloud_cur = target;
   h->cx = c.x; h->cy = c.y; h->cz = c.z;
   h->n = n;
@@ -1377,16 +1464,22 @@ int set_detections(gv_context *h, const gv_frame_desc *d)
   if (!vision && d->n_poses && !d->poses) return GV_ERR_BAD_ARG;
   int rc = set_device_only(h);
   if (rc) return rc;
-  // The other detection set: frames already enqueued read the current one, and they precede this upload on
-  // stream A, as the frames that will read it follow it there -- stream order is all the ordering needed.
+  // The other detection set (frames already enqueued read the current one), uploaded on the stream of the
+  // frame that will read it first: in order before that frame, and -- two sets, two lanes -- after the
+  // frame that last read this set when every frame brings new detections.  Any other case waits on events.
   const int target = h->det_cur ^ 1;
   DetSet &D = h->det[target];
+  const int k = (sector_path(h) && !h->no_pipeline) ? 1 + (int)(h->lane_frames % 2u) : 0;
+  hipStream_t s = h->streams[k];
+  if (D.release_slot >= 0 && D.release_stream != k) GV_HIP(hipStreamWaitEvent(s, h->ev_fin[D.release_slot], 0));
   const bool net = vision && d->n_bboxes;
   if ((rc = upload_det(h, D, d->bboxes, d->n_bboxes, vision ? nullptr : d->poses, vision ? 0 : d->n_poses,
-                       net ? d->orient : nullptr, net ? d->conf : nullptr, net ? d->dims : nullptr, h->stream)))
+                       net ? d->orient : nullptr, net ? d->conf : nullptr, net ? d->dims : nullptr, s)))
     return rc;
   D.flags = d->flags;
-  GV_HIP(hipEventRecord(D.ready, h->stream));   // (only guards the reuse of the set's pinned staging block)
+  GV_HIP(hipEventRecord(D.ready, s));
+  D.seen = 1u << k;
+  D.release_slot = -1;
   h->det_cur = target;
   return GV_OK;
 }
@@ -1779,12 +1872,11 @@ int gv_frame_fence(gv_handle h)
   if (!h) return GV_ERR_BAD_ARG;
   int rc = set_device_only(h);
   if (rc) return rc;
-  if (h->pipe_busy) {   // join streams B and C (and the copy stream) into stream A
-    hipStream_t others[3] = {h->stream2, h->stream3, h->stream_copy};
-    for (int k = 0; k < 3; ++k) {
-      GV_HIP(hipEventRecord(h->ev_join[k], others[k]));
-      GV_HIP(hipStreamWaitEvent(h->stream, h->ev_join[k], 0));
-    }
+  // Every frame ends with its grid pass on the public stream, behind an event that follows its other
+  // kernels: frames are already in order there.  What is left to join is the copy stream.
+  if (h->cloud_wait) {
+    GV_HIP(hipEventRecord(h->ev_join, h->stream_copy));
+    GV_HIP(hipStreamWaitEvent(h->stream, h->ev_join, 0));
   }
   return GV_OK;
 }
@@ -2235,11 +2327,12 @@ int gv_debug_frame_sharded_emulated(gv_handle h, const gv_frame_desc *desc, int3
       GV_HIP(hipMalloc(reinterpret_cast<void **>(&packs[r]), chunk * (size_t)world * sizeof(uint32_t)));
     }
     Rect *rects = h->x_rects[0];
-    const int32_t n_rects = enqueue_rects(h, D, rects, s);
     int rc2;
+    if ((rc2 = wait_inputs(h, h->cloud[h->cloud_cur], D, 0))) return rc2;
+    const int32_t n_rects = enqueue_rects(h, D, rects, h->d_vout_s[0], s);
     for (int r = 0; r < world; ++r) {   // every rank bins its slice
       const size_t lo = h->n * (size_t)r / (size_t)world, hi = h->n * (size_t)(r + 1) / (size_t)world;
-      if ((rc2 = enqueue_binning(h, D, 0, lo, hi - lo, keep_cell, do_ray, do_bbox, false, s, nullptr))) return rc2;
+      if ((rc2 = enqueue_binning(h, D, 0, 0, lo, hi - lo, keep_cell, do_ray, do_bbox, false, nullptr))) return rc2;
       GV_HIP(hipMemcpyAsync(ends[r], h->x_ends[0], Ep * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
     }
     for (int q = 0; q < world; ++q) {   // exchange 1: rank q ORs slice q; the all-gather is the union of the slices
@@ -2267,6 +2360,9 @@ int gv_debug_frame_sharded_emulated(gv_handle h, const gv_frame_desc *desc, int3
   (void)hipStreamSynchronize(s);
   cleanup();
   h->last_set = 0;
+  h->hits = h->hits_s[0];
+  h->bbox_id = h->bbox_id_s[0];
+  h->cell_idx = h->cell_idx_s[0];
   h->have_hits = false;
   h->have_miss = false;
   h->have_cell_idx = do_bin && keep_cell;
