@@ -1799,7 +1799,7 @@ int gv_to_occupancy_grid_async(gv_handle h, int8_t *data)
 {
   if (!h || !data) return GV_ERR_BAD_ARG;
   GV_TRY
-  int rc = gv_frame_fence(h);   // stream A now waits for every enqueued frame
+  int rc = set_device_only(h);   // the public stream runs the grid passes: this copy sits between two of them
   if (rc) return rc;
   GV_HIP(hipMemcpyAsync(data, h->occ_i8, (size_t)h->g.G, hipMemcpyDeviceToHost, h->stream));
   return GV_OK;

@@ -15,9 +15,9 @@
  *     points are NOT errors (the reference skips them silently,
  *     src/occupancy_grid.cpp:152-156,171-172);
  *   - one handle = one GPU + one resident grid + the HIP streams of its frame
- *     pipeline (gv_stream returns the one callers may order their own work on,
- *     after gv_frame_fence); a handle is used by one thread at a time; handles
- *     are independent;
+ *     pipeline (gv_stream returns the public one: every frame finishes there, in
+ *     order, and callers may order their own work on it); a handle is used by
+ *     one thread at a time; handles are independent;
  *   - host pointers are caller owned and may be pageable; every call returns
  *     after its results are complete in the caller's buffers (synchronous),
  *     except the streaming calls gv_frame_enqueue, gv_cloud_upload_*_async and
@@ -229,9 +229,10 @@ int gv_update_map_points(gv_handle h, const double *base_points_xyz, const gv_bb
  * GridMapRosConverter::toOccupancyGrid(map,"occupancy",0,1,msg)
  * (grid_vision_node.cpp:265-278): data[G] int8 in OccupancyGrid order. */
 int gv_to_occupancy_grid(gv_handle h, int8_t *data, gv_grid_info *info);
-/* The same without stalling the frame pipeline: gv_frame_fence + an asynchronous device-to-host copy
- * of data[G] on gv_stream(h).  data should be pinned (gv_host_alloc); it is complete once an event
- * recorded on gv_stream(h) after this call has passed, or after gv_synchronize. */
+/* The same without stalling the frame pipeline: an asynchronous device-to-host copy of data[G] on
+ * gv_stream(h), behind the grid pass of the last enqueued frame and ahead of the next one's.  data
+ * should be pinned (gv_host_alloc); it is complete once an event recorded on gv_stream(h) after this
+ * call has passed, or after gv_synchronize. */
 int gv_to_occupancy_grid_async(gv_handle h, int8_t *data);
 /* Layer read-back (grid_map_["log_odds"], ["occupancy"]; occupancy_grid.hpp:22) */
 int gv_get_log_odds(gv_handle h, float *out);
@@ -261,24 +262,26 @@ typedef struct {
   int32_t n_poses;
   const float *orient, *conf, *dims;  /* GV_FRAME_VISION_ORIENT: nb*4, nb*2, nb*3 */
 } gv_frame_desc;
-/* Upload the small per-frame detection inputs (bboxes, poses / net outputs).  Two sets alternate like
- * the clouds do: the arrays are copied into pinned staging (the caller's arrays are free on return), go
- * to the device in one copy on the frame's first stream -- in order between the frames that read the
- * previous set and those that will read this one -- and are turned into the bbox-test tables there.
+/* Upload the small per-frame detection inputs (bboxes, poses / net outputs).  Two sets alternate: the
+ * arrays are copied into pinned staging (the caller's arrays are free on return), go to the device in
+ * one copy on the stream of the frame that reads them first -- in order ahead of it -- and are turned
+ * into the bbox-test tables there.
  * Neither form waits for the copy or drains the frame pipeline (the _async name is kept for symmetry
  * with the cloud uploads).  The standalone entry points above (gv_extract_cloud_per_bbox,
  * gv_update_map_poses, ...) keep their inputs in a set of their own and never change what
  * gv_frame_enqueue uses. */
 int gv_frame_set_detections(gv_handle h, const gv_frame_desc *desc);
 int gv_frame_set_detections_async(gv_handle h, const gv_frame_desc *desc);
-/* Enqueue one frame using the resident cloud and the last detections set; returns without
- * waiting (asynchronous).  GV_ERR_STATE before the first gv_frame_set_detections.  The
- * default frame is pipelined over internal streams (rectangles + binning of frame f+1
- * overlap the ray stage and the grid pass of frame f): work a caller puts on gv_stream() is
- * ordered after the enqueued frames only once gv_frame_fence has been called. */
+/* Enqueue one frame using the resident cloud and the last detections set (asynchronous).
+ * GV_ERR_STATE before the first gv_frame_set_detections.  Two frames run side by side: binning and
+ * ray stage of frame f on internal stream f % 2, its grid pass on gv_stream(h) behind them, so the
+ * grid passes -- and anything the caller puts on gv_stream(h) between two frames -- execute in
+ * enqueue order and see every result of the frames before them.  At most FOUR frames are in flight:
+ * the call waits on the host for the frame four back when the caller runs further ahead. */
 int gv_frame_enqueue(gv_handle h);
-/* Make gv_stream(h) wait (on the device, not the host) for every frame and upload enqueued so
- * far: afterwards an event recorded or a kernel launched on gv_stream(h) sees their results. */
+/* Make gv_stream(h) wait (on the device, not the host) for every upload enqueued so far as well
+ * (frames are ordered on gv_stream(h) by construction): afterwards an event recorded or a kernel
+ * launched there sees the results of everything enqueued on the handle. */
 int gv_frame_fence(gv_handle h);
 /* Wait (host) for everything enqueued on the handle. */
 int gv_synchronize(gv_handle h);
@@ -293,9 +296,9 @@ int gv_get_bbox_id(gv_handle h, int32_t *out);       /* N ints, BBOX_TEST     */
 int gv_get_ray_stats(gv_handle h, uint64_t *n_rays, uint64_t *n_visits);
 
 /* ------------------------------------------------ raw stream / timing hooks -- */
-/* The HIP stream of the handle (hipStream_t as void*), for callers that record their own
- * events around gv_frame_enqueue or consume the grid layers on the device: call
- * gv_frame_fence first, the pipelined frame finishes on internal streams. */
+/* The public HIP stream of the handle (hipStream_t as void*), for callers that record their own
+ * events around gv_frame_enqueue or consume the grid layers on the device: every frame's grid pass
+ * runs on it, behind the frame's other kernels. */
 void *gv_stream(gv_handle h);
 /* Time `frames` back-to-back gv_frame_enqueue calls with HIP events on the
  * handle's stream; *ms_total is the elapsed device time. */

@@ -997,40 +997,50 @@ def test_streaming_ingest_matches_oracle(gvamd):
             p.close()
 
 
-def test_stream_contract_fence(gvamd):
-    """gv_stream contract: the pipelined frame finishes on internal streams, so work a caller puts on
-    gv_stream(h) is ordered after the enqueued frames only through gv_frame_fence.  Several frames are
-    enqueued, the packed grid is read back asynchronously on gv_stream (gv_to_occupancy_grid_async =
-    fence + copy) and ONLY that stream is synchronised (hipStreamSynchronize through ctypes): the bytes
-    must equal the fully drained result of an identical handle."""
+def test_stream_contract_public_stream(gvamd):
+    """gv_stream contract: every frame's grid pass runs on gv_stream(h) behind the frame's other kernels
+    (which run on the two internal lanes), so a copy the caller puts there between two gv_frame_enqueue
+    calls sees exactly the frames enqueued before it -- without a host wait and without stalling the
+    frames after it.  Seven frames are enqueued; the packed grid is read asynchronously after the 4th
+    and after the 7th (gv_to_occupancy_grid_async) and ONLY gv_stream(h) is synchronised
+    (hipStreamSynchronize through ctypes).  Both must equal fully drained handles run for 4 / 7 frames."""
     import ctypes
     hip = ctypes.CDLL("libamdhip64.so")
     config = 2
     x, y, z, _ = synth.cloud_lidar_like(config, 90_000)
     poses = synth.lshape_poses(config, 20)
     flags = gvamd.FRAME_BIN | gvamd.FRAME_RAYMARCH
-    outs = []
-    pin = gvamd.PinnedF32((synth.CONFIGS[config]["grid"].nx * synth.CONFIGS[config]["grid"].ny + 3) // 4)
-    for mode in ("fence", "drain"):
-        h, tfs = make_handle(gvamd, config, perturbed=True)
-        h.upload_xyz(x, y, z)
-        h.set_detections(flags, poses=poses)
-        for _ in range(7):
-            h.enqueue_frame()
-        if mode == "fence":
-            buf = pin.array.view(np.int8)[:h.G]
-            buf[:] = 0
-            h.to_occupancy_grid_async(buf)
-            rc = hip.hipStreamSynchronize(ctypes.c_void_p(h.stream()))   # stream A only: B and C are not waited for by the host
-            assert rc == 0
-            outs.append(buf.copy())
-            h.synchronize()
-        else:
-            h.synchronize()
-            outs.append(h.to_occupancy_grid()[0])
-        h.close()
-    pin.close()
-    assert np.array_equal(outs[0], outs[1])
+    G = synth.CONFIGS[config]["grid"].nx * synth.CONFIGS[config]["grid"].ny
+    pins = [gvamd.PinnedF32((G + 3) // 4) for _ in range(2)]
+    h, tfs = make_handle(gvamd, config, perturbed=True)
+    h.upload_xyz(x, y, z)
+    h.set_detections(flags, poses=poses)
+    bufs = [p.array.view(np.int8)[:h.G] for p in pins]
+    for b in bufs:
+        b[:] = 0
+    for f in range(7):
+        h.enqueue_frame()
+        if f == 3:
+            h.to_occupancy_grid_async(bufs[0])
+    h.to_occupancy_grid_async(bufs[1])
+    rc = hip.hipStreamSynchronize(ctypes.c_void_p(h.stream()))   # the public stream only: the lanes are not waited for by the host
+    assert rc == 0
+    got = [b.copy() for b in bufs]
+    h.synchronize()
+    h.close()
+    for frames, g in zip((4, 7), got):
+        r, _ = make_handle(gvamd, config, perturbed=True)
+        r.upload_xyz(x, y, z)
+        r.set_detections(flags, poses=poses)
+        for _ in range(frames):
+            r.enqueue_frame()
+        r.synchronize()
+        want = r.to_occupancy_grid()[0]
+        r.close()
+        assert np.array_equal(g, want), f"grid read on the public stream after {frames} frames differs"
+    assert not np.array_equal(got[0], got[1])   # the scene does change between the two reads
+    for p in pins:
+        p.close()
 
 
 def test_standalone_calls_keep_frame_detections(gvamd):
