@@ -31,7 +31,7 @@ namespace gv {
 constexpr unsigned kKeyClip = 1u << 14;
 constexpr unsigned kStagedNone = 0xFFFFFFFFu;      // dropped point (non-finite, or outside with no ray)
 constexpr unsigned kStagedOutside = 0xFFFFFFFEu;   // out-of-map point waiting for the clip
-constexpr int kPartThreads = 1024;            // 16 wavefronts per chunk: the pass is latency bound, it wants every SIMD full
+constexpr int kPartThreads = 512;             // 8 wavefronts per chunk (fits beside a sector workgroup)
 constexpr int kTileThreads = 1024;
 
 // Diagnostic build only (-DGV_DIAG): thread 0 of every workgroup stamps the shader clock at phase
