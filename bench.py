@@ -440,8 +440,10 @@ def main():
     out = None
     if rank == 0:
         # per-kernel device time: HIP events recorded between the kernels on the stream they are launched
-        # on (gv_time_frame_stages, serial frame).  Read ~3 us per stage higher than rocprofv3's kernel
-        # durations (profiles/): the event records are in the interval.
+        # on (gv_time_frame_stages: serial frames, so every kernel runs alone).  Read ~3 us per stage higher
+        # than rocprofv3's kernel durations (profiles/rNN/serial_kernel_stats.csv): the event records are in
+        # the interval.  In the timed region two frames run side by side and every kernel is stretched by its
+        # neighbours (profiles/rNN/pipelined_kernel_stats.csv); `value` comes from that region.
         stages = h.time_frame_stages(max(10, min(a.steps, 50)))
         n_rays, n_visits = h.ray_stats()
         bytes_frame = 12.0 * N + 13.0 * G
@@ -477,6 +479,8 @@ def main():
             pmc, pmc_err = pmc_child_passes(config, "")
         kernels = []
         for st, ms in stages.items():
+            if st == "detections":
+                continue   # the rectangles ride the partition launch: no kernel of their own (the slot times two event records)
             kn = KERNEL_OF[st]
             c = (pmc or {}).get(kn, {})
             e = {"stage": st, "kernel": kn, "ms": ms, "traffic": c.get("hbm_bytes"),
