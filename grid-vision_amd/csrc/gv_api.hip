@@ -703,21 +703,24 @@ int enqueue_binning(gv_context *h, const DetSet &D, int p, int k, size_t lo, siz
 
 // sector ray stage over the end bitmaps of set p into its free-cell bitmaps; workgroups first,
 // first + stride, ... of the dispatch order (one GPU: 0, 1)
-int enqueue_sectors(gv_context *h, int p, int first, int stride, hipStream_t s)
+int enqueue_sectors(gv_context *h, int p, int first, int stride, hipStream_t s, hipEvent_t done = nullptr,
+                    bool *done_attached = nullptr)
 {
+  if (done_attached) *done_attached = false;
   if (!h->org.valid) return GV_OK;
   SectorArgs sa{};
   int rc = fill_sector_args(h, sa, p);
   if (rc) return rc;
   sa.wg_first = first;
   sa.wg_stride = stride;
-  launch_ray_sectors(sa, s);
+  const bool launched = launch_ray_sectors(sa, s, done);
+  if (done_attached) *done_attached = launched && done;
   GV_HIP(hipGetLastError());
   return GV_OK;
 }
 
 int enqueue_grid_pass(gv_context *h, int p, const Rect *rects, int32_t n_rects, bool counts, int32_t y0, int32_t y1,
-                      hipStream_t s)
+                      hipStream_t s, hipEvent_t done = nullptr)
 {
   FinalizeTileArgs t{};
   t.g = h->g;
@@ -734,7 +737,7 @@ int enqueue_grid_pass(gv_context *h, int p, const Rect *rects, int32_t n_rects, 
   t.counts = counts;
   t.y_begin = y0;
   t.y_end = y1;
-  launch_finalize_tiles(t, s);
+  if (!launch_finalize_tiles(t, s, done) && done) GV_HIP(hipEventRecord(done, s));
   GV_HIP(hipGetLastError());
   return GV_OK;
 }
@@ -829,26 +832,27 @@ int enqueue_frame_tiles(gv_context *h, bool pipelined, bool stage_events, bool s
   h->have_bbox_id = do_bbox;
   if (sharded) return sharded_tail(h, rects, n_rects);
 
-  // --- free-space ray stage
+  // --- free-space ray stage.  On a lane its completion event rides the kernel's own dispatch packet.
+  const int slot = (int)(h->frame_no % (uint64_t)gv_context::kRing);
+  bool sec_event = false;
   mark(s);
-  if (do_ray && (rc = enqueue_sectors(h, p, 0, 1, s))) return rc;
+  if (do_ray && (rc = enqueue_sectors(h, p, 0, 1, s, pipelined ? h->ev_sec[slot] : nullptr, &sec_event))) return rc;
   mark(s);
   if (stage_events) GV_HIP(hipEventRecord(h->ev[kStageRayMarch + 1], s));
 
   // --- grid pass, on the public stream: in order behind the previous frame's and behind whatever the
   // caller queued there (the download of the previous grid, a plain map update)
-  const int slot = (int)(h->frame_no % (uint64_t)gv_context::kRing);
   if (pipelined) {
-    GV_HIP(hipEventRecord(h->ev_sec[slot], s));
+    if (!sec_event) GV_HIP(hipEventRecord(h->ev_sec[slot], s));
     GV_HIP(hipStreamWaitEvent(h->stream, h->ev_sec[slot], 0));
     s = h->stream;
   }
   mark(s);
-  if ((rc = enqueue_grid_pass(h, p, rects, n_rects, do_bin, 0, h->g.ny, s))) return rc;
+  // ev_fin[slot] completes with the grid pass: this frame done => every earlier frame done
+  if ((rc = enqueue_grid_pass(h, p, rects, n_rects, do_bin, 0, h->g.ny, s, h->ev_fin[slot]))) return rc;
   mark(s);
   if (stage_events) GV_HIP(hipEventRecord(h->ev[kStageFinalize + 1], s));
-  // this frame done => every earlier frame done; cloud, detection set and buffer set remember their last user
-  GV_HIP(hipEventRecord(h->ev_fin[slot], s));
+  // cloud, detection set and buffer set remember their last user
   h->last_fin_slot = slot;
   h->set_fin_slot[p] = slot;
   CS.release_slot = slot;

@@ -155,7 +155,7 @@ struct SectorArgs {
   unsigned long long *dbg; // diagnostic phase stamps, 16 per workgroup (null in production)
 };
 size_t sector_lds_bytes(int cap, int marks_words, int log2m);
-void launch_ray_sectors(const SectorArgs &a, hipStream_t s);
+bool launch_ray_sectors(const SectorArgs &a, hipStream_t s, hipEvent_t done = nullptr);
 
 struct FinalizeTileArgs {
   GridParams g;
@@ -169,7 +169,7 @@ struct FinalizeTileArgs {
   bool counts;            // apply the hit/miss rule
   int32_t y_begin, y_end; // rows to finalise ([0, ny) on one GPU)
 };
-void launch_finalize_tiles(const FinalizeTileArgs &a, hipStream_t s);
+bool launch_finalize_tiles(const FinalizeTileArgs &a, hipStream_t s, hipEvent_t done = nullptr);
 void launch_miss_to_i32(const uint32_t *freeN, const uint32_t *freeT, int nx, int ny, int nx_pad, int ny_pad,
                         int32_t *out, hipStream_t s);
 

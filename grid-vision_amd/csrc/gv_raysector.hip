@@ -19,6 +19,8 @@
 // integer arithmetic: bit-exact against the oracle's literal march.
 #include "gv_kernels.hpp"
 
+#include <hip/hip_ext.h>
+
 #include <algorithm>
 
 namespace gv {
@@ -856,21 +858,26 @@ size_t sector_lds_bytes(int cap, int marks_words, int log2m)
   return sector_lds_layout(cap, marks_words, log2m).total;
 }
 
-void launch_ray_sectors(const SectorArgs &a, hipStream_t s)
+// `done` (optional): an event that completes with this kernel, carried by the kernel's own dispatch packet
+// (hipExtLaunchKernelGGL) -- a hipEventRecord behind it would put a marker packet into the queue and ~7 us
+// between this kernel and the next one of the stream.  Returns false when nothing was launched (the
+// caller then records the event the ordinary way).
+bool launch_ray_sectors(const SectorArgs &a, hipStream_t s, hipEvent_t done)
 {
-  if (!a.org.valid) return;
+  if (!a.org.valid) return false;
   const size_t lds = sector_lds_bytes(a.cap, a.marks_words, a.log2m);
   const int imax = std::max(std::max(a.org.cx, a.g.nx - 1 - a.org.cx), std::max(a.org.cy, a.g.ny - 1 - a.org.cy));
   // every wedge column lives in a register slot of one thread: CH * 512 >= imax
   const int total = a.wg_base[8];
-  if (a.wg_first >= total) return;
+  if (a.wg_first >= total) return false;
   const int grid = (total - a.wg_first + a.wg_stride - 1) / a.wg_stride;
   if (imax <= 4 * kSecThreads)
-    hipLaunchKernelGGL(k_ray_sectors<4>, dim3(grid), dim3(kSecThreads), lds, s, a);
+    hipExtLaunchKernelGGL(k_ray_sectors<4>, dim3(grid), dim3(kSecThreads), (uint32_t)lds, s, nullptr, done, 0, a);
   else if (imax <= 8 * kSecThreads)
-    hipLaunchKernelGGL(k_ray_sectors<8>, dim3(grid), dim3(kSecThreads), lds, s, a);
+    hipExtLaunchKernelGGL(k_ray_sectors<8>, dim3(grid), dim3(kSecThreads), (uint32_t)lds, s, nullptr, done, 0, a);
   else
-    hipLaunchKernelGGL(k_ray_sectors<16>, dim3(grid), dim3(kSecThreads), lds, s, a);
+    hipExtLaunchKernelGGL(k_ray_sectors<16>, dim3(grid), dim3(kSecThreads), (uint32_t)lds, s, nullptr, done, 0, a);
+  return true;
 }
 
 // ------------------------------------------------------ tile grid pass -----
@@ -987,13 +994,16 @@ __global__ void __launch_bounds__(256) k_finalize_tiles(FinalizeTileArgs a)
   }
 }
 
-void launch_finalize_tiles(const FinalizeTileArgs &a, hipStream_t s)
+// `done` (optional) completes with the kernel, on its own dispatch packet (see launch_ray_sectors);
+// false: nothing launched
+bool launch_finalize_tiles(const FinalizeTileArgs &a, hipStream_t s, hipEvent_t done)
 {
   const int rows = a.y_end - a.y_begin;
-  if (rows <= 0) return;
+  if (rows <= 0) return false;
   const dim3 grid((a.g.nx + 63) / 64, (rows + 63) / 64);
-  if (a.counts) hipLaunchKernelGGL(k_finalize_tiles<true>, grid, dim3(256), 0, s, a);
-  else hipLaunchKernelGGL(k_finalize_tiles<false>, grid, dim3(256), 0, s, a);
+  if (a.counts) hipExtLaunchKernelGGL(k_finalize_tiles<true>, grid, dim3(256), 0, s, nullptr, done, 0, a);
+  else hipExtLaunchKernelGGL(k_finalize_tiles<false>, grid, dim3(256), 0, s, nullptr, done, 0, a);
+  return true;
 }
 
 // miss read-back: free-cell bitmaps N | T as int32 0/1 per cell

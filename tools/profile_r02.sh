@@ -12,4 +12,4 @@ timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/s
 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_lidar -- python3 $GRAFT_REPO_ROOT/bench.py --steps 100 --warmup 10 --plain --cloud lidar > $OUT/stats_lidar.log 2>&1 || echo "lidar stats failed"
 bash $GRAFT_REPO_ROOT/tools/pmc_r02.sh $OUT/pmc > $OUT/pmc.log 2>&1 || echo "pmc failed"
 for d in serial pipelined lidar; do echo "== $d"; find $OUT/stats_$d -name "*kernel_stats.csv" | head -1 | xargs cat | head -8; done
-python3 $GRAFT_REPO_ROOT/tools/trace_timeline.py $OUT/stats_pipelined 24 0.6
+python3 $GRAFT_REPO_ROOT/tools/trace_timeline.py $OUT/stats_pipelined 24 0.5
