@@ -267,14 +267,16 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
     unsigned mx = 0;
     const int l = lo + 1, r = min(hi - 1, M - 1);
     if (l <= r) mx = rmq(l, r);
-    if (mx <= (unsigned)i && lo >= 0 && lo < M) {
+    // a boundary bucket is only walked when its own max reach (level 0 of the range-max table) says that
+    // one of its ends could decide the cell: beyond the threshold column most buckets hold short rays only
+    if (mx <= (unsigned)i && lo >= 0 && lo < M && (unsigned)lvl[lo] > (unsigned)i) {
       for (unsigned e = bstart[lo]; e < bstart[lo + 1]; ++e) {
         const unsigned p = abv[e];
         const int a = ab_a(p), bq = ab_b(p) * Q;
         if (bq >= Plo * a && (hi != lo || bq < Phi * a)) mx = max(mx, (unsigned)(a + (int)(p & 1u)));
       }
     }
-    if (mx <= (unsigned)i && hi >= 0 && hi < M && hi != lo) {
+    if (mx <= (unsigned)i && hi >= 0 && hi < M && hi != lo && (unsigned)lvl[hi] > (unsigned)i) {
       for (unsigned e = bstart[hi]; e < bstart[hi + 1]; ++e) {
         const unsigned p = abv[e];
         const int a = ab_a(p);
@@ -732,14 +734,14 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
         const unsigned e0l = bstart[loc], e1l = bstart[loc + 1];
         unsigned mxh = (hi >= 1) ? max(pf, bpf) : 0u;
         unsigned mxl = (lo + 1 <= M - 1) ? max(sf, bsf) : 0u;
-        if (mxh <= (unsigned)i && hi >= 0 && hi < M) {
+        if (mxh <= (unsigned)i && hi >= 0 && hi < M && (unsigned)lvl[hic] > (unsigned)i) {
           for (unsigned e = e0h; e < e1h; ++e) {
             const unsigned p = abv[e];
             const int a = ab_a(p);
             if (ab_b(p) * Q < Phi * a) mxh = max(mxh, (unsigned)(a + (int)(p & 1u)));
           }
         }
-        if (mxl <= (unsigned)i && lo >= 0 && lo < M) {
+        if (mxl <= (unsigned)i && lo >= 0 && lo < M && (unsigned)lvl[loc] > (unsigned)i) {
           for (unsigned e = e0l; e < e1l; ++e) {
             const unsigned p = abv[e];
             const int a = ab_a(p);

@@ -1,6 +1,7 @@
 """Diagnostic: per-phase shader-clock cycles of the sector kernel (GV_SECTOR_DBG=1)."""
 import ctypes as C, os, sys
 os.environ["GV_SECTOR_DBG"] = "1"
+os.environ["GV_PIPELINE"] = "0"   # one launch at a time writes the stamp buffer
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 os.environ.setdefault("GV_LIB_AB", os.path.join(ROOT, "gpurun_out", "libgv_diag.so"))   # -DGV_DIAG build: tools/build_diag.sh
 sys.path.insert(0, os.path.join(ROOT, "grid-vision_amd"))
@@ -59,7 +60,8 @@ if "detail" in sys.argv:
     nl = (buf[:, 13] & np.uint64(0xFFFFFFFF)).astype(np.int64); ts = (buf[:, 13] >> np.uint64(32)).astype(np.int64)
     print("T>=imax:", int((Tv >= im).sum()), " marched tails:", int(((Tv < im) & (nl <= 512) & (ts <= 32768)).sum()),
           " full-loop tails:", int(((Tv < im) & ~((nl <= 512) & (ts <= 32768))).sum()))
-    fl = (Tv < im) & ~((nl <= 512) & (ts <= 32768))
+    fl = ((Tv < im) & ~((nl <= 512) & (ts <= 32768)))[full]
+    Tv, mr, im, nn, nl, ts = Tv[full], mr[full], im[full], nn[full], nl[full], ts[full]
     print("full-loop WGs: mean edge", d[fl][:, 9].mean() if fl.any() else 0, "others mean edge", d[~fl][:, 9].mean())
     print("full-loop: columns beyond T mean", (im - Tv)[fl].mean() if fl.any() else 0, " of which beyond maxreach", np.maximum(im - np.maximum(mr, Tv), 0)[fl].mean() if fl.any() else 0)
     print("n ends: mean", nn.mean(), "max", nn.max())
