@@ -56,6 +56,7 @@ __device__ __forceinline__ unsigned wave_incl_scan_add(unsigned v)
 }
 
 // ------------------------------------------------------------- partition -----
+#define GV_KARG(field) load_karg<decltype(BinArgs::field)>(offsetof(BinArgs, field))
 template <bool RAY, bool BBOX, bool KEEPCELL>
 __global__ void __launch_bounds__(kPartThreads, 8) k_bin_partition(BinArgs a)
 {
@@ -110,12 +111,16 @@ __global__ void __launch_bounds__(kPartThreads, 8) k_bin_partition(BinArgs a)
       if (k < npts) {
         const uint32_t i = base + k;
         float bx, by, bz;
-        xform34(a.m_base, px[u], py[u], pz[u], bx, by, bz);
+        {
+          const Mat34f mb = GV_KARG(m_base);   // constants are fetched where they are used (gv_device.hpp, load_karg)
+          xform34(mb, px[u], py[u], pz[u], bx, by, bz);
+        }
         int cell = -1;
         if (isfinite(bx) && isfinite(by) && isfinite(bz)) {
           int ix, iy;
-          if (get_index_fast(a.g, (double)bx, (double)by, ix, iy)) {
-            cell = iy * a.g.nx + ix;
+          const GridParams g = GV_KARG(g);
+          if (get_index_fast(g, (double)bx, (double)by, ix, iy)) {
+            cell = iy * g.nx + ix;
             const unsigned tile = (unsigned)((iy >> kBinTileLog) * a.tiles_x + (ix >> kBinTileLog));
             st = (tile << 16) | (unsigned)(((iy & (kBinTile - 1)) << kBinTileLog) | (ix & (kBinTile - 1)));
             atomicAdd(&hist[tile], 1u);
@@ -126,8 +131,12 @@ __global__ void __launch_bounds__(kPartThreads, 8) k_bin_partition(BinArgs a)
         if (KEEPCELL) a.cell_idx[i] = cell;
         if (BBOX) {
           float cx, cy, cz;
-          xform34(a.m_cam, px[u], py[u], pz[u], cx, cy, cz);
-          a.bbox_id[i] = (int16_t)first_bbox(a.cam, lbt, cx, cy, cz);
+          {
+            const Mat34f mc = GV_KARG(m_cam);
+            xform34(mc, px[u], py[u], pz[u], cx, cy, cz);
+          }
+          const CamK ck = GV_KARG(cam);
+          a.bbox_id[i] = (int16_t)first_bbox(ck, lbt, cx, cy, cz);
         }
       }
       staged[k] = st;

@@ -11,11 +11,33 @@
 #include <hip/hip_runtime.h>
 
 #include <float.h>
+#include <stddef.h>
 #include <math.h>
 
 #include "gv_kernels.hpp"
 
 namespace gv {
+
+// A kernel argument field, loaded from the kernarg segment AT THE POINT OF USE.  The compiler loads every
+// field of a by-value argument struct at the top of the kernel and keeps it in SGPRs for as long as some
+// loop uses it; a kernel whose loops need more constants than the ~96 SGPRs of a fully occupied SIMD then
+// spills them to VGPR lanes and pays a v_readlane (a VALU issue slot) per use.  Reading the field through a
+// pointer the optimiser cannot see through turns that into a scalar load (SMEM, its own issue port, served
+// from the scalar cache) whose registers die after the use.  `off` = offsetof(the kernel's single argument
+// struct, field).
+#define GV_AS4 __attribute__((address_space(4)))
+template <typename T>
+__device__ __forceinline__ T load_karg(size_t off)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+  const GV_AS4 char *kp = (const GV_AS4 char *)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(kp));
+  return *(const GV_AS4 T *)(kp + off);
+#else
+  (void)off;
+  return T{};
+#endif
+}
 
 // pcl::detail::Transformer<float>::se3 (SSE2 path): x*c0 + (y*c1 + (z*c2 + c3)),
 // fp32, no FMA.  Call site: src/grid_vision_node.cpp:304.
