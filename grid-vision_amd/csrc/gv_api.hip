@@ -1146,8 +1146,11 @@ int gv_create(gv_handle *out, uint8_t grid_x, uint8_t grid_y, double resolution,
   h->streams[0] = h->stream;
   h->streams[1] = h->stream2;
   h->streams[2] = h->stream3;
-  for (auto &e : h->ev_fin) GV_C(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-  for (auto &e : h->ev_sec) GV_C(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  // Ordering-only events between queues of this device (and a completion flag the host polls): nobody reads
+  // memory on the strength of them -- results are read in stream order on the public stream or after a
+  // stream synchronise -- so the kernels that carry them need no system-scope release at their end.
+  for (auto &e : h->ev_fin) GV_C(hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventDisableSystemFence));
+  for (auto &e : h->ev_sec) GV_C(hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventDisableSystemFence));
   GV_C(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
   for (auto &c : h->cloud) GV_C(hipEventCreateWithFlags(&c.ready, hipEventDisableTiming));
   for (auto &d : h->det) GV_C(hipEventCreateWithFlags(&d.ready, hipEventDisableTiming));
