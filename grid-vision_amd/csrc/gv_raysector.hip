@@ -989,10 +989,13 @@ __global__ void __launch_bounds__(256) k_finalize_tiles(FinalizeTileArgs a)
     l4.w = cell_update_t(l4.w, k3, COUNTS, hb & 8u, fb & 8u);
     float4 p4;
     p4.x = sigmoid_ref_t(l4.x); p4.y = sigmoid_ref_t(l4.y); p4.z = sigmoid_ref_t(l4.z); p4.w = sigmoid_ref_t(l4.w);
-    *reinterpret_cast<float4 *>(a.log_odds + c) = l4;
-    *reinterpret_cast<float4 *>(a.occupancy + c) = p4;
+    *reinterpret_cast<float4 *>(a.log_odds + c) = l4;   // read again by the next frame
+    // occupancy and the packed grid are outputs nobody reads on the device: streaming stores
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    v4f np4; np4.x = p4.x; np4.y = p4.y; np4.z = p4.z; np4.w = p4.w;
+    __builtin_nontemporal_store(np4, reinterpret_cast<v4f *>(a.occupancy + c));
     const unsigned packed = pack_i8_t(p4.w) | (pack_i8_t(p4.z) << 8) | (pack_i8_t(p4.y) << 16) | (pack_i8_t(p4.x) << 24);
-    *reinterpret_cast<unsigned *>(a.occ_i8 + ((size_t)a.g.G - 4 - c)) = packed;
+    __builtin_nontemporal_store(packed, reinterpret_cast<unsigned *>(a.occ_i8 + ((size_t)a.g.G - 4 - c)));
   }
 }
 
