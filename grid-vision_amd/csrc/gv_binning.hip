@@ -136,7 +136,7 @@ __global__ void __launch_bounds__(kPartThreads, 8) k_bin_partition(BinArgs a)
             xform34(mc, px[u], py[u], pz[u], cx, cy, cz);
           }
           const CamK ck = GV_KARG(cam);
-          a.bbox_id[i] = (int16_t)first_bbox(ck, lbt, cx, cy, cz);
+          __builtin_nontemporal_store((int16_t)first_bbox(ck, lbt, cx, cy, cz), &a.bbox_id[i]);   // host-read output
         }
       }
       staged[k] = st;
