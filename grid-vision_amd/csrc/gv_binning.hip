@@ -33,6 +33,7 @@ constexpr unsigned kStagedNone = 0xFFFFFFFFu;      // dropped point (non-finite,
 constexpr unsigned kStagedOutside = 0xFFFFFFFEu;   // out-of-map point waiting for the clip
 constexpr int kPartThreads = 512;             // 8 wavefronts per chunk (fits beside a sector workgroup)
 constexpr int kTileThreads = 1024;
+constexpr uint32_t kInLaneKeys = 128;         // tile pass: a segment up to this long is histogrammed by its own lane
 
 // Diagnostic build only (-DGV_DIAG): thread 0 of every workgroup stamps the shader clock at phase
 // boundaries into a buffer nothing else reads (tools/bin_phases.py); absent from the shipped kernels.
@@ -359,7 +360,12 @@ __global__ void __launch_bounds__(kTileThreads) k_bin_tiles(BinTileArgs a)
           v[q] = make_uint4(0, 0, 0, 0);
           if (hi > wb + 8u * (uint32_t)q) v[q] = keys4[(wb >> 3) + (uint32_t)q];   // (the buffer has slack past the last chunk)
         }
-        if (hi > wb + 32u) {
+        // what lies beyond: a long remainder (a crowded tile: hundreds of keys per segment) goes to the list and
+        // gets a wavefront; a medium one (the ring of tiles around the sensor: 40..128 keys per segment) stays in
+        // this lane, four windows at a time -- a wavefront per 5-window remainder would run 59 idle lanes through
+        // a full load latency, 30 times in a row (measured: 80 k cycles for such a tile, the slowest of the launch)
+        const bool listed = hi > wb + 32u && hi - wb > kInLaneKeys;
+        if (listed) {
           const unsigned slot = atomicAdd(&s_nlong, 1u);
           s_lbase[slot] = wb + 32u;
           s_llen[slot] = hi - (wb + 32u);
@@ -367,6 +373,18 @@ __global__ void __launch_bounds__(kTileThreads) k_bin_tiles(BinTileArgs a)
 #pragma unroll
         for (int q = 0; q < 4; ++q)
           if (hi > wb + 8u * (uint32_t)q) add_window(v[q], wb + 8u * (uint32_t)q, lo, hi);
+        if (!listed) {
+          for (uint32_t w2 = wb + 32u; w2 < hi; w2 += 32u) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              v[q] = make_uint4(0, 0, 0, 0);
+              if (hi > w2 + 8u * (uint32_t)q) v[q] = keys4[(w2 >> 3) + (uint32_t)q];
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              if (hi > w2 + 8u * (uint32_t)q) add_window(v[q], w2 + 8u * (uint32_t)q, lo, hi);
+          }
+        }
       }
     }
     desc = next;

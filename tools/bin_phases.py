@@ -40,4 +40,10 @@ for which, label in ((0, "k_bin_partition"), (1, "k_bin_tiles")):
         print(f"  {nme:10s} mean {d[:, k].mean():9.0f}  p50 {np.median(d[:, k]):9.0f}  max {d[:, k].max():9.0f}")
     tot = t[:, 5] - t[:, 0]
     print(f"  total      mean {tot.mean():9.0f}  max {tot.max():9.0f}")
+    if "detail" in sys.argv:
+        idx = np.nonzero(live)[0]
+        order = np.argsort(-d[:, 2])[:14]
+        print("  slowest in phase 2 (workgroup index: phase cycles):")
+        for o in order:
+            print(f"    wg {idx[o]:5d}: {d[o].tolist()}  start {int(t[o, 0] - t[:, 0].min())}")
 print("stages", h.time_frame_stages(20))
