@@ -331,6 +331,16 @@ __global__ void __launch_bounds__(kTileThreads) k_bin_tiles(BinTileArgs a)
   // keys [lo, hi) of the aligned window at key index wb (8 keys = one uint4)
   auto add_window = [&](const uint4 &v, uint32_t wb, uint32_t lo, uint32_t hi) {
     const unsigned wv[4] = {v.x, v.y, v.z, v.w};
+    if (wb >= lo && wb + 8u <= hi && !((v.x | v.y | v.z | v.w) & (kKeyClip | (kKeyClip << 16)))) {
+      // a whole window inside the segment and no clipped end in it (every window of a long segment but its first
+      // and last): eight plain increments
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        atomicAdd(&hist[wv[u] & (kBinTileCells - 1)], 1u);
+        atomicAdd(&hist[(wv[u] >> 16) & (kBinTileCells - 1)], 1u);
+      }
+      return;
+    }
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const uint32_t pos = wb + (uint32_t)u;
@@ -391,6 +401,7 @@ __global__ void __launch_bounds__(kTileThreads) k_bin_tiles(BinTileArgs a)
     kb0 = kbn;
     __syncthreads();
     const unsigned nl = s_nlong;   // <= 1024 per round
+    GV_STAMP(a.dbg, 6 + 2 * (round > 0));   // diagnostic: in-lane part of the round done
     // long remainders: wavefront per list entry, a lane per aligned 8-key window, four windows in flight per lane
     for (unsigned e = (unsigned)wave; e < nl; e += kTileThreads / 64) {
       const uint32_t lo = s_lbase[e], hi = lo + s_llen[e];   // lo is window aligned
@@ -407,6 +418,7 @@ __global__ void __launch_bounds__(kTileThreads) k_bin_tiles(BinTileArgs a)
           if (w0 + 64u * (uint32_t)q < nwin) add_window(v[q], lo + 8u * (w0 + 64u * (uint32_t)q), lo, hi);
       }
     }
+    GV_STAMP(a.dbg, 7 + 2 * (round > 0));   // diagnostic: wavefront 0 done with its list entries
   }
   __syncthreads();
   GV_STAMP(a.dbg, 3);   // keys histogrammed
@@ -435,11 +447,15 @@ __global__ void __launch_bounds__(kTileThreads) k_bin_tiles(BinTileArgs a)
     __syncthreads();
     if (s_ticket != k - 1u) return;
     for (int c = tid; c < kBinTileCells / 4; c += kTileThreads) {
-      uint4 v = make_uint4(0, 0, 0, 0);
-      for (unsigned q = 0; q < k; ++q) {
-        const uint4 p = reinterpret_cast<const uint4 *>(slab + (size_t)q * stride)[c];
-        v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
+      uint4 p[kBinSplitMax];   // every share's vector requested before the first is added (k <= kBinSplitMax)
+#pragma unroll
+      for (unsigned q = 0; q < (unsigned)kBinSplitMax; ++q) {
+        p[q] = make_uint4(0, 0, 0, 0);
+        if (q < k) p[q] = reinterpret_cast<const uint4 *>(slab + (size_t)q * stride)[c];
       }
+      uint4 v = make_uint4(0, 0, 0, 0);
+#pragma unroll
+      for (unsigned q = 0; q < (unsigned)kBinSplitMax; ++q) { v.x += p[q].x; v.y += p[q].y; v.z += p[q].z; v.w += p[q].w; }
       reinterpret_cast<uint4 *>(hist)[c] = v;
     }
     if (tid < 512) {

@@ -45,5 +45,5 @@ for which, label in ((0, "k_bin_partition"), (1, "k_bin_tiles")):
         order = np.argsort(-d[:, 2])[:14]
         print("  slowest in phase 2 (workgroup index: phase cycles):")
         for o in order:
-            print(f"    wg {idx[o]:5d}: {d[o].tolist()}  start {int(t[o, 0] - t[:, 0].min())}")
+            print(f"    wg {idx[o]:5d}: {d[o].tolist()}  start {int(t[o, 0] - t[:, 0].min())}  in-lane {int(t[o, 6] - t[o, 2])} list(w0) {int(t[o, 7] - t[o, 6])} wait {int(t[o, 3] - t[o, 7])}")
 print("stages", h.time_frame_stages(20))
