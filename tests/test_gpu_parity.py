@@ -973,22 +973,25 @@ def test_streaming_ingest_matches_oracle(gvamd):
         pins.append((px, py, pz))
         clouds.append((x, y, z))
         dets.append((synth.detections(3, 10 + 5 * f, seed_extra=f), synth.lshape_poses(config, 8 + 3 * f, seed_extra=f)))
-    flags = gvamd.FRAME_BIN | gvamd.FRAME_RAYMARCH | gvamd.FRAME_BBOX_TEST
-    for upto in (1, 2, 6):
+    flags = gvamd.FRAME_BIN | gvamd.FRAME_RAYMARCH | gvamd.FRAME_BBOX_TEST | gvamd.FRAME_KEEP_CELL_IDX
+    # frame counts 1, 2, 4, 3, 5, 12: the last frame ends on either lane, and 12 frames wrap the four buffer
+    # sets three times (the host back-pressure of gv_frame_enqueue is exercised)
+    for upto, reps in ((1, 1), (1, 2), (2, 2), (3, 1), (5, 1), (6, 2)):
         h, tfs = make_handle(gvamd, config, perturbed=True)
         og = ol.OGrid(g.grid_x, g.grid_y, g.resolution)
-        for rep in range(2):
+        for rep in range(reps):
             for f in range(upto):
                 px, py, pz = pins[f]
                 h.upload_xyz_async(px.array, py.array, pz.array)
                 h.set_detections_async(flags, bboxes=dets[f][0], poses=dets[f][1])
                 h.enqueue_frame()
         h.synchronize()
-        for rep in range(2):
+        for rep in range(reps):
             for f in range(upto):
-                hits, _, _, ids, _ = oracle_frame(og, tfs, *clouds[f], dets[f][0], dets[f][1])
+                hits, cells, _, ids, _ = oracle_frame(og, tfs, *clouds[f], dets[f][0], dets[f][1])
         assert np.array_equal(h.hits(), hits)
         assert np.array_equal(h.bbox_id(), ids)
+        assert np.array_equal(h.cell_idx(), cells)
         nlo, _, _ = check_grid(h, og)
         assert nlo == 0
         h.close()
