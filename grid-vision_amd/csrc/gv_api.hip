@@ -255,7 +255,7 @@ int set_device_only(gv_context *h)
 }
 
 // Every entry point except the streaming ones (gv_frame_enqueue, gv_*_async, the uploads) starts from
-// idle streams: its work on stream A then sees every earlier frame and upload completed.
+// idle streams: its work on the public stream then sees every earlier frame and upload completed.
 int use_device(gv_context *h)
 {
   GV_HIP(hipSetDevice(h->device));
