@@ -439,11 +439,11 @@ def main():
 
     out = None
     if rank == 0:
-        # per-kernel device time: HIP events recorded between the kernels on the stream they are launched
-        # on (gv_time_frame_stages: serial frames, so every kernel runs alone).  Read ~3 us per stage higher
-        # than rocprofv3's kernel durations (profiles/rNN/serial_kernel_stats.csv): the event records are in
-        # the interval.  In the timed region two frames run side by side and every kernel is stretched by its
-        # neighbours (profiles/rNN/pipelined_kernel_stats.csv); `value` comes from that region.
+        # per-kernel device time (gv_time_frame_stages: serial frames, so every kernel runs alone): each kernel
+        # carries a start and an end HIP event on its own dispatch packet (hipExtLaunchKernelGGL), so the
+        # figure is the kernel's duration as rocprofv3 reports it (profiles/rNN/serial_kernel_stats.csv), not
+        # an interval between event records.  In the timed region two frames run side by side and every kernel
+        # is stretched by its neighbours (profiles/rNN/pipelined_kernel_stats.csv); `value` comes from there.
         stages = h.time_frame_stages(max(10, min(a.steps, 50)))
         n_rays, n_visits = h.ray_stats()
         bytes_frame = 12.0 * N + 13.0 * G

@@ -189,6 +189,10 @@ struct gv_context {
   size_t sh_xchg_cap = 0;
 
   hipEvent_t ev[kNumStages + 1]{};
+  // stage timing (gv_time_frame_stages): start / end of the partition, tile-pass, sector and grid-pass kernels,
+  // taken from their own dispatch packets; kt_used: the kernel was launched in the frame just timed
+  hipEvent_t kt[4][2]{};
+  bool kt_used[4]{};
   std::string err;
 };
 
@@ -624,7 +628,7 @@ int check_frame_flags(const gv_context *h, uint32_t fl)
 // (or not), per-point outputs and binning scratch; the end bitmaps of buffer set p; zeroes the set's
 // free-cell bitmaps.  ev_* are stage-timing events or null.
 int enqueue_binning(gv_context *h, const DetSet &D, int p, int k, size_t lo, size_t n, bool keep_cell, bool do_ray,
-                    bool do_bbox, bool write_hits, hipEvent_t ev_points, Rect *fold_rects = nullptr)
+                    bool do_bbox, bool write_hits, hipEvent_t ev_points, Rect *fold_rects = nullptr, bool timed = false)
 {
   hipStream_t s = h->streams[k];
   const uint32_t chunk = bin_chunk_for(n);
@@ -661,7 +665,8 @@ int enqueue_binning(gv_context *h, const DetSet &D, int p, int k, size_t lo, siz
 #ifdef GV_DIAG
   a.dbg = h->d_bin_dbg[0];
 #endif
-  launch_bin_partition(a, s);
+  launch_bin_partition(a, s, timed ? h->kt[0][0] : nullptr, timed ? h->kt[0][1] : nullptr);
+  if (timed) h->kt_used[0] = n > 0 || fold_rects;
   if (do_bbox && !bbox_fused) {
     PointsArgs pa{};
     pa.x = a.x; pa.y = a.y; pa.z = a.z;
@@ -695,7 +700,8 @@ int enqueue_binning(gv_context *h, const DetSet &D, int p, int k, size_t lo, siz
 #ifdef GV_DIAG
   t.dbg = h->d_bin_dbg[1];
 #endif
-  launch_bin_tiles(t, (uint32_t)(n / kBinSplitKeys), s);
+  launch_bin_tiles(t, (uint32_t)(n / kBinSplitKeys), s, timed ? h->kt[1][0] : nullptr, timed ? h->kt[1][1] : nullptr);
+  if (timed) h->kt_used[1] = true;
   h->bin_parity[k] ^= 1;
   GV_HIP(hipGetLastError());
   return GV_OK;
@@ -704,7 +710,7 @@ int enqueue_binning(gv_context *h, const DetSet &D, int p, int k, size_t lo, siz
 // sector ray stage over the end bitmaps of set p into its free-cell bitmaps; workgroups first,
 // first + stride, ... of the dispatch order (one GPU: 0, 1)
 int enqueue_sectors(gv_context *h, int p, int first, int stride, hipStream_t s, hipEvent_t done = nullptr,
-                    bool *done_attached = nullptr)
+                    bool *done_attached = nullptr, hipEvent_t t0 = nullptr)
 {
   if (done_attached) *done_attached = false;
   if (!h->org.valid) return GV_OK;
@@ -713,14 +719,14 @@ int enqueue_sectors(gv_context *h, int p, int first, int stride, hipStream_t s, 
   if (rc) return rc;
   sa.wg_first = first;
   sa.wg_stride = stride;
-  const bool launched = launch_ray_sectors(sa, s, done);
+  const bool launched = launch_ray_sectors(sa, s, done, t0);
   if (done_attached) *done_attached = launched && done;
   GV_HIP(hipGetLastError());
   return GV_OK;
 }
 
 int enqueue_grid_pass(gv_context *h, int p, const Rect *rects, int32_t n_rects, bool counts, int32_t y0, int32_t y1,
-                      hipStream_t s, hipEvent_t done = nullptr)
+                      hipStream_t s, hipEvent_t done = nullptr, hipEvent_t t0 = nullptr, bool *launched = nullptr)
 {
   FinalizeTileArgs t{};
   t.g = h->g;
@@ -737,7 +743,9 @@ int enqueue_grid_pass(gv_context *h, int p, const Rect *rects, int32_t n_rects, 
   t.counts = counts;
   t.y_begin = y0;
   t.y_end = y1;
-  if (!launch_finalize_tiles(t, s, done) && done) GV_HIP(hipEventRecord(done, s));
+  const bool ran = launch_finalize_tiles(t, s, done, t0);
+  if (launched) *launched = ran;
+  if (!ran && done) GV_HIP(hipEventRecord(done, s));
   GV_HIP(hipGetLastError());
   return GV_OK;
 }
@@ -789,7 +797,10 @@ int enqueue_frame_tiles(gv_context *h, bool pipelined, bool stage_events, bool s
   auto mark = [](hipStream_t) {};
 #endif
   if ((rc = wait_inputs(h, CS, D, k))) return rc;
-  if (stage_events) GV_HIP(hipEventRecord(h->ev[0], s));
+  if (stage_events) {
+    GV_HIP(hipEventRecord(h->ev[0], s));
+    for (bool &u : h->kt_used) u = false;
+  }
 
   // --- detections -> rectangles.  Base-frame poses of a binning frame ride the partition launch (one
   // extra workgroup) instead of a launch of their own; network outputs go through the vision kernels.
@@ -804,7 +815,7 @@ int enqueue_frame_tiles(gv_context *h, bool pipelined, bool stage_events, bool s
   mark(s);
   if (do_bin) {
     if ((rc = enqueue_binning(h, D, p, k, 0, h->n, keep_cell, do_ray, do_bbox, true,
-                              stage_events ? h->ev[kStagePoints + 1] : nullptr, fold_rects ? rects : nullptr)))
+                              stage_events ? h->ev[kStagePoints + 1] : nullptr, fold_rects ? rects : nullptr, stage_events)))
       return rc;
   } else {
     if (do_bbox) {
@@ -836,7 +847,10 @@ int enqueue_frame_tiles(gv_context *h, bool pipelined, bool stage_events, bool s
   const int slot = (int)(h->frame_no % (uint64_t)gv_context::kRing);
   bool sec_event = false;
   mark(s);
-  if (do_ray && (rc = enqueue_sectors(h, p, 0, 1, s, pipelined ? h->ev_sec[slot] : nullptr, &sec_event))) return rc;
+  if (do_ray && (rc = enqueue_sectors(h, p, 0, 1, s, pipelined ? h->ev_sec[slot] : (stage_events ? h->kt[2][1] : nullptr), &sec_event,
+                                      stage_events ? h->kt[2][0] : nullptr)))
+    return rc;
+  if (stage_events) h->kt_used[2] = sec_event;
   mark(s);
   if (stage_events) GV_HIP(hipEventRecord(h->ev[kStageRayMarch + 1], s));
 
@@ -849,7 +863,12 @@ int enqueue_frame_tiles(gv_context *h, bool pipelined, bool stage_events, bool s
   }
   mark(s);
   // ev_fin[slot] completes with the grid pass: this frame done => every earlier frame done
-  if ((rc = enqueue_grid_pass(h, p, rects, n_rects, do_bin, 0, h->g.ny, s, h->ev_fin[slot]))) return rc;
+  if (stage_events) {   // stage timing: the kernel carries its own start / end events, ev_fin follows as a marker
+    bool ran = false;
+    if ((rc = enqueue_grid_pass(h, p, rects, n_rects, do_bin, 0, h->g.ny, s, h->kt[3][1], h->kt[3][0], &ran))) return rc;
+    h->kt_used[3] = ran;
+    GV_HIP(hipEventRecord(h->ev_fin[slot], s));
+  } else if ((rc = enqueue_grid_pass(h, p, rects, n_rects, do_bin, 0, h->g.ny, s, h->ev_fin[slot]))) return rc;
   mark(s);
   if (stage_events) GV_HIP(hipEventRecord(h->ev[kStageFinalize + 1], s));
   // cloud, detection set and buffer set remember their last user
@@ -1252,6 +1271,8 @@ int gv_create(gv_handle *out, uint8_t grid_x, uint8_t grid_y, double resolution,
     GV_C(hipMalloc(reinterpret_cast<void **>(&h->ray_list), G * sizeof(uint32_t)));
   }
   for (auto &e : h->ev) GV_C(hipEventCreate(&e));
+  for (auto &pr : h->kt)
+    for (auto &e : pr) GV_C(hipEventCreate(&e));
 #undef GV_C
   if (ensure_det_shared(h, 64) != GV_OK) return fail(GV_ERR_HIP);
   for (auto &d : h->det)
@@ -1305,6 +1326,9 @@ int gv_destroy(gv_handle h)
   }
   for (auto &e : h->ev)
     if (e) (void)hipEventDestroy(e);
+  for (auto &pr : h->kt)
+    for (auto &e : pr)
+      if (e) (void)hipEventDestroy(e);
   for (auto &e : h->ev_fin)
     if (e) (void)hipEventDestroy(e);
   for (auto &e : h->ev_sec)
@@ -2034,7 +2058,14 @@ int gv_time_frame_stages(gv_handle h, int32_t frames, float *stage_ms)
     GV_HIP(hipEventSynchronize(h->ev[kNumStages]));
     for (int s = 0; s < kNumStages; ++s) {
       float ms = 0.0f;
-      GV_HIP(hipEventElapsedTime(&ms, h->ev[s], h->ev[s + 1]));
+      // tile path: the four kernels report their own start / end (dispatch-packet timestamps, the figure
+      // rocprofv3 shows); everything else is the interval between two event records on the stream
+      const int kq = s - kStagePoints;   // points, tile pass ("ray ends"), sectors, grid pass
+      if (sector_path(h) && kq >= 0 && kq < 4) {
+        if (h->kt_used[kq]) GV_HIP(hipEventElapsedTime(&ms, h->kt[kq][0], h->kt[kq][1]));
+      } else {
+        GV_HIP(hipEventElapsedTime(&ms, h->ev[s], h->ev[s + 1]));
+      }
       stage_ms[s] += ms;
     }
   }

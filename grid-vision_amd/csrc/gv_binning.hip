@@ -22,6 +22,8 @@
 // Keys: bits 0..13 = cell inside the tile (ly << 7 | lx), bit 14 = clipped ray end (X2: end of
 // an out-of-map point's ray on the map border, counts as traversed), bit 15 unused.
 #include "gv_kernels.hpp"
+
+#include <hip/hip_ext.h>
 #include "gv_device.hpp"
 
 #include <algorithm>
@@ -540,13 +542,15 @@ size_t bin_bbox_lds(int nb_pad, const BBoxTest &bt)
 
 bool bin_bbox_fits(int nb, const BBoxTest &bt) { return bin_bbox_lds((nb + 3) & ~3, bt) <= kBinBBoxLdsMax; }
 
-void launch_bin_partition(const BinArgs &a, hipStream_t s)
+// t0 / t1 (optional, timing-enabled events): start and end of the kernel itself, taken from its dispatch packet
+// (hipExtLaunchKernelGGL) -- the per-kernel times of gv_time_frame_stages, free of the event-record overhead
+void launch_bin_partition(const BinArgs &a, hipStream_t s, hipEvent_t t0, hipEvent_t t1)
 {
   const uint32_t grid = a.n_wg + (a.n_rect_poses > 0 ? 1u : 0u);
   if (grid == 0) return;
   const size_t lds = bin_partition_lds(a.chunk, a.n_tiles) + (a.do_bbox ? bin_bbox_lds(a.nb_pad, a.bt) : 0);
   const bool keep = a.cell_idx != nullptr;
-#define GV_BP(R, X, K) hipLaunchKernelGGL((k_bin_partition<R, X, K>), dim3(grid), dim3(kPartThreads), lds, s, a)
+#define GV_BP(R, X, K) hipExtLaunchKernelGGL((k_bin_partition<R, X, K>), dim3(grid), dim3(kPartThreads), (uint32_t)lds, s, t0, t1, 0, a)
   if (a.do_ray && a.do_bbox && keep) GV_BP(true, true, true);
   else if (a.do_ray && a.do_bbox) GV_BP(true, true, false);
   else if (a.do_ray && keep) GV_BP(true, false, true);
@@ -558,11 +562,11 @@ void launch_bin_partition(const BinArgs &a, hipStream_t s)
 #undef GV_BP
 }
 
-void launch_bin_tiles(const BinTileArgs &a, uint32_t n_helpers, hipStream_t s)
+void launch_bin_tiles(const BinTileArgs &a, uint32_t n_helpers, hipStream_t s, hipEvent_t t0, hipEvent_t t1)
 {
   const uint32_t grid = (uint32_t)(((a.n_tiles + 7) >> 3) << 3) + n_helpers;   // primaries by XCD run, then the helpers
-  if (a.hits) hipLaunchKernelGGL(k_bin_tiles<true>, dim3(grid), dim3(kTileThreads), 0, s, a);
-  else hipLaunchKernelGGL(k_bin_tiles<false>, dim3(grid), dim3(kTileThreads), 0, s, a);
+  if (a.hits) hipExtLaunchKernelGGL(k_bin_tiles<true>, dim3(grid), dim3(kTileThreads), 0, s, t0, t1, 0, a);
+  else hipExtLaunchKernelGGL(k_bin_tiles<false>, dim3(grid), dim3(kTileThreads), 0, s, t0, t1, 0, a);
 }
 
 }  // namespace gv

@@ -111,7 +111,7 @@ struct BinArgs {
 constexpr size_t kBinBBoxLdsMax = 24 * 1024;   // LDS the partition kernel may spend on the bbox-test tables
 uint32_t bin_chunk_for(size_t n);
 bool bin_bbox_fits(int nb, const BBoxTest &bt);
-void launch_bin_partition(const BinArgs &a, hipStream_t s);
+void launch_bin_partition(const BinArgs &a, hipStream_t s, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr);
 
 struct BinTileArgs {
   int32_t nx, ny, tiles_x, tiles_y, n_tiles;
@@ -130,7 +130,7 @@ struct BinTileArgs {
   unsigned long long *dbg;                 // diagnostic build: 16 clock stamps per workgroup (null in production)
 };
 // n_helpers >= n / split_keys extra workgroups serve the shares 1.. of crowded tiles
-void launch_bin_tiles(const BinTileArgs &a, uint32_t n_helpers, hipStream_t s);
+void launch_bin_tiles(const BinTileArgs &a, uint32_t n_helpers, hipStream_t s, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr);
 
 // ---- sector/gather ray stage + tile grid pass (gv_raysector.hip) ----
 struct SectorArgs {
@@ -155,7 +155,7 @@ struct SectorArgs {
   unsigned long long *dbg; // diagnostic phase stamps, 16 per workgroup (null in production)
 };
 size_t sector_lds_bytes(int cap, int marks_words, int log2m);
-bool launch_ray_sectors(const SectorArgs &a, hipStream_t s, hipEvent_t done = nullptr);
+bool launch_ray_sectors(const SectorArgs &a, hipStream_t s, hipEvent_t done = nullptr, hipEvent_t t0 = nullptr);
 
 struct FinalizeTileArgs {
   GridParams g;
@@ -169,7 +169,7 @@ struct FinalizeTileArgs {
   bool counts;            // apply the hit/miss rule
   int32_t y_begin, y_end; // rows to finalise ([0, ny) on one GPU)
 };
-bool launch_finalize_tiles(const FinalizeTileArgs &a, hipStream_t s, hipEvent_t done = nullptr);
+bool launch_finalize_tiles(const FinalizeTileArgs &a, hipStream_t s, hipEvent_t done = nullptr, hipEvent_t t0 = nullptr);
 void launch_miss_to_i32(const uint32_t *freeN, const uint32_t *freeT, int nx, int ny, int nx_pad, int ny_pad,
                         int32_t *out, hipStream_t s);
 

@@ -864,7 +864,7 @@ size_t sector_lds_bytes(int cap, int marks_words, int log2m)
 // (hipExtLaunchKernelGGL) -- a hipEventRecord behind it would put a marker packet into the queue and ~7 us
 // between this kernel and the next one of the stream.  Returns false when nothing was launched (the
 // caller then records the event the ordinary way).
-bool launch_ray_sectors(const SectorArgs &a, hipStream_t s, hipEvent_t done)
+bool launch_ray_sectors(const SectorArgs &a, hipStream_t s, hipEvent_t done, hipEvent_t t0)
 {
   if (!a.org.valid) return false;
   const size_t lds = sector_lds_bytes(a.cap, a.marks_words, a.log2m);
@@ -874,11 +874,11 @@ bool launch_ray_sectors(const SectorArgs &a, hipStream_t s, hipEvent_t done)
   if (a.wg_first >= total) return false;
   const int grid = (total - a.wg_first + a.wg_stride - 1) / a.wg_stride;
   if (imax <= 4 * kSecThreads)
-    hipExtLaunchKernelGGL(k_ray_sectors<4>, dim3(grid), dim3(kSecThreads), (uint32_t)lds, s, nullptr, done, 0, a);
+    hipExtLaunchKernelGGL(k_ray_sectors<4>, dim3(grid), dim3(kSecThreads), (uint32_t)lds, s, t0, done, 0, a);
   else if (imax <= 8 * kSecThreads)
-    hipExtLaunchKernelGGL(k_ray_sectors<8>, dim3(grid), dim3(kSecThreads), (uint32_t)lds, s, nullptr, done, 0, a);
+    hipExtLaunchKernelGGL(k_ray_sectors<8>, dim3(grid), dim3(kSecThreads), (uint32_t)lds, s, t0, done, 0, a);
   else
-    hipExtLaunchKernelGGL(k_ray_sectors<16>, dim3(grid), dim3(kSecThreads), (uint32_t)lds, s, nullptr, done, 0, a);
+    hipExtLaunchKernelGGL(k_ray_sectors<16>, dim3(grid), dim3(kSecThreads), (uint32_t)lds, s, t0, done, 0, a);
   return true;
 }
 
@@ -1001,13 +1001,13 @@ __global__ void __launch_bounds__(256) k_finalize_tiles(FinalizeTileArgs a)
 
 // `done` (optional) completes with the kernel, on its own dispatch packet (see launch_ray_sectors);
 // false: nothing launched
-bool launch_finalize_tiles(const FinalizeTileArgs &a, hipStream_t s, hipEvent_t done)
+bool launch_finalize_tiles(const FinalizeTileArgs &a, hipStream_t s, hipEvent_t done, hipEvent_t t0)
 {
   const int rows = a.y_end - a.y_begin;
   if (rows <= 0) return false;
   const dim3 grid((a.g.nx + 63) / 64, (rows + 63) / 64);
-  if (a.counts) hipExtLaunchKernelGGL(k_finalize_tiles<true>, grid, dim3(256), 0, s, nullptr, done, 0, a);
-  else hipExtLaunchKernelGGL(k_finalize_tiles<false>, grid, dim3(256), 0, s, nullptr, done, 0, a);
+  if (a.counts) hipExtLaunchKernelGGL(k_finalize_tiles<true>, grid, dim3(256), 0, s, t0, done, 0, a);
+  else hipExtLaunchKernelGGL(k_finalize_tiles<false>, grid, dim3(256), 0, s, t0, done, 0, a);
   return true;
 }
 

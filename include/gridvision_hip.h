@@ -303,8 +303,9 @@ void *gv_stream(gv_handle h);
 /* Time `frames` back-to-back gv_frame_enqueue calls with HIP events on the
  * handle's stream; *ms_total is the elapsed device time. */
 int gv_time_frames(gv_handle h, int32_t frames, float *ms_total);
-/* Per-stage device time of one frame, averaged over `frames` frames, measured
- * with HIP events recorded between the kernels on the handle's stream.
+/* Per-stage device time of one frame, averaged over `frames` serial frames.  On the tile path
+ * the four kernels carry their own start / end events (dispatch-packet timestamps); other stages are
+ * intervals between HIP events recorded on the handle's stream.
  * stage_ms has GV_NUM_STAGES entries. */
 enum {
   GV_STAGE_DETECTIONS = 0,   /* vision-orientation geometry + rectangles       */
