@@ -217,6 +217,24 @@ def leg_with_h2d(gvamd, synth, g, tfs, config, flags, local_rank, steps):
     t_host = time.perf_counter() - t0   # host time to enqueue everything (no wait inside the loop)
     h.synchronize()
     dt = time.perf_counter() - t0
+    # the node's whole loop: upload + frame + the packed grid back to the host (publishOccupancyGrid,
+    # grid_vision_node.cpp:265-278), 4 MB device-to-host on the public stream behind every grid pass, no host wait
+    G = h.G
+    outs = [gvamd.PinnedF32((G + 3) // 4) for _ in range(2)]
+    def one_pub(f):
+        one(f)
+        h.to_occupancy_grid_async(outs[f % 2].array.view("int8")[:G])
+    for f in range(30):
+        one_pub(f)
+    h.synchronize()
+    tp0 = time.perf_counter()
+    npub = 150
+    for f in range(npub):
+        one_pub(f)
+    h.synchronize()
+    dtp = time.perf_counter() - tp0
+    for o in outs:
+        o.close()
     # copy rate alone: the same streaming loop with a frame that does next to nothing (no binning, no ray stage, no
     # bbox test: only the 14 us grid pass), so that the period is the copy engine's.  (Timing bare uploads is
     # unreliable: one copy at a time lets the idle device clock down between copies -- 11 GB/s; unthrottled bursts
@@ -249,6 +267,7 @@ def leg_with_h2d(gvamd, synth, g, tfs, config, flags, local_rank, steps):
             "h2d_GBps_measured": h2d_gbps, "h2d_GBps_spec": PCIE_SPEC_GBPS,
             "copy_bound_frames_per_s": bound_fps, "frac_of_copy_bound": (steps / dt) / bound_fps,
             "host_us_per_frame": t_host / steps * 1e6, "host_us_per_upload_call": t_host_c / ncopy * 1e6,
+            "with_grid_download_frames_per_s": npub / dtp,   # + 4 MB OccupancyGrid.data to pinned host memory every frame
             "note": "fresh 1M-point cloud (12 MB, one pinned host block, one DMA) + fresh detections every frame, async "
                     "double-buffered ingest on a copy stream, no host wait between frames; never the headline"}
 
