@@ -1,5 +1,5 @@
 """Streaming frames (fresh pinned cloud + detections every frame) for a kernel-trace: run under
-   rocprofv3 --kernel-trace --output-format csv -d <dir> -- python3 tools/stream_run.py [frames]"""
+   rocprofv3 --kernel-trace --output-format csv -d <dir> -- python3 tools/stream_run.py [frames] [pub]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "grid-vision_amd"))
@@ -26,6 +26,7 @@ for f in range(3):
 h = gvamd.GridVisionHIP(g.grid_x, g.grid_y, g.resolution)
 h.set_transforms(tfs["cam_lidar"], tfs["base_cam"], tfs["base_lidar"])
 flags = gvamd.FRAME_BIN | gvamd.FRAME_RAYMARCH | gvamd.FRAME_BBOX_TEST
+pub = [gvamd.PinnedF32((h.G + 3) // 4) for _ in range(2)] if "pub" in sys.argv else None
 per = []
 done = 0
 while done < frames:
@@ -36,6 +37,8 @@ while done < frames:
         h.upload_xyz_async(px, py, pz)
         h.set_detections_async(flags, bboxes=dets[f % 3][0], poses=dets[f % 3][1])
         h.enqueue_frame()
+        if pub is not None:   # "pub": the packed grid goes back to pinned host memory behind every grid pass
+            h.to_occupancy_grid_async(pub[f % 2].array.view("int8")[:h.G])
     h.synchronize()
     per.append(round((time.perf_counter() - t0) / nchunk * 1e6, 1))
     done += nchunk
