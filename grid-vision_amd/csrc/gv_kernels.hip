@@ -145,7 +145,7 @@ __global__ void __launch_bounds__(256) k_bbox_prepare(const gv_bbox *__restrict_
                                                       int32_t tiles_y, int32_t mask_words, float4 *__restrict__ bbox_f,
                                                       unsigned long long *__restrict__ tile_mask)
 {
-  __shared__ float4 s_f[kPrepBoxes];
+  __shared__ int4 s_r[kPrepBoxes];   // tile range {tx0, ty0, tx1, ty1} of a box (empty range: tx0 > tx1)
   const int gid = blockIdx.x * blockDim.x + threadIdx.x;
   const int nwords = tiles_x * tiles_y * mask_words;
   const int wd = (gid < nwords) ? gid % mask_words : 0, tile = (gid < nwords) ? gid / mask_words : 0;
@@ -158,20 +158,22 @@ __global__ void __launch_bounds__(256) k_bbox_prepare(const gv_bbox *__restrict_
       const gv_bbox b = bb[i];
       const float4 f = make_float4(__double2float_ru(b.x_min), __double2float_ru(b.y_min), __double2float_rd(b.x_max),
                                    __double2float_rd(b.y_max));
-      s_f[threadIdx.x] = f;
       if (blockIdx.x == 0) bbox_f[i] = f;
+      // the box's tile range, once per workgroup (every thread used to redo this for every box): tiles whose
+      // pixel range [16t, 16t+16) can contain a u in [f.x, f.z]
+      int4 r = make_int4(1, 1, 0, 0);   // empty or NaN box never matches
+      if (f.x <= f.z && f.y <= f.w) {
+        int tx0 = (int)floorf(fmaxf(f.x, 0.0f) / 16.0f), tx1 = (int)floorf(fminf(f.z, 16.0f * tiles_x - 1.0f) / 16.0f);
+        int ty0 = (int)floorf(fmaxf(f.y, 0.0f) / 16.0f), ty1 = (int)floorf(fminf(f.w, 16.0f * tiles_y - 1.0f) / 16.0f);
+        r = make_int4(max(tx0, 0), max(ty0, 0), min(tx1, tiles_x - 1), min(ty1, tiles_y - 1));
+      }
+      s_r[threadIdx.x] = r;
     }
     __syncthreads();
     const int lo = max(b0, 64 * wd), hi = min(min(nb, b0 + kPrepBoxes), 64 * wd + 64);
     for (int q = lo; q < hi; ++q) {
-      const float4 f = s_f[q - b0];
-      if (!(f.x <= f.z && f.y <= f.w)) continue;   // empty or NaN box never matches
-      // tiles whose pixel range [16t, 16t+16) can contain a u in [f.x, f.z]
-      int tx0 = (int)floorf(fmaxf(f.x, 0.0f) / 16.0f), tx1 = (int)floorf(fminf(f.z, 16.0f * tiles_x - 1.0f) / 16.0f);
-      int ty0 = (int)floorf(fmaxf(f.y, 0.0f) / 16.0f), ty1 = (int)floorf(fminf(f.w, 16.0f * tiles_y - 1.0f) / 16.0f);
-      tx0 = max(tx0, 0); ty0 = max(ty0, 0);
-      tx1 = min(tx1, tiles_x - 1); ty1 = min(ty1, tiles_y - 1);
-      if (tx >= tx0 && tx <= tx1 && ty >= ty0 && ty <= ty1) m |= 1ull << (q & 63);
+      const int4 r = s_r[q - b0];
+      if (tx >= r.x && tx <= r.z && ty >= r.y && ty <= r.w) m |= 1ull << (q & 63);
     }
   }
   if (gid < nwords) tile_mask[gid] = m;
