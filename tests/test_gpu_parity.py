@@ -1283,3 +1283,41 @@ def test_handle_lifecycle_with_frames_in_flight(gvamd):
         h.close()   # frames in flight
     after = free_bytes()
     assert before - after < (64 << 20), f"device memory not returned: {before - after} bytes"
+
+
+def test_streaming_growth_reallocates_under_load(gvamd):
+    """Clouds and detection sets that GROW while frames are in flight: every per-point buffer, binning scratch,
+    detection block and rectangle list is reallocated mid-stream (the growth paths drain the lanes first).
+    Grid, hit counts and bbox ids after the last frame must equal the oracle's."""
+    config = 2
+    g = synth.CONFIGS[config]["grid"]
+    sizes = [20_000, 45_000, 45_000, 130_000, 60_000, 260_000]
+    nbox = [10, 70, 70, 150, 30, 300]
+    flags = gvamd.FRAME_BIN | gvamd.FRAME_RAYMARCH | gvamd.FRAME_BBOX_TEST
+    h, tfs = make_handle(gvamd, config, perturbed=True)
+    og = ol.OGrid(g.grid_x, g.grid_y, g.resolution)
+    pins = []
+    last = None
+    for f, (n, nb) in enumerate(zip(sizes, nbox)):
+        gen = synth.cloud_lidar_like if f % 2 else synth.cloud_uniform
+        x, y, z, _ = gen(config, n, seed_extra=40 + f)
+        bboxes, poses = synth.detections(3, nb, seed_extra=f), synth.lshape_poses(config, nb // 2 + 1, seed_extra=f)
+        p3 = tuple(gvamd.PinnedF32(n) for _ in range(3))
+        p3[0].array[:], p3[1].array[:], p3[2].array[:] = x, y, z
+        pins.append(p3)
+        h.upload_xyz_async(p3[0].array, p3[1].array, p3[2].array)
+        h.set_detections_async(flags, bboxes=bboxes, poses=poses)
+        h.enqueue_frame()
+        h.enqueue_frame()   # a second frame on the same inputs: both lanes busy when the next upload grows things
+        for _ in range(2):
+            last = oracle_frame(og, tfs, x, y, z, bboxes, poses)
+    h.synchronize()
+    hits, _, _, ids, _ = last
+    assert np.array_equal(h.hits(), hits)
+    assert np.array_equal(h.bbox_id(), ids)
+    nlo, _, _ = check_grid(h, og)
+    assert nlo == 0
+    h.close()
+    for p3 in pins:
+        for p in p3:
+            p.close()
