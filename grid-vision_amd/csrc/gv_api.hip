@@ -52,7 +52,8 @@ struct DetSet {
   size_t stage_cap = 0;
   hipEvent_t ready = nullptr;   // the set's last upload is complete (and has left its staging block)
   uint32_t seen = ~0u;          // bit k: stream k (0 public, 1 / 2 the lanes) is ordered after the upload
-  int release_slot = -1, release_stream = 0;   // last frame that reads this set: ev_fin[release_slot]; its points pass ran on release_stream
+  int release_slot = -1;        // last frame that reads this set: ev_fin[release_slot] (a finished grid pass => every earlier frame finished)
+  uint32_t readers = 0;         // bit k: a frame on stream k has read this set since its last upload
 };
 
 }  // namespace
@@ -246,7 +247,7 @@ int drain(gv_context *h)
   for (int &q : h->set_fin_slot) q = -1;
   h->cloud_wait = false;
   for (auto &c : h->cloud) { c.seen = ~0u; c.release_slot = -1; }   // every upload landed, every reader finished
-  for (auto &d : h->det) { d.seen = ~0u; d.release_slot = -1; }
+  for (auto &d : h->det) { d.seen = ~0u; d.release_slot = -1; d.readers = 0; }
   return GV_OK;
 }
 
@@ -269,14 +270,30 @@ int use_device(gv_context *h)
 
 // buffers whose size follows the cloud: per-point outputs and the binning scratch, one of each per
 // buffer set.  Growing them needs the frames in flight to finish first (rare: the cloud grew).
-int ensure_point_buffers(gv_context *h, size_t n)
+// keys / table entries one binning launch over n points needs (the chunk size follows n)
+void bin_needs(const gv_context *h, size_t n, size_t &keys_need, size_t &tab_need)
+{
+  const uint32_t chunk = bin_chunk_for(n);
+  const size_t n_wg = (n + chunk - 1) / chunk;
+  keys_need = n_wg * chunk + 64;   // + slack: the tile pass reads whole 16-byte windows
+  tab_need = n_wg * ((size_t)h->n_tiles + 1) + 2;
+}
+
+// n_slice > 0: binning launches over slices of n_slice points will run as well (the one-device emulation of
+// the sharded frame): a slice may pick a smaller chunk than the whole cloud and then needs MORE table rows
+int ensure_point_buffers(gv_context *h, size_t n, size_t n_slice = 0)
 {
   const int nsets = sector_path(h) ? 3 : 1;   // per-stream copies
   const bool need_idx = n > h->idx_cap || !h->cell_idx;
-  const uint32_t chunk = bin_chunk_for(n);
-  const size_t n_wg = (n + chunk - 1) / chunk;
-  const size_t keys_need = n_wg * chunk + 64;   // + slack: the tile pass reads whole 16-byte windows
-  const size_t tab_need = n_wg * ((size_t)h->n_tiles + 1) + 2;
+  size_t keys_need, tab_need;
+  bin_needs(h, n, keys_need, tab_need);
+  for (size_t m : {n_slice, n_slice ? n_slice - 1 : (size_t)0}) {   // slices are floor or ceil of n / world
+    if (!m) continue;
+    size_t k2, t2;
+    bin_needs(h, m, k2, t2);
+    keys_need = std::max(keys_need, k2);
+    tab_need = std::max(tab_need, t2);
+  }
   const size_t slots_need = n / kBinSplitKeys + 1;
   const bool need_bin = sector_path(h) && (keys_need > h->bin_keys_cap || tab_need > h->bin_tab_cap || slots_need > h->bin_slots);
   if (!need_idx && !need_bin) return GV_OK;
@@ -633,6 +650,14 @@ int enqueue_binning(gv_context *h, const DetSet &D, int p, int k, size_t lo, siz
   hipStream_t s = h->streams[k];
   const uint32_t chunk = bin_chunk_for(n);
   const uint32_t n_wg = (uint32_t)((n + chunk - 1) / chunk);
+  {   // the partition pass writes n_wg table rows and n_wg * chunk keys: never past what was allocated
+    size_t keys_need, tab_need;
+    bin_needs(h, n, keys_need, tab_need);
+    if (keys_need > h->bin_keys_cap || tab_need > h->bin_tab_cap || lo + n > h->idx_cap) {
+      h->err = "binning scratch too small for this launch";
+      return GV_ERR_STATE;
+    }
+  }
   BinArgs a{};
   a.x = h->cx + lo; a.y = h->cy + lo; a.z = h->cz + lo;
   a.n = (uint32_t)n;
@@ -876,7 +901,7 @@ int enqueue_frame_tiles(gv_context *h, bool pipelined, bool stage_events, bool s
   h->set_fin_slot[p] = slot;
   CS.release_slot = slot;
   D.release_slot = slot;
-  D.release_stream = k;
+  D.readers |= 1u << k;
   h->frame_no++;
   if (pipelined) {
     h->lane_frames++;
@@ -955,7 +980,7 @@ int enqueue_frame_generic(gv_context *h, bool stage_events)
   h->last_fin_slot = slot;
   CS.release_slot = slot;
   D.release_slot = slot;
-  D.release_stream = 0;
+  D.readers |= 1u;
   h->frame_no++;
   h->last_set = 0;
   h->counts_dirty = do_bin && keep_counts;
@@ -1413,7 +1438,7 @@ int begin_cloud_upload(gv_context *h, size_t n, int &target)
     if (c.base) GV_HIP(hipFree(c.base));
     c.base = nullptr;
     c.cap = 0;
-    const size_t want = n + n / 8 + 1024;
+    const size_t want = (n + n / 8 + 1024 + 3) & ~(size_t)3;   // the arrays sit at a stride of (n + 3) & ~3 floats
     GV_HIP(hipMalloc(reinterpret_cast<void **>(&c.base), 3 * want * sizeof(float)));
     c.cap = want;
   }
@@ -1499,13 +1524,16 @@ int set_detections(gv_context *h, const gv_frame_desc *d)
   int rc = set_device_only(h);
   if (rc) return rc;
   // The other detection set (frames already enqueued read the current one), uploaded on the stream of the
-  // frame that will read it first: in order before that frame, and -- two sets, two lanes -- after the
-  // frame that last read this set when every frame brings new detections.  Any other case waits on events.
+  // frame that will read it first: in order before that frame.  The frames that read the set's previous
+  // contents: when all of them ran on that same lane (every frame brings new detections: two sets, two
+  // lanes) the upload is already in order behind them; a set that was read on another stream as well (a
+  // detection set kept for several frames is read on both lanes) waits for the grid pass of its last
+  // reader, which completes after every earlier frame.
   const int target = h->det_cur ^ 1;
   DetSet &D = h->det[target];
   const int k = (sector_path(h) && !h->no_pipeline) ? 1 + (int)(h->lane_frames % 2u) : 0;
   hipStream_t s = h->streams[k];
-  if (D.release_slot >= 0 && D.release_stream != k) GV_HIP(hipStreamWaitEvent(s, h->ev_fin[D.release_slot], 0));
+  if (D.release_slot >= 0 && D.readers != (1u << k)) GV_HIP(hipStreamWaitEvent(s, h->ev_fin[D.release_slot], 0));
   const bool net = vision && d->n_bboxes;
   if ((rc = upload_det(h, D, d->bboxes, d->n_bboxes, vision ? nullptr : d->poses, vision ? 0 : d->n_poses,
                        net ? d->orient : nullptr, net ? d->conf : nullptr, net ? d->dims : nullptr, s)))
@@ -1514,6 +1542,7 @@ int set_detections(gv_context *h, const gv_frame_desc *d)
   GV_HIP(hipEventRecord(D.ready, s));
   D.seen = 1u << k;
   D.release_slot = -1;
+  D.readers = 0;
   h->det_cur = target;
   return GV_OK;
 }
@@ -2351,6 +2380,7 @@ int gv_debug_frame_sharded_emulated(gv_handle h, const gv_frame_desc *desc, int3
   if ((rc = check_frame_flags(h, fl))) return rc;
   if (!do_bin) return GV_ERR_STATE;
   if ((rc = ensure_shard_scratch(h, world))) return rc;
+  if ((rc = ensure_point_buffers(h, h->n, (h->n + (size_t)world - 1) / (size_t)world))) return rc;
   hipStream_t s = h->stream;
   const size_t slice = shard_ends_slice(h, world), Ep = slice * (size_t)world;
   const size_t chunk = free_band_chunk_words(h->nxw, h->nx_pad, h->ny_pad, world);

@@ -232,6 +232,14 @@ class GridVisionHIP:
                  "upload_pointcloud2")
         self.n = n
 
+    def upload_pointcloud2_async(self, data: np.ndarray, n, point_step, off_x, off_y, off_z):
+        """data: uint8 bytes (pinned for a truly asynchronous copy) that stay unchanged until upload_wait()"""
+        assert data.dtype == np.uint8 and data.flags["C_CONTIGUOUS"] and data.size >= n * point_step
+        self._ck(self._lib.gv_cloud_upload_pointcloud2_async(self._h, _ptr(data), C.c_size_t(n), C.c_uint32(point_step),
+                                                             C.c_uint32(off_x), C.c_uint32(off_y), C.c_uint32(off_z)),
+                 "upload_pointcloud2_async")
+        self.n = n
+
     # ---- reference-surface calls
     def transform_lidar_to_camera(self):
         x, y, z = (np.empty(self.n, np.float32) for _ in range(3))

@@ -83,7 +83,7 @@ public:
     n_ = n;
   }
   // Streaming form: the copy of the next cloud is enqueued on the handle's copy stream and overlaps the frames in
-  // flight (two resident clouds alternate).  The ROS message is released when the callback returns, so the
+  // flight (three resident clouds rotate).  The ROS message is released when the callback returns, so the
   // bytes are staged in the context's own pinned buffers first (two, alternating); the host never waits for the
   // device here.
   void setCloudPointCloud2Async(const uint8_t *data, size_t n, uint32_t point_step, uint32_t ox, uint32_t oy, uint32_t oz)
@@ -97,9 +97,12 @@ public:
       gv::check(gv_host_alloc(&st.p, bytes + bytes / 8 + 4096), nullptr, "gv_host_alloc");
       st.cap = bytes + bytes / 8 + 4096;
     }
-    // (with two buffers in turn, the copy that last read this one was enqueued two clouds ago; at the node's
-    //  20 Hz it has long finished -- a faster producer calls gv_cloud_upload_wait here)
+    // The copy that last read this buffer was enqueued two clouds ago.  At the node's 20 Hz it has long
+    // finished and the wait returns at once; behind a held-back copy stream (back-pressure, a burst of clouds)
+    // it keeps the bytes under an in-flight DMA unchanged, as the header demands.
+    if (st.submitted) gv::check(gv_cloud_upload_wait(h_), h_, "gv_cloud_upload_wait");
     std::memcpy(st.p, data, bytes);
+    st.submitted = true;
     gv::check(gv_cloud_upload_pointcloud2_async(h_, static_cast<const uint8_t *>(st.p), n, point_step, ox, oy, oz), h_,
               "gv_cloud_upload_pointcloud2_async");
     n_ = n;
@@ -118,6 +121,7 @@ private:
   struct Staging {
     void *p = nullptr;
     size_t cap = 0;
+    bool submitted = false;   // a copy out of this buffer has been enqueued
   };
   Staging stage_[2];
   int flip_ = 0;

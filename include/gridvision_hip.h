@@ -120,7 +120,7 @@ int gv_cloud_upload_pointcloud2(gv_handle h, const uint8_t *data, size_t n, uint
                                 uint32_t off_x, uint32_t off_y, uint32_t off_z);
 /* Streaming ingest: the node receives a new cloud (cloudCallback, grid_vision_node.cpp:103-106)
  * while the previous frame is still being processed (timerCallback, :108-244).  The handle
- * keeps TWO resident clouds: the *_async calls enqueue the host-to-device copy of the next one
+ * keeps THREE resident clouds in rotation: the *_async calls enqueue the host-to-device copy of the next one
  * on a copy stream, ordered after the last frame that reads the buffer being replaced, and return
  * at once; frames enqueued afterwards use the new cloud (stream-ordered, no host wait).  The copy
  * is truly asynchronous when the host buffers are pinned (gv_host_alloc); pageable buffers work

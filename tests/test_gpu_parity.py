@@ -1000,6 +1000,37 @@ def test_streaming_ingest_matches_oracle(gvamd):
             p.close()
 
 
+def test_detection_set_kept_over_several_frames(gvamd):
+    """Detections arrive slower than frames (the 2D detector runs below the 20 Hz timer,
+    grid_vision_node.cpp:49-50,108-244): a detection set is read by frames on BOTH lanes before the set
+    is re-uploaded.  The upload must come after every one of those readers, not only after the reader on
+    its own lane (round-2 advisor finding).  Schedules: 2 frames on set A, 1 on B, then A', and longer runs
+    with 1..3 frames per set; grids and the last frame's bbox ids must equal the oracle's."""
+    config = 2
+    g = synth.CONFIGS[config]["grid"]
+    x, y, z, _ = synth.cloud_uniform(config, 70_000, seed_extra=3)
+    dets = [(synth.detections(3, 12 + 7 * f, seed_extra=20 + f), synth.lshape_poses(config, 6 + 4 * f, seed_extra=20 + f))
+            for f in range(7)]
+    flags = gvamd.FRAME_BIN | gvamd.FRAME_RAYMARCH | gvamd.FRAME_BBOX_TEST
+    for schedule in ((2, 1, 1), (2, 1, 2, 1), (1, 2, 3, 1, 2, 3, 1), (3, 3, 3, 3)):
+        h, tfs = make_handle(gvamd, config, perturbed=True)
+        og = ol.OGrid(g.grid_x, g.grid_y, g.resolution)
+        h.upload_xyz(x, y, z)
+        for d, reps in enumerate(schedule):
+            h.set_detections_async(flags, bboxes=dets[d][0], poses=dets[d][1])
+            for _ in range(reps):
+                h.enqueue_frame()
+        h.synchronize()
+        ids = None
+        for d, reps in enumerate(schedule):
+            for _ in range(reps):
+                _, _, _, ids, _ = oracle_frame(og, tfs, x, y, z, dets[d][0], dets[d][1])
+        assert np.array_equal(h.bbox_id(), ids), schedule
+        nlo, _, _ = check_grid(h, og)
+        assert nlo == 0, schedule
+        h.close()
+
+
 def test_stream_contract_public_stream(gvamd):
     """gv_stream contract: every frame's grid pass runs on gv_stream(h) behind the frame's other kernels
     (which run on the two internal lanes), so a copy the caller puts there between two gv_frame_enqueue

@@ -17,6 +17,17 @@ DPM = ["pp_dpm_sclk", "pp_dpm_mclk", "pp_dpm_fclk", "pp_dpm_socclk", "pp_dpm_pci
 
 
 def card_dir():
+    """sysfs directory of HIP device 0 (the host's other GPUs are visible in sysfs too): matched by PCI bus id"""
+    import ctypes as C
+    try:
+        hip = C.CDLL("libamdhip64.so")
+        buf = C.create_string_buffer(64)
+        if hip.hipDeviceGetPCIBusId(buf, 64, 0) == 0:
+            d = "/sys/bus/pci/devices/" + buf.value.decode().lower()
+            if os.path.exists(os.path.join(d, "pp_dpm_sclk")):
+                return d
+    except OSError:
+        pass
     for d in sorted(glob.glob("/sys/class/drm/card*/device")):
         if os.path.exists(os.path.join(d, "pp_dpm_sclk")):
             return d
