@@ -169,14 +169,16 @@ struct gv_context {
   // kNN depth / PCA pose scratch
   Cand2 *knn_partial = nullptr; size_t knn_partial_cap = 0;
   float *d_depths = nullptr, *d_knn_d2 = nullptr; size_t knn_out_cap = 0;
-  int32_t *d_idx = nullptr, *d_segof = nullptr, *d_segstart = nullptr; size_t seg_cap = 0, segstart_cap = 0;
-  float *gx = nullptr, *gy = nullptr, *gz = nullptr; uint8_t *d_keep = nullptr; size_t gcap = 0;
+  int32_t *d_segstart = nullptr; size_t segstart_cap = 0;
+  float *gx = nullptr, *gy = nullptr, *gz = nullptr; size_t gcap = 0;   // kept points by bbox, cloud order
+  CellNode *d_nodes = nullptr; uint8_t *d_drop = nullptr; size_t pc_cap = 0;   // per point: cell-list node, filtered-out flag
+  uint32_t *d_cellcnt = nullptr, *d_cellpre = nullptr, *d_celloff = nullptr; size_t head_cap = 0;   // cell buckets: counts, prefix, block offsets (+ ticket)
   float4 *d_planes = nullptr; unsigned *d_plane_counts = nullptr; size_t planes_cap = 0;
   uint8_t *d_ground = nullptr; size_t ground_cap = 0;   // last ground mask (device resident)
   size_t ground_n = 0;
   double *d_rscratch = nullptr; size_t rscratch_cap = 0;   // tree-sum partials of the plane refinement
   RansacState *d_rstate = nullptr;
-  uint32_t *d_blockcnt = nullptr; size_t blockcnt_cap = 0;   // per (1024-point block, bbox) counts of the cloud split
+  uint32_t *d_blockcnt = nullptr; size_t blockcnt_cap = 0;   // per (1024-point block, bbox) counts of the kept-point split
   gv_lshape_pose *d_pose_out = nullptr; size_t pose_out_cap = 0;
   uint8_t *d_pose_valid = nullptr; size_t pose_valid_cap = 0;
 
@@ -1319,7 +1321,7 @@ int gv_destroy(gv_handle h)
   if (h->comm) { ncclCommDestroy(h->comm); h->comm = nullptr; }
   void *bufs[] = {h->log_odds, h->occupancy, h->occ_i8, h->clip_end, h->miss8, h->sh_xchg, h->ray_list, h->ray_count, h->scratch_i32,
                   h->tx, h->ty, h->tz, h->d_pts, h->knn_partial, h->d_depths,
-                  h->d_knn_d2, h->d_idx, h->d_segof, h->d_segstart, h->gx, h->gy, h->gz, h->d_keep, h->d_planes,
+                  h->d_knn_d2, h->d_segstart, h->gx, h->gy, h->gz, h->d_nodes, h->d_drop, h->d_cellcnt, h->d_cellpre, h->d_celloff, h->d_planes,
                   h->d_plane_counts, h->d_ground, h->d_rscratch, h->d_rstate, h->d_blockcnt, h->d_pose_out, h->d_pose_valid};
   for (void *p : bufs)
     if (p) (void)hipFree(p);
@@ -2132,8 +2134,7 @@ int gv_compute_depth_for_bboxes(gv_handle h, const gv_bbox *bboxes, int32_t nb, 
   if (rc) return rc;
   if ((rc = upload_scratch_bboxes(h, bboxes, nb))) return rc;
   if ((rc = ensure_tbuf(h, std::max<size_t>(h->n, 1)))) return rc;
-  const int nchunks = 64;
-  if ((rc = grow(h, h->knn_partial, h->knn_partial_cap, (size_t)nb * nchunks * k))) return rc;
+  if ((rc = grow(h, h->knn_partial, h->knn_partial_cap, knn_partial_entries(nb, k)))) return rc;
   if ((size_t)nb * k > h->knn_out_cap) {
     if (h->d_depths) GV_HIP(hipFree(h->d_depths));
     if (h->d_knn_d2) GV_HIP(hipFree(h->d_knn_d2));
@@ -2145,8 +2146,7 @@ int gv_compute_depth_for_bboxes(gv_handle h, const gv_bbox *bboxes, int32_t nb, 
   }
   // buildKDTree projection (cloud_detections.cpp:8-33) then the exact k nearest (:43-87)
   launch_project_uvd(h->cx, h->cy, h->cz, (uint32_t)h->n, h->m_cam, h->camk, h->tx, h->ty, h->tz, h->stream);
-  launch_knn(h->tx, h->ty, h->tz, (uint32_t)h->n, h->det[2].bboxes, nb, k, nchunks, h->knn_partial, h->d_depths,
-             h->d_knn_d2, h->stream);
+  launch_knn(h->tx, h->ty, h->tz, (uint32_t)h->n, h->det[2].bboxes, nb, k, h->knn_partial, h->d_depths, h->d_knn_d2, h->stream);
   GV_HIP(hipGetLastError());
   GV_HIP(hipMemcpyAsync(depths, h->d_depths, (size_t)nb * sizeof(float), hipMemcpyDeviceToHost, h->stream));
   if (knn_d2)
@@ -2156,67 +2156,131 @@ int gv_compute_depth_for_bboxes(gv_handle h, const gv_bbox *bboxes, int32_t nb, 
   GV_CATCH
 }
 
-// extractCloudPerBBox -> RadiusOutlierRemoval -> centroid + PCA rectangle, all on the device; only the nb
-// poses come back.  skip (device, n bytes or null): points removed before the split (ground).
-static int compute_bbox_pose_impl(gv_handle h, const gv_bbox *bboxes, int32_t nb, gv_lshape_pose *poses_out,
-                                  uint8_t *valid, const uint8_t *d_skip)
+// smallest float >= the fp64 threshold: for a float f, f < thr_f <=> (double)f < thr
+static float ceil_to_float(double v)
 {
-  if (!h || nb < 0 || nb > 32767 || (nb && (!bboxes || !poses_out || !valid))) return GV_ERR_BAD_ARG;
-  if (!h->has_cl) return GV_ERR_TF;
-  GV_TRY
-  if (nb == 0) return GV_OK;
-  int rc = use_device(h);
-  if (rc) return rc;
-  const size_t n = h->n;
-  for (int32_t b = 0; b < nb; ++b) { valid[b] = 0; poses_out[b] = gv_lshape_pose{}; }
-  if (n == 0) return GV_OK;
-  if ((rc = upload_scratch_bboxes(h, bboxes, nb))) return rc;
-  // extractCloudPerBBox (cloud_detections.cpp:250-298): first-match bbox id per point
-  {
-    PointsArgs a{};
-    bbox_points_args(h, a);
-    launch_points(a, h->stream);
-    GV_HIP(hipGetLastError());
+  float f = (float)v;
+  if ((double)f < v) f = std::nextafterf(f, INFINITY);
+  return f;
+}
+
+static int ensure_ransac_buffers(gv_context *h, size_t n, int32_t iterations)
+{
+  int rc;
+  if ((size_t)iterations > h->planes_cap) {
+    if (h->d_planes) { GV_HIP(hipFree(h->d_planes)); h->d_planes = nullptr; }
+    if (h->d_plane_counts) { GV_HIP(hipFree(h->d_plane_counts)); h->d_plane_counts = nullptr; }
+    h->planes_cap = 0;
+    GV_HIP(hipMalloc(reinterpret_cast<void **>(&h->d_planes), (size_t)iterations * sizeof(float4)));
+    GV_HIP(hipMalloc(reinterpret_cast<void **>(&h->d_plane_counts), (size_t)iterations * sizeof(unsigned)));
+    GV_HIP(hipMemsetAsync(h->d_plane_counts, 0, (size_t)iterations * sizeof(unsigned), h->stream));   // every pass leaves them zero
+    h->planes_cap = (size_t)iterations;
   }
-  h->have_bbox_id = true;
-  // per-bbox point lists in cloud order (the reference appends in cloud order, :286): stable device split
-  const size_t nblocks = (n + 1023) / 1024;
-  if ((rc = grow(h, h->d_blockcnt, h->blockcnt_cap, nblocks * (size_t)nb + 16))) return rc;
-  if ((rc = grow(h, h->d_segstart, h->segstart_cap, (size_t)nb + 2))) return rc;
-  if (n > h->seg_cap) {
-    if (h->d_idx) { GV_HIP(hipFree(h->d_idx)); h->d_idx = nullptr; }
-    if (h->d_segof) { GV_HIP(hipFree(h->d_segof)); h->d_segof = nullptr; }
-    h->seg_cap = 0;
+  if ((rc = grow(h, h->d_rscratch, h->rscratch_cap, ransac_scratch_doubles(n)))) return rc;
+  if (!h->d_rstate) {
+    GV_HIP(hipMalloc(reinterpret_cast<void **>(&h->d_rstate), sizeof(RansacState)));
+    GV_HIP(hipMemsetAsync(h->d_rstate, 0, sizeof(RansacState), h->stream));
+  }
+  return GV_OK;
+}
+
+// extractCloudPerBBox -> RadiusOutlierRemoval -> centroid + PCA rectangle, all on the device and all enqueued
+// without a host wait in between; only the nb poses come back.  with_ground: the points of the refined RANSAC
+// plane in *d_rstate are dropped first (computeBBoxPose, cloud_detections.cpp:300-321), and the "empty segmented
+// cloud" outcomes (:307-309) are decided on the device.
+static int enqueue_bbox_pose(gv_context *h, int32_t nb, bool with_ground, float thr_f)
+{
+  const size_t n = h->n;
+  int rc;
+  if (n > h->pc_cap) {
+    if (h->d_nodes) { GV_HIP(hipFree(h->d_nodes)); h->d_nodes = nullptr; }
+    if (h->d_drop) { GV_HIP(hipFree(h->d_drop)); h->d_drop = nullptr; }
+    h->pc_cap = 0;
     const size_t want = n + n / 8 + 1024;
-    GV_HIP(hipMalloc(reinterpret_cast<void **>(&h->d_idx), want * sizeof(int32_t)));
-    GV_HIP(hipMalloc(reinterpret_cast<void **>(&h->d_segof), want * sizeof(int32_t)));
-    h->seg_cap = want;
+    GV_HIP(hipMalloc(reinterpret_cast<void **>(&h->d_nodes), want * sizeof(CellNode)));
+    GV_HIP(hipMalloc(reinterpret_cast<void **>(&h->d_drop), want));
+    h->pc_cap = want;
   }
   if (n > h->gcap) {
     for (float **p : {&h->gx, &h->gy, &h->gz})
       if (*p) { GV_HIP(hipFree(*p)); *p = nullptr; }
-    if (h->d_keep) { GV_HIP(hipFree(h->d_keep)); h->d_keep = nullptr; }
     h->gcap = 0;
     const size_t want = n + n / 8 + 1024;
     GV_HIP(hipMalloc(reinterpret_cast<void **>(&h->gx), want * sizeof(float)));
     GV_HIP(hipMalloc(reinterpret_cast<void **>(&h->gy), want * sizeof(float)));
     GV_HIP(hipMalloc(reinterpret_cast<void **>(&h->gz), want * sizeof(float)));
-    GV_HIP(hipMalloc(reinterpret_cast<void **>(&h->d_keep), want));
     h->gcap = want;
   }
+  // cell buckets: a power of two, about one per two points (the three arrays stay L2 resident at config-3 size;
+  // cells that share a bucket only add candidates that fail the id or distance test)
+  size_t n_buckets = 4096;
+  while (n_buckets < n / 2 && n_buckets < ((size_t)1 << 25)) n_buckets <<= 1;
+  if (n_buckets > h->head_cap) {
+    for (uint32_t **p : {&h->d_cellcnt, &h->d_cellpre, &h->d_celloff})
+      if (*p) { GV_HIP(hipFree(*p)); *p = nullptr; }
+    h->head_cap = 0;
+    GV_HIP(hipMalloc(reinterpret_cast<void **>(&h->d_cellcnt), n_buckets * sizeof(uint32_t)));
+    GV_HIP(hipMalloc(reinterpret_cast<void **>(&h->d_cellpre), (n_buckets + 4) * sizeof(uint32_t)));
+    GV_HIP(hipMalloc(reinterpret_cast<void **>(&h->d_celloff), (n_buckets / 4096 + 4) * sizeof(uint32_t)));
+    GV_HIP(hipMemsetAsync(h->d_cellcnt, 0, n_buckets * sizeof(uint32_t), h->stream));   // every call counts them back to zero
+    GV_HIP(hipMemsetAsync(h->d_celloff, 0, (n_buckets / 4096 + 4) * sizeof(uint32_t), h->stream));   // [n_buckets / 4096 + 2] = the scan's ticket
+    h->head_cap = n_buckets;
+  }
+  n_buckets = h->head_cap;   // the table only grows
+  const size_t nblocks = (n + 1023) / 1024;
+  if ((rc = grow(h, h->d_blockcnt, h->blockcnt_cap, nblocks * (size_t)nb + 16))) return rc;
+  if ((rc = grow(h, h->d_segstart, h->segstart_cap, (size_t)nb + 2))) return rc;
   if ((rc = grow(h, h->d_pose_out, h->pose_out_cap, (size_t)nb))) return rc;
   if ((rc = grow(h, h->d_pose_valid, h->pose_valid_cap, (size_t)nb))) return rc;
-  launch_split_by_bbox(h->bbox_id, d_skip, (uint32_t)n, nb, h->d_blockcnt, h->d_segstart, h->d_idx, h->d_segof, h->stream);
-  launch_gather_cam(h->cx, h->cy, h->cz, h->m_cam, h->d_idx, h->d_segstart, nb, (uint32_t)n, h->gx, h->gy, h->gz, h->stream);
-  // RadiusOutlierRemoval(0.4, 10)  (cloud_detections.cpp:150-154)
+  if (!h->d_rstate) {
+    GV_HIP(hipMalloc(reinterpret_cast<void **>(&h->d_rstate), sizeof(RansacState)));
+    GV_HIP(hipMemsetAsync(h->d_rstate, 0, sizeof(RansacState), h->stream));
+  }
+  hipStream_t s = h->stream;
+  // extractCloudPerBBox + RadiusOutlierRemoval(0.4, 10)  (cloud_detections.cpp:250-298, 150-154)
   const double radius = 0.4;
-  launch_radius_count(h->gx, h->gy, h->gz, h->d_segof, h->d_segstart, (int32_t)n, h->d_segstart + nb,
-                      host::floor_to_float(radius * radius), 10, h->d_keep, h->stream);
-  // centroid + PCA rectangle per bbox on the filtered points, reference order (:156-247)
-  launch_pca_bbox(h->gx, h->gy, h->gz, h->d_keep, h->d_segstart, nb, h->d_pose_out, h->d_pose_valid, h->stream);
+  launch_radius_filter(h->cx, h->cy, h->cz, (uint32_t)n, h->m_cam, h->camk, bbox_test_of(h, h->det[2]), nb, with_ground, thr_f,
+                       h->d_rstate, h->bbox_id, h->d_drop, h->d_cellcnt, h->d_cellpre, h->d_celloff,
+                       h->d_celloff + n_buckets / 4096 + 2, h->d_nodes, (uint32_t)n_buckets, host::floor_to_float(radius * radius), 10, s);
+  h->have_bbox_id = true;
+  // the kept points by bbox in cloud order (the reference appends in cloud order, :286), then centroid +
+  // PCA rectangle per bbox in the reference's accumulation order (:156-247)
+  launch_split_kept(h->bbox_id, h->d_drop, h->cx, h->cy, h->cz, h->m_cam, (uint32_t)n, nb, h->d_blockcnt, h->d_segstart, h->gx, h->gy, h->gz, s);
+  launch_pca_bbox(h->gx, h->gy, h->gz, h->d_segstart, nb, h->d_rstate, with_ground, (uint32_t)n, h->d_pose_out, h->d_pose_valid, s);
   GV_HIP(hipGetLastError());
-  GV_HIP(hipMemcpyAsync(poses_out, h->d_pose_out, (size_t)nb * sizeof(gv_lshape_pose), hipMemcpyDeviceToHost, h->stream));
-  GV_HIP(hipMemcpyAsync(valid, h->d_pose_valid, (size_t)nb, hipMemcpyDeviceToHost, h->stream));
+  return GV_OK;
+}
+
+static int compute_bbox_pose_impl(gv_handle h, const gv_bbox *bboxes, int32_t nb, gv_lshape_pose *poses_out,
+                                  uint8_t *valid, bool with_ground, RansacState *st_out)
+{
+  if (!h || nb < 0 || nb > 32767 || (nb && (!bboxes || !poses_out || !valid))) return GV_ERR_BAD_ARG;
+  if (!h->has_cl) return GV_ERR_TF;
+  GV_TRY
+  int rc = use_device(h);
+  if (rc) return rc;
+  const size_t n = h->n;
+  for (int32_t b = 0; b < nb; ++b) { valid[b] = 0; poses_out[b] = gv_lshape_pose{}; }
+  if (st_out) *st_out = RansacState{};
+  if (n == 0 || (with_ground && n < 3)) return GV_OK;
+  if (nb && (rc = upload_scratch_bboxes(h, bboxes, nb))) return rc;
+  const float thr_f = ceil_to_float(0.04);
+  if (with_ground) {   // segmentGroundPlane(0.04, 50 hypotheses) on the camera-frame cloud (grid_vision_node.cpp:215-216)
+    if ((rc = ensure_ransac_buffers(h, n, 50))) return rc;
+    launch_ransac_plane(h->cx, h->cy, h->cz, (uint32_t)n, h->m_cam, thr_f, 50, 12345ull, h->d_planes, h->d_plane_counts,
+                        h->d_rscratch, h->d_rstate, h->stream);
+    GV_HIP(hipGetLastError());
+    h->ground_n = 0;   // the mask itself is not materialised on this path
+  }
+  if (nb) {
+    if ((rc = enqueue_bbox_pose(h, nb, with_ground, thr_f))) return rc;
+    GV_HIP(hipMemcpyAsync(poses_out, h->d_pose_out, (size_t)nb * sizeof(gv_lshape_pose), hipMemcpyDeviceToHost, h->stream));
+    GV_HIP(hipMemcpyAsync(valid, h->d_pose_valid, (size_t)nb, hipMemcpyDeviceToHost, h->stream));
+  } else if (with_ground) {   // no boxes: the ground count still decides the return value
+    if ((rc = grow(h, h->d_ground, h->ground_cap, n))) return rc;
+    launch_ransac_mask(h->cx, h->cy, h->cz, (uint32_t)n, h->m_cam, thr_f, h->d_rstate, h->d_ground, h->stream);
+  }
+  if (st_out) GV_HIP(hipMemcpyAsync(st_out, h->d_rstate, sizeof(RansacState), hipMemcpyDeviceToHost, h->stream));
   GV_HIP(hipStreamSynchronize(h->stream));
   return GV_OK;
   GV_CATCH
@@ -2224,7 +2288,7 @@ static int compute_bbox_pose_impl(gv_handle h, const gv_bbox *bboxes, int32_t nb
 
 int gv_compute_bbox_pose(gv_handle h, const gv_bbox *bboxes, int32_t nb, gv_lshape_pose *poses_out, uint8_t *valid)
 {
-  return compute_bbox_pose_impl(h, bboxes, nb, poses_out, valid, nullptr);
+  return compute_bbox_pose_impl(h, bboxes, nb, poses_out, valid, false, nullptr);
 }
 
 // segmentGroundPlane on the device; state (plane, inlier count) comes back, the mask stays resident
@@ -2235,20 +2299,13 @@ static int segment_ground_device(gv_context *h, double threshold, int32_t iterat
   h->ground_n = 0;
   if (n < 3) return GV_OK;
   int rc;
-  if ((size_t)iterations > h->planes_cap) {
-    if (h->d_planes) { GV_HIP(hipFree(h->d_planes)); h->d_planes = nullptr; }
-    if (h->d_plane_counts) { GV_HIP(hipFree(h->d_plane_counts)); h->d_plane_counts = nullptr; }
-    h->planes_cap = 0;
-    GV_HIP(hipMalloc(reinterpret_cast<void **>(&h->d_planes), (size_t)iterations * sizeof(float4)));
-    GV_HIP(hipMalloc(reinterpret_cast<void **>(&h->d_plane_counts), (size_t)iterations * sizeof(unsigned)));
-    h->planes_cap = (size_t)iterations;
-  }
+  if ((rc = ensure_ransac_buffers(h, n, iterations))) return rc;
   if ((rc = grow(h, h->d_ground, h->ground_cap, n))) return rc;
-  if ((rc = grow(h, h->d_rscratch, h->rscratch_cap, ransac_scratch_doubles(n)))) return rc;
-  if (!h->d_rstate) GV_HIP(hipMalloc(reinterpret_cast<void **>(&h->d_rstate), sizeof(RansacState)));
+  const float thr_f = ceil_to_float(threshold);
   // camera-frame cloud (the reference segments transformed_cloud, grid_vision_node.cpp:215-216): transformed on the fly
-  launch_ransac(h->cx, h->cy, h->cz, (uint32_t)n, h->m_cam, threshold, iterations, seed, h->d_planes, h->d_plane_counts,
-                h->d_rscratch, h->d_rstate, h->d_ground, h->stream);
+  launch_ransac_plane(h->cx, h->cy, h->cz, (uint32_t)n, h->m_cam, thr_f, iterations, seed, h->d_planes, h->d_plane_counts,
+                      h->d_rscratch, h->d_rstate, h->stream);
+  launch_ransac_mask(h->cx, h->cy, h->cz, (uint32_t)n, h->m_cam, thr_f, h->d_rstate, h->d_ground, h->stream);
   GV_HIP(hipGetLastError());
   GV_HIP(hipMemcpyAsync(&st, h->d_rstate, sizeof(RansacState), hipMemcpyDeviceToHost, h->stream));
   GV_HIP(hipStreamSynchronize(h->stream));
@@ -2285,25 +2342,21 @@ int gv_compute_bbox_pose_ground_removed(gv_handle h, const gv_bbox *bboxes, int3
 {
   if (!h || nb < 0 || (nb && (!bboxes || !poses_out || !valid))) return GV_ERR_BAD_ARG;
   if (!h->has_cl) return GV_ERR_TF;
-  GV_TRY
-  // computeBBoxPose (cloud_detections.cpp:300-321): segmentGroundPlane -> extractCloudPerBBox -> PCA
-  int rc = use_device(h);
-  if (rc) return rc;
-  RansacState st;
-  if ((rc = segment_ground_device(h, 0.04, 50, 12345ull, st))) return rc;
-  const uint64_t m = st.best_count ? st.n_inliers : 0;
+  // computeBBoxPose (cloud_detections.cpp:300-321): segmentGroundPlane -> extractCloudPerBBox -> PCA, enqueued as
+  // one batch: the device decides the "empty segmented cloud" cases, the host reads 56 bytes of state + the poses
   if (n_poses_or_fail) *n_poses_or_fail = 0;
+  RansacState st;
+  int rc = compute_bbox_pose_impl(h, bboxes, nb, poses_out, valid, true, &st);
+  if (rc) return rc;
+  const uint64_t m = st.best_count ? st.n_inliers : 0;
   if (m == 0 || (size_t)m == h->n) {   // empty segmented cloud -> the reference returns {} (:307-309)
     for (int32_t b = 0; b < nb; ++b) valid[b] = 0;
     if (n_poses_or_fail) *n_poses_or_fail = -1;
     return GV_OK;
   }
-  rc = compute_bbox_pose_impl(h, bboxes, nb, poses_out, valid, h->d_ground);
-  if (rc) return rc;
   if (n_poses_or_fail)
     for (int32_t b = 0; b < nb; ++b) *n_poses_or_fail += valid[b];
   return GV_OK;
-  GV_CATCH
 }
 
 int gv_comm_unique_id(uint8_t id_out[128])

@@ -190,33 +190,48 @@ struct Cand2 {
 };
 void launch_project_uvd(const float *x, const float *y, const float *z, uint32_t n, const Mat34f &m,
                         const CamK &cam, float *pu, float *pv, float *pd, hipStream_t s);
+size_t knn_partial_entries(int nb, int k);   // Cand2 entries of the stage-1 lists
 void launch_knn(const float *pu, const float *pv, const float *pd, uint32_t n, const gv_bbox *bboxes, int nb, int k,
-                int nchunks, Cand2 *partial, float *depths, float *knn_d2, hipStream_t s);
-// keep[i] for the points [0, n) of the segment-ordered arrays; n = min(n_max, *n_dev) when n_dev is given
-void launch_radius_count(const float *x, const float *y, const float *z, const int32_t *seg_of,
-                         const int32_t *seg_start, int32_t n_max, const int32_t *n_dev, float r2f, int32_t min_pts,
-                         uint8_t *keep, hipStream_t s);
+                Cand2 *partial, float *depths, float *knn_d2, hipStream_t s);
 
-// ---- device-resident RANSAC ground plane + per-bbox clouds / PCA (gv_cloudops.hip) ----
+// ---- device-resident RANSAC ground plane + per-bbox clouds / radius filter / PCA (gv_cloudops.hip) ----
 struct RansacState {
   float4 plane;             // best sampled plane
   float4 refined;           // least-squares plane of its inliers (= plane when fewer than 3)
-  double centroid[3];
   unsigned long long m;         // inliers of `plane`
-  unsigned long long n_inliers; // inliers of `refined` (the mask)
+  unsigned long long n_inliers; // inliers of `refined` (the mask / the ground points the classify pass dropped)
   unsigned best_count;          // 0: could not estimate a planar model
+  unsigned ticket;              // arrival counter of the moments pass (zero between calls)
 };
 size_t ransac_scratch_doubles(size_t n);
-// the whole of segmentGroundPlane on stream s; mask[n] and *st stay on the device
-void launch_ransac(const float *x, const float *y, const float *z, uint32_t n, const Mat34f &m_cam, double thr, int iters,
-                   unsigned long long seed, float4 *planes, unsigned *counts, double *scratch, RansacState *st,
-                   uint8_t *mask, hipStream_t s);
-// stable split of the cloud by bbox id (skip[i] != 0 drops point i): seg_start[nb + 1], idx / seg_of in segment order
-void launch_split_by_bbox(const int16_t *ids, const uint8_t *skip, uint32_t n, int nb, uint32_t *block_counts,
-                          int32_t *seg_start, int32_t *idx, int32_t *seg_of, hipStream_t s);
-void launch_gather_cam(const float *x, const float *y, const float *z, const Mat34f &m, const int32_t *idx,
-                       const int32_t *seg_start, int nb, uint32_t n_max, float *ox, float *oy, float *oz, hipStream_t s);
-void launch_pca_bbox(const float *gx, const float *gy, const float *gz, const uint8_t *keep, const int32_t *seg_start, int nb,
-                     gv_lshape_pose *poses, uint8_t *valid, hipStream_t s);
+// hypotheses, inlier counts of all of them, selection + refinement on stream s; *st stays on the device.
+// counts[iters] must be zero on entry (the pass leaves it zero); thr_f = smallest float >= the fp64 threshold
+void launch_ransac_plane(const float *x, const float *y, const float *z, uint32_t n, const Mat34f &m_cam, float thr_f, int iters,
+                         unsigned long long seed, float4 *planes, unsigned *counts, double *scratch, RansacState *st,
+                         hipStream_t s);
+// mask[n] of the refined plane's inliers + st->n_inliers
+void launch_ransac_mask(const float *x, const float *y, const float *z, uint32_t n, const Mat34f &m_cam, float thr_f,
+                        RansacState *st, uint8_t *mask, hipStream_t s);
+// one selected point of the radius filter, in bucket order
+struct CellNode {
+  float x, y, z;    // camera frame
+  int32_t id;       // bbox
+  int32_t orig;     // index in the cloud
+  int32_t pad[3];
+};
+static_assert(sizeof(CellNode) == 32, "one node = one 32-byte access");
+// extractCloudPerBBox + RadiusOutlierRemoval: ids[n] (ground points of st->refined dropped when use_plane) and
+// drop[n] (1 = not selected or filtered out).  cell_cnt[n_buckets] must be zero on entry (left zero), pre has
+// n_buckets + 1 entries, blk_off n_buckets / 4096 + 1, *ticket zero on entry; sorted holds n nodes.
+// n_buckets: a power of two >= 4096
+void launch_radius_filter(const float *x, const float *y, const float *z, uint32_t n, const Mat34f &m_cam, const CamK &cam,
+                          const BBoxTest &bt, int nb, bool use_plane, float thr_f, RansacState *st, int16_t *ids, uint8_t *drop,
+                          uint32_t *cell_cnt, uint32_t *pre, uint32_t *blk_off, unsigned *ticket, CellNode *sorted,
+                          uint32_t n_buckets, float r2f, int min_pts, hipStream_t s);
+// stable split of the kept points by bbox id: seg_start[nb + 1], camera coordinates in segment order
+void launch_split_kept(const int16_t *ids, const uint8_t *drop, const float *x, const float *y, const float *z, const Mat34f &m_cam,
+                       uint32_t n, int nb, uint32_t *block_counts, int32_t *seg_start, float *gx, float *gy, float *gz, hipStream_t s);
+void launch_pca_bbox(const float *gx, const float *gy, const float *gz, const int32_t *seg_start, int nb, const RansacState *st,
+                     bool use_plane, uint32_t n_cloud, gv_lshape_pose *poses, uint8_t *valid, hipStream_t s);
 
 }  // namespace gv

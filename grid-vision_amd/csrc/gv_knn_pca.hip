@@ -1,8 +1,6 @@
-// gv_knn_pca.hip -- the two "next tier" cloud_detections kernels:
-//   * exact brute-force kNN of each bbox centre over the projected cloud
-//     (buildKDTree + computeDepthForBoundingBoxes, src/cloud_detections.cpp:8-87)
-//   * RadiusOutlierRemoval neighbour counting per bbox cloud
-//     (src/cloud_detections.cpp:150-154)
+// gv_knn_pca.hip -- exact brute-force kNN of each bbox centre over the projected cloud
+// (buildKDTree + computeDepthForBoundingBoxes, src/cloud_detections.cpp:8-87).  The radius filter and the PCA
+// rectangle of the same reference file live in gv_cloudops.hip.
 // gfx950, wave64, built with -ffp-contract=off.
 #include "gv_kernels.hpp"
 
@@ -55,118 +53,152 @@ void launch_project_uvd(const float *x, const float *y, const float *z, uint32_t
   hipLaunchKernelGGL(k_project_uvd, dim3(blocks), dim3(256), 0, s, x, y, z, n, m, cam, pu, pv, pd);
 }
 
-// (d2, index) candidates ordered lexicographically: equal distances resolve to the
-// lower point index (the oracle's stable insertion has the same rule; FLANN's own tie
-// order is tree dependent).
-struct Cand {
-  float d2;
-  uint32_t idx;
-};
-__device__ __forceinline__ bool cand_less(const Cand &a, const Cand &b)
+// (d2, index) candidates ordered lexicographically: equal distances resolve to the lower point index (the
+// oracle's stable insertion has the same rule; FLANN's own tie order is tree dependent).
+// A candidate is ONE 64-bit key, (bits of d2) << 32 | index: d2 is a sum of squares, never negative, so the
+// unsigned order of the keys is that lexicographic order and a wavefront arg-min is six 64-bit butterflies.
+typedef unsigned long long KnnKey;
+constexpr KnnKey kKnnNone = ~0ull;   // the d2 half is a NaN pattern: never a real candidate
+__device__ __forceinline__ KnnKey knn_key(float d2, uint32_t idx) { return ((KnnKey)__float_as_uint(d2) << 32) | (KnnKey)idx; }
+__device__ __forceinline__ KnnKey wave_min_key(KnnKey v)
 {
-  return a.d2 < b.d2 || (a.d2 == b.d2 && a.idx < b.idx);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const KnnKey o = __shfl_xor(v, off);
+    v = o < v ? o : v;
+  }
+  return v;
 }
 
 constexpr int kKnnMaxK = 32;
 constexpr int kKnnThreads = 256;
+constexpr int kKnnWaves = kKnnThreads / 64;
 
-// Stage 1: grid (chunks, nb).  Each thread keeps the k best of its strided points in a
-// private sorted LDS list; the block then extracts its k best by k rounds of a block-wide
-// arg-min.  FLANN L2_Simple distance: ((du*du) + dv*dv) + dz*dz in fp32, query (cx, cy, 0).
-__global__ void __launch_bounds__(kKnnThreads) k_knn_stage1(const float *__restrict__ pu,
-                                                            const float *__restrict__ pv,
+// Stage 1: grid (chunks, nb), four wavefronts per workgroup, each on its own slice of the chunk and with its
+// own running top-k (lane r holds the r-th best).  A lane's candidate is looked at only if it beats the
+// wavefront's k-th best so far; survivors are appended -- ballot-compacted, no divergence -- to the wavefront's
+// LDS buffer, and when 64 or more have gathered the buffer and the old top-k are merged by k rounds of
+// wavefront arg-min.  The threshold tightens with every merge (after 64, ~500, ~4000 points ...), so a slice of
+// 8000 points sees three or four merges and a few hundred survivors.  (Round 2 kept a sorted list per THREAD:
+// 122 points per thread make a loose threshold, some lane of the wavefront inserted on almost every iteration
+// and the divergent insertion loops were the whole 0.4 ms.)  FLANN L2_Simple distance: ((du*du) + dv*dv) + dz*dz
+// in fp32, query (cx, cy, 0).
+constexpr int kKnnBuf = 128;
+__global__ void __launch_bounds__(kKnnThreads) k_knn_stage1(const float *__restrict__ pu, const float *__restrict__ pv,
                                                             const float *__restrict__ pd, uint32_t n,
                                                             const gv_bbox *__restrict__ bboxes, int k,
-                                                            Cand *__restrict__ partial)
+                                                            KnnKey *__restrict__ partial)
 {
-  extern __shared__ Cand s_list[];   // [threads][k]
-  __shared__ Cand s_red[kKnnThreads];
-  __shared__ int s_head[kKnnThreads];
-  const int tid = threadIdx.x, b = blockIdx.y;
+  __shared__ KnnKey s_buf[kKnnWaves][kKnnBuf];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, b = blockIdx.y;
   const gv_bbox bb = bboxes[b];
   const float qx = (float)(bb.x_min + ((bb.x_max - bb.x_min) / 2.0f));   // :57
   const float qy = (float)(bb.y_min + ((bb.y_max - bb.y_min) / 2.0f));   // :58
   const float qz = 0.0f;                                                  // :59
-  Cand *mine = s_list + (size_t)tid * k;
-  int cnt = 0;
+  KnnKey *buf = s_buf[w];
+  KnnKey mytop = kKnnNone;    // lane r: the r-th best so far (r < k)
+  KnnKey thresh = kKnnNone;   // the k-th best so far once k candidates exist
+  int nbuf = 0;               // wavefront-uniform
+  auto merge = [&]() {
+    KnnKey a0 = (lane < k) ? mytop : kKnnNone;
+    KnnKey a1 = (lane < nbuf) ? buf[lane] : kKnnNone;
+    KnnKey a2 = (lane + 64 < nbuf) ? buf[lane + 64] : kKnnNone;
+    KnnKey nt = kKnnNone;
+    for (int r = 0; r < k; ++r) {
+      KnnKey mn = a0 < a1 ? a0 : a1;
+      mn = a2 < mn ? a2 : mn;
+      const KnnKey best = wave_min_key(mn);
+      if (best == kKnnNone) break;
+      if (a0 == best) a0 = kKnnNone;   // keys are unique (the index half): exactly one copy exists
+      if (a1 == best) a1 = kKnnNone;
+      if (a2 == best) a2 = kKnnNone;
+      if (lane == r) nt = best;
+    }
+    mytop = nt;
+    nbuf = 0;
+    const unsigned tl = __builtin_amdgcn_readlane((unsigned)(mytop & 0xffffffffull), k - 1);
+    const unsigned th = __builtin_amdgcn_readlane((unsigned)(mytop >> 32), k - 1);
+    thresh = ((KnnKey)th << 32) | (KnnKey)tl;   // still "none" while fewer than k candidates exist
+  };
   const uint32_t per = (n + gridDim.x - 1) / gridDim.x;
   const uint32_t lo = blockIdx.x * per, hi = min(n, lo + per);
-  for (uint32_t i = lo + tid; i < hi; i += kKnnThreads) {
-    float d, r = 0.0f;
-    d = pu[i] - qx; r = __fadd_rn(r, __fmul_rn(d, d));
-    d = pv[i] - qy; r = __fadd_rn(r, __fmul_rn(d, d));
-    d = pd[i] - qz; r = __fadd_rn(r, __fmul_rn(d, d));
-    if (!(r == r)) continue;   // NaN never ranks
-    const Cand c{r, i};
-    if (cnt < k) {
-      int j = cnt++;
-      while (j > 0 && cand_less(c, mine[j - 1])) { mine[j] = mine[j - 1]; --j; }
-      mine[j] = c;
-    } else if (cand_less(c, mine[k - 1])) {
-      int j = k - 1;
-      while (j > 0 && cand_less(c, mine[j - 1])) { mine[j] = mine[j - 1]; --j; }
-      mine[j] = c;
+  constexpr int kBatch = 4;   // points per lane requested before the first is looked at
+  for (uint32_t base = lo; base < hi; base += kKnnThreads * kBatch) {   // the same trip count for every lane: the ballots need whole wavefronts
+    const uint32_t i0 = base + (uint32_t)tid;
+    float bu[kBatch], bv[kBatch], bd[kBatch];
+#pragma unroll
+    for (int q = 0; q < kBatch; ++q) {
+      const uint32_t i = i0 + (uint32_t)q * kKnnThreads;
+      const bool in = i < hi;
+      bu[q] = in ? pu[i] : 0.0f;
+      bv[q] = in ? pv[i] : 0.0f;
+      bd[q] = in ? pd[i] : __uint_as_float(0x7fc00000u);   // past the end: NaN, never ranks
+    }
+#pragma unroll
+    for (int q = 0; q < kBatch; ++q) {
+      const uint32_t i = i0 + (uint32_t)q * kKnnThreads;
+      float d = bu[q] - qx;
+      float r = __fmul_rn(d, d);
+      d = bv[q] - qy; r = __fadd_rn(r, __fmul_rn(d, d));
+      d = bd[q] - qz; r = __fadd_rn(r, __fmul_rn(d, d));
+      const KnnKey c = knn_key(r, i);
+      const bool ok = (r == r) && c < thresh;   // NaN never ranks
+      const unsigned long long mk = __ballot(ok);
+      if (mk) {
+        if (ok) buf[nbuf + __popcll(mk & ((1ull << lane) - 1ull))] = c;
+        nbuf += (int)__popcll(mk);
+        if (nbuf >= 64) merge();
+      }
     }
   }
-  // k rounds of block arg-min over the heads of the private sorted lists
-  s_head[tid] = 0;
-  const Cand none{INFINITY, 0xFFFFFFFFu};
-  for (int round = 0; round < k; ++round) {
-    const int h = s_head[tid];
-    s_red[tid] = (h < cnt) ? mine[h] : none;
-    __syncthreads();
-    for (int off = kKnnThreads / 2; off > 0; off >>= 1) {
-      if (tid < off && cand_less(s_red[tid + off], s_red[tid])) s_red[tid] = s_red[tid + off];
-      __syncthreads();
-    }
-    const Cand best = s_red[0];
-    if (tid == 0) partial[((size_t)b * gridDim.x + blockIdx.x) * k + round] = best;
-    if (h < cnt && mine[h].idx == best.idx) s_head[tid] = h + 1;   // the owner advances
-    __syncthreads();
-  }
+  if (nbuf) merge();
+  KnnKey *out = partial + (((size_t)b * gridDim.x + blockIdx.x) * kKnnWaves + w) * k;
+  if (lane < k) out[lane] = mytop;   // sorted ascending, "none" past the candidates found
 }
 
-// Stage 2: one block per bbox merges the chunk winners, writes the sorted squared
-// distances and the upper-median depth (nth_element at size/2, :78-81).
-__global__ void __launch_bounds__(kKnnThreads) k_knn_stage2(const Cand *__restrict__ partial, int nchunks, int k,
-                                                            const float *__restrict__ pd,
-                                                            float *__restrict__ depths,
-                                                            float *__restrict__ knn_d2)
+// Stage 2: one wavefront per bbox merges the sorted lists of stage 1 (a lane owns every 64th list and keeps
+// their heads in registers), writes the sorted squared distances and the upper-median depth (nth_element at
+// size/2, :78-81).
+constexpr int kKnnListsPerLane = 4;
+__global__ void __launch_bounds__(64) k_knn_stage2(const KnnKey *__restrict__ partial, int nlists, int k,
+                                                   const float *__restrict__ pd, float *__restrict__ depths,
+                                                   float *__restrict__ knn_d2)
 {
-  __shared__ Cand s_red[kKnnThreads];
-  __shared__ Cand s_best[kKnnMaxK];
-  const int tid = threadIdx.x, b = blockIdx.x;
-  const Cand *p = partial + (size_t)b * nchunks * k;
-  const int total = nchunks * k;
-  const Cand none{INFINITY, 0xFFFFFFFFu};
-  Cand last{-INFINITY, 0};
-  bool have_last = false;
-  for (int round = 0; round < k; ++round) {
-    Cand m = none;
-    for (int i = tid; i < total; i += kKnnThreads) {
-      const Cand c = p[i];
-      if (c.idx == 0xFFFFFFFFu) continue;
-      if (have_last && !cand_less(last, c)) continue;   // already taken
-      if (cand_less(c, m)) m = c;
-    }
-    s_red[tid] = m;
-    __syncthreads();
-    for (int off = kKnnThreads / 2; off > 0; off >>= 1) {
-      if (tid < off && cand_less(s_red[tid + off], s_red[tid])) s_red[tid] = s_red[tid + off];
-      __syncthreads();
-    }
-    last = s_red[0];
-    have_last = true;
-    if (tid == 0) s_best[round] = last;
-    __syncthreads();
+  __shared__ KnnKey s_best[kKnnMaxK];
+  const int lane = threadIdx.x, b = blockIdx.x;
+  const KnnKey *p = partial + (size_t)b * nlists * k;
+  int hp[kKnnListsPerLane];
+  KnnKey cur[kKnnListsPerLane];
+#pragma unroll
+  for (int q = 0; q < kKnnListsPerLane; ++q) {
+    const int l = lane + 64 * q;
+    hp[q] = 0;
+    cur[q] = (l < nlists) ? p[(size_t)l * k] : kKnnNone;
   }
-  if (tid == 0) {
+  for (int round = 0; round < k; ++round) {
+    KnnKey cand = cur[0];
+#pragma unroll
+    for (int q = 1; q < kKnnListsPerLane; ++q) cand = cur[q] < cand ? cur[q] : cand;
+    const KnnKey best = wave_min_key(cand);
+    if (best != kKnnNone) {
+#pragma unroll
+      for (int q = 0; q < kKnnListsPerLane; ++q)
+        if (cur[q] == best) {   // the owner advances that list
+          const int l = lane + 64 * q;
+          ++hp[q];
+          cur[q] = (hp[q] < k) ? p[(size_t)l * k + hp[q]] : kKnnNone;
+        }
+    }
+    if (lane == 0) s_best[round] = best;
+  }
+  __syncthreads();
+  if (lane == 0) {
     int cnt = 0;
     float dv[kKnnMaxK];
     for (int j = 0; j < k; ++j) {
-      const Cand c = s_best[j];
-      if (knn_d2) knn_d2[(size_t)b * k + j] = (c.idx == 0xFFFFFFFFu) ? INFINITY : c.d2;
-      if (c.idx != 0xFFFFFFFFu) dv[cnt++] = pd[c.idx];
+      const KnnKey c = s_best[j];
+      if (knn_d2) knn_d2[(size_t)b * k + j] = (c == kKnnNone) ? INFINITY : __uint_as_float((unsigned)(c >> 32));
+      if (c != kKnnNone) dv[cnt++] = pd[(uint32_t)(c & 0xffffffffull)];
     }
     float out = -1.0f;   // :49
     if (cnt > 0) {
@@ -182,77 +214,19 @@ __global__ void __launch_bounds__(kKnnThreads) k_knn_stage2(const Cand *__restri
   }
 }
 
+int knn_chunks() { return 64 * kKnnListsPerLane / kKnnWaves / 2; }   // 32 chunks x 4 wavefronts = 128 lists: two per lane
+size_t knn_partial_entries(int nb, int k) { return (size_t)nb * knn_chunks() * kKnnWaves * k; }
+
 void launch_knn(const float *pu, const float *pv, const float *pd, uint32_t n, const gv_bbox *bboxes, int nb, int k,
-                int nchunks, Cand2 *partial, float *depths, float *knn_d2, hipStream_t s)
+                Cand2 *partial, float *depths, float *knn_d2, hipStream_t s)
 {
   if (nb <= 0) return;
-  static_assert(sizeof(Cand2) == sizeof(Cand), "candidate layout");
-  hipLaunchKernelGGL(k_knn_stage1, dim3(nchunks, nb), dim3(kKnnThreads), (size_t)kKnnThreads * k * sizeof(Cand), s, pu,
-                     pv, pd, n, bboxes, k, reinterpret_cast<Cand *>(partial));
-  hipLaunchKernelGGL(k_knn_stage2, dim3(nb), dim3(kKnnThreads), 0, s, reinterpret_cast<const Cand *>(partial), nchunks, k,
+  static_assert(sizeof(Cand2) == sizeof(KnnKey), "candidate layout");
+  const int nchunks = knn_chunks();
+  hipLaunchKernelGGL(k_knn_stage1, dim3(nchunks, nb), dim3(kKnnThreads), 0, s, pu, pv, pd, n, bboxes, k,
+                     reinterpret_cast<KnnKey *>(partial));
+  hipLaunchKernelGGL(k_knn_stage2, dim3(nb), dim3(64), 0, s, reinterpret_cast<const KnnKey *>(partial), nchunks * kKnnWaves, k,
                      pd, depths, knn_d2);
-}
-
-// ---- RadiusOutlierRemoval neighbour counts --------------------------------------
-// Points are given grouped by bbox (segments).  keep[i] = 1 iff at least min_pts+1 points
-// of the same segment (the point itself included) lie within d2 <= r2f, where r2f is the
-// largest float not above the fp64 radius*radius (PCL >= 1.11 dense path).
-__global__ void __launch_bounds__(256) k_radius_count(const float *__restrict__ x, const float *__restrict__ y,
-                                                      const float *__restrict__ z,
-                                                      const int32_t *__restrict__ seg_of,
-                                                      const int32_t *__restrict__ seg_start, int32_t n_max,
-                                                      const int32_t *__restrict__ n_dev, float r2f,
-                                                      int32_t min_pts, uint8_t *__restrict__ keep)
-{
-  const int32_t n = n_dev ? min(n_max, *n_dev) : n_max;   // the number of gathered points may live on the device
-  if ((int)blockIdx.x * 256 >= n) return;
-  __shared__ float sx[256], sy[256], sz[256];
-  // one block per 256 consecutive points; a block may straddle segments, so each thread
-  // walks its own segment in tiles of 256 shared by the block when the tile ranges agree
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  const bool active = i < n;
-  int s0 = 0, s1 = 0;
-  float px = 0, py = 0, pz = 0;
-  if (active) {
-    const int sg = seg_of[i];
-    s0 = seg_start[sg];
-    s1 = seg_start[sg + 1];
-    px = x[i]; py = y[i]; pz = z[i];
-  }
-  // the block scans the union range of its threads' segments
-  __shared__ int s_lo, s_hi;
-  if (threadIdx.x == 0) { s_lo = 0x7fffffff; s_hi = 0; }
-  __syncthreads();
-  if (active) { atomicMin(&s_lo, s0); atomicMax(&s_hi, s1); }
-  __syncthreads();
-  const int lo = s_lo, hi = s_hi;
-  int cnt = 0;
-  for (int t0 = lo; t0 < hi; t0 += 256) {
-    const int j = t0 + threadIdx.x;
-    if (j < hi) { sx[threadIdx.x] = x[j]; sy[threadIdx.x] = y[j]; sz[threadIdx.x] = z[j]; }
-    __syncthreads();
-    if (active && cnt <= min_pts) {
-      const int jb = max(t0, s0), je = min(min(t0 + 256, hi), s1);
-      for (int jj = jb; jj < je; ++jj) {
-        float d, r = 0.0f;
-        d = sx[jj - t0] - px; r = __fadd_rn(r, __fmul_rn(d, d));
-        d = sy[jj - t0] - py; r = __fadd_rn(r, __fmul_rn(d, d));
-        d = sz[jj - t0] - pz; r = __fadd_rn(r, __fmul_rn(d, d));
-        cnt += (r <= r2f);
-      }
-    }
-    __syncthreads();
-  }
-  if (active) keep[i] = (uint8_t)(cnt >= min_pts + 1);
-}
-
-void launch_radius_count(const float *x, const float *y, const float *z, const int32_t *seg_of,
-                         const int32_t *seg_start, int32_t n_max, const int32_t *n_dev, float r2f, int32_t min_pts,
-                         uint8_t *keep, hipStream_t s)
-{
-  if (n_max <= 0) return;
-  hipLaunchKernelGGL(k_radius_count, dim3((n_max + 255) / 256), dim3(256), 0, s, x, y, z, seg_of, seg_start, n_max, n_dev,
-                     r2f, min_pts, keep);
 }
 
 }  // namespace gv

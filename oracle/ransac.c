@@ -13,10 +13,11 @@
  *     SampleConsensusModelPlane::computeModelCoefficients / isSampleGood (fp32);
  *   - inlier iff |n.p + d| < threshold (fp32 distance vs fp64 threshold), best = most
  *     inliers, first wins ties;
- *   - refinement: centroid + covariance of the inliers in fp64; every sum is taken by a fixed
- *     64-ary tree over the cloud order (below), so that a parallel implementation rounds the
- *     same way as this one; normal = eigenvector of the smallest eigenvalue (cyclic Jacobi),
- *     d = -n.centroid; the final inlier set is re-selected with the refined coefficients.
+ *   - refinement: one pass of fp64 raw moments of the inliers (as pcl::computeMeanAndCovarianceMatrix);
+ *     every sum is taken by a fixed 64-ary tree over the cloud order (below), so that a parallel
+ *     implementation rounds the same way as this one; covariance = Q/m - c c^T; normal = eigenvector
+ *     of the smallest eigenvalue (cyclic Jacobi), d = -n.centroid; the final inlier set is
+ *     re-selected with the refined coefficients.
  */
 #include "gv_oracle.h"
 
@@ -121,8 +122,14 @@ static double tree_sum64(double *v, size_t n)
   return v[0];
 }
 
-/* refined plane from the inliers of `coeff` (fp64, tree sums over the cloud order: a non-inlier
- * contributes +0.0); returns inlier count */
+/* refined plane from the inliers of `coeff`: ONE pass of fp64 raw moments (count, sums of x y z, sums of the
+ * six products -- each product of two fp32 coordinates is exact in fp64), every sum taken by the 64-ary tree
+ * over the cloud order (a non-inlier contributes +0.0); centroid c = S / m, covariance C_ij = Q_ij / m - c_i c_j
+ * (as pcl::computeMeanAndCovarianceMatrix, which SACSegmentation's optimizeModelCoefficients calls, accumulates
+ * [UPSTREAM-RECALL]); normal = eigenvector of the smallest eigenvalue, d = -n.c.  Returns the inlier count.
+ * (Round 3: the round-2 definition took the covariance in a second pass around the centroid; one pass is what
+ * PCL does and is one sweep of the cloud on the device.  tests/test_oracle_second_opinions.py holds the plane
+ * against numpy's SVD of the same inliers.) */
 size_t gvo_refine_plane(const float *x, const float *y, const float *z, size_t n, const float coeff[4],
                         double thr, float refined[4])
 {
@@ -132,26 +139,24 @@ size_t gvo_refine_plane(const float *x, const float *y, const float *z, size_t n
   size_t m = 0;
   for (size_t i = 0; i < n; ++i) m += (size_t)is_inlier(coeff, x[i], y[i], z[i], thr);
   if (m < 3) { free(buf); return m; }
-  double s[3];
-  const float *src[3] = {x, y, z};
-  for (int k = 0; k < 3; ++k) {
-    for (size_t i = 0; i < n; ++i) buf[i] = is_inlier(coeff, x[i], y[i], z[i], thr) ? (double)src[k][i] : 0.0;
-    s[k] = tree_sum64(buf, n);
-  }
-  const double cx = s[0] / (double)m, cy = s[1] / (double)m, cz = s[2] / (double)m;
-  double cov[6];
-  for (int k = 0; k < 6; ++k) {
+  double mom[9];   /* Sx Sy Sz Qxx Qxy Qxz Qyy Qyz Qzz */
+  for (int k = 0; k < 9; ++k) {
     for (size_t i = 0; i < n; ++i) {
       double t = 0.0;
       if (is_inlier(coeff, x[i], y[i], z[i], thr)) {
-        const double dx = x[i] - cx, dy = y[i] - cy, dz = z[i] - cz;
-        t = (k == 0) ? dx * dx : (k == 1) ? dx * dy : (k == 2) ? dx * dz : (k == 3) ? dy * dy : (k == 4) ? dy * dz : dz * dz;
+        const double dx = x[i], dy = y[i], dz = z[i];
+        t = (k == 0) ? dx : (k == 1) ? dy : (k == 2) ? dz : (k == 3) ? dx * dx : (k == 4) ? dx * dy : (k == 5) ? dx * dz
+          : (k == 6) ? dy * dy : (k == 7) ? dy * dz : dz * dz;
       }
       buf[i] = t;
     }
-    cov[k] = tree_sum64(buf, n);
+    mom[k] = tree_sum64(buf, n);
   }
   free(buf);
+  const double dm = (double)m;
+  const double cx = mom[0] / dm, cy = mom[1] / dm, cz = mom[2] / dm;
+  const double cov[6] = {mom[3] / dm - cx * cx, mom[4] / dm - cx * cy, mom[5] / dm - cx * cz,
+                         mom[6] / dm - cy * cy, mom[7] / dm - cy * cz, mom[8] / dm - cz * cz};
   double nv[3];
   gvo_smallest_eigenvector3(cov, nv);
   refined[0] = (float)nv[0]; refined[1] = (float)nv[1]; refined[2] = (float)nv[2];
