@@ -179,8 +179,7 @@ struct gv_context {
   double *d_rscratch = nullptr; size_t rscratch_cap = 0;   // tree-sum partials of the plane refinement
   RansacState *d_rstate = nullptr;
   uint32_t *d_blockcnt = nullptr; size_t blockcnt_cap = 0;   // per (1024-point block, bbox) counts of the kept-point split
-  gv_lshape_pose *d_pose_out = nullptr; size_t pose_out_cap = 0;
-  uint8_t *d_pose_valid = nullptr; size_t pose_valid_cap = 0;
+  uint8_t *d_pose_out = nullptr; size_t pose_out_cap = 0;   // one read-back block: nb poses | RansacState | nb valid flags
 
   bool counts_dirty = false;   // generic path: hits/miss/clip_end hold a kept frame
   bool have_hits = false, have_miss = false, have_cell_idx = false, have_bbox_id = false;
@@ -1322,7 +1321,7 @@ int gv_destroy(gv_handle h)
   void *bufs[] = {h->log_odds, h->occupancy, h->occ_i8, h->clip_end, h->miss8, h->sh_xchg, h->ray_list, h->ray_count, h->scratch_i32,
                   h->tx, h->ty, h->tz, h->d_pts, h->knn_partial, h->d_depths,
                   h->d_knn_d2, h->d_segstart, h->gx, h->gy, h->gz, h->d_nodes, h->d_drop, h->d_cellcnt, h->d_cellpre, h->d_celloff, h->d_planes,
-                  h->d_plane_counts, h->d_ground, h->d_rscratch, h->d_rstate, h->d_blockcnt, h->d_pose_out, h->d_pose_valid};
+                  h->d_plane_counts, h->d_ground, h->d_rscratch, h->d_rstate, h->d_blockcnt, h->d_pose_out};
   for (void *p : bufs)
     if (p) (void)hipFree(p);
 #ifdef GV_DIAG
@@ -2184,6 +2183,9 @@ static int ensure_ransac_buffers(gv_context *h, size_t n, int32_t iterations)
   return GV_OK;
 }
 
+static size_t pose_block_valid_off(int32_t nb) { return (size_t)nb * sizeof(gv_lshape_pose) + sizeof(RansacState); }
+static size_t pose_block_bytes(int32_t nb) { return pose_block_valid_off(nb) + (size_t)nb; }
+
 // extractCloudPerBBox -> RadiusOutlierRemoval -> centroid + PCA rectangle, all on the device and all enqueued
 // without a host wait in between; only the nb poses come back.  with_ground: the points of the refined RANSAC
 // plane in *d_rstate are dropped first (computeBBoxPose, cloud_detections.cpp:300-321), and the "empty segmented
@@ -2230,8 +2232,7 @@ static int enqueue_bbox_pose(gv_context *h, int32_t nb, bool with_ground, float 
   const size_t nblocks = (n + 1023) / 1024;
   if ((rc = grow(h, h->d_blockcnt, h->blockcnt_cap, nblocks * (size_t)nb + 16))) return rc;
   if ((rc = grow(h, h->d_segstart, h->segstart_cap, (size_t)nb + 2))) return rc;
-  if ((rc = grow(h, h->d_pose_out, h->pose_out_cap, (size_t)nb))) return rc;
-  if ((rc = grow(h, h->d_pose_valid, h->pose_valid_cap, (size_t)nb))) return rc;
+  if ((rc = grow(h, h->d_pose_out, h->pose_out_cap, pose_block_bytes(nb)))) return rc;
   if (!h->d_rstate) {
     GV_HIP(hipMalloc(reinterpret_cast<void **>(&h->d_rstate), sizeof(RansacState)));
     GV_HIP(hipMemsetAsync(h->d_rstate, 0, sizeof(RansacState), h->stream));
@@ -2246,7 +2247,9 @@ static int enqueue_bbox_pose(gv_context *h, int32_t nb, bool with_ground, float 
   // the kept points by bbox in cloud order (the reference appends in cloud order, :286), then centroid +
   // PCA rectangle per bbox in the reference's accumulation order (:156-247)
   launch_split_kept(h->bbox_id, h->d_drop, h->cx, h->cy, h->cz, h->m_cam, (uint32_t)n, nb, h->d_blockcnt, h->d_segstart, h->gx, h->gy, h->gz, s);
-  launch_pca_bbox(h->gx, h->gy, h->gz, h->d_segstart, nb, h->d_rstate, with_ground, (uint32_t)n, h->d_pose_out, h->d_pose_valid, s);
+  launch_pca_bbox(h->gx, h->gy, h->gz, h->d_segstart, nb, h->d_rstate, with_ground, (uint32_t)n,
+                  reinterpret_cast<gv_lshape_pose *>(h->d_pose_out), h->d_pose_out + pose_block_valid_off(nb),
+                  reinterpret_cast<RansacState *>(h->d_pose_out + (size_t)nb * sizeof(gv_lshape_pose)), s);
   GV_HIP(hipGetLastError());
   return GV_OK;
 }
@@ -2274,13 +2277,19 @@ static int compute_bbox_pose_impl(gv_handle h, const gv_bbox *bboxes, int32_t nb
   }
   if (nb) {
     if ((rc = enqueue_bbox_pose(h, nb, with_ground, thr_f))) return rc;
-    GV_HIP(hipMemcpyAsync(poses_out, h->d_pose_out, (size_t)nb * sizeof(gv_lshape_pose), hipMemcpyDeviceToHost, h->stream));
-    GV_HIP(hipMemcpyAsync(valid, h->d_pose_valid, (size_t)nb, hipMemcpyDeviceToHost, h->stream));
-  } else if (with_ground) {   // no boxes: the ground count still decides the return value
+    std::vector<uint8_t> blk(pose_block_bytes(nb));   // poses | state | flags: one copy, one wait
+    GV_HIP(hipMemcpyAsync(blk.data(), h->d_pose_out, blk.size(), hipMemcpyDeviceToHost, h->stream));
+    GV_HIP(hipStreamSynchronize(h->stream));
+    std::memcpy(poses_out, blk.data(), (size_t)nb * sizeof(gv_lshape_pose));
+    std::memcpy(valid, blk.data() + pose_block_valid_off(nb), (size_t)nb);
+    if (st_out) std::memcpy(st_out, blk.data() + (size_t)nb * sizeof(gv_lshape_pose), sizeof(RansacState));
+    return GV_OK;
+  }
+  if (with_ground) {   // no boxes: the ground count still decides the return value
     if ((rc = grow(h, h->d_ground, h->ground_cap, n))) return rc;
     launch_ransac_mask(h->cx, h->cy, h->cz, (uint32_t)n, h->m_cam, thr_f, h->d_rstate, h->d_ground, h->stream);
+    if (st_out) GV_HIP(hipMemcpyAsync(st_out, h->d_rstate, sizeof(RansacState), hipMemcpyDeviceToHost, h->stream));
   }
-  if (st_out) GV_HIP(hipMemcpyAsync(st_out, h->d_rstate, sizeof(RansacState), hipMemcpyDeviceToHost, h->stream));
   GV_HIP(hipStreamSynchronize(h->stream));
   return GV_OK;
   GV_CATCH

@@ -155,10 +155,29 @@ __device__ void smallest_eigenvector3_dev(const double cov[6], double v[3])
 
 constexpr int kMom = 10;   // Sx Sy Sz Qxx Qxy Qxz Qyy Qyz Qzz + the inlier count (as a double: exact)
 
+// lane i <- lane i + N inside its row of 16 (DPP row_shl:N; lanes whose source falls outside read 0.0 and hold
+// values nobody uses afterwards)
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v)
+{
+  const long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), CTRL, 0xF, 0xF, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xF, 0xF, true);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned long long)(unsigned)lo);
+}
+
+// The tree's butterfly v[i] += v[i + off], off = 32 .. 1; lane 0 ends with the sum of the 64 values in the
+// oracle's order (tree_sum64, oracle/ransac.c).  Only lanes below `off` matter at each step, so the four
+// in-row steps are DPP shifts on the operand (no LDS traffic); the two cross-row steps go through the
+// permute network.
 __device__ __forceinline__ double wave_butterfly(double v)
 {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v = v + __shfl_xor(v, off);
+  v = v + __shfl_down(v, 32);
+  v = v + __shfl_down(v, 16);
+  v = v + dpp_f64<0x108>(v);   // row_shl:8
+  v = v + dpp_f64<0x104>(v);   // row_shl:4
+  v = v + dpp_f64<0x102>(v);   // row_shl:2
+  v = v + dpp_f64<0x101>(v);   // row_shl:1
   return v;
 }
 
@@ -748,13 +767,21 @@ __global__ void __launch_bounds__(64) k_seg_scatter(const int16_t *__restrict__ 
   for (int b = lane; b < nb; b += 64) s_cur[b] = 0;
   __syncthreads();
   const size_t base = (size_t)blockIdx.x * kSegBlock;
-  for (int k0 = 0; k0 < kSegBlock; k0 += 64) {
-    const size_t i = base + k0 + lane;
+  int idb[kSegBlock / 64];   // this lane's ids of all 16 batches, requested together
+#pragma unroll
+  for (int q = 0; q < kSegBlock / 64; ++q) {
+    const size_t i = base + (size_t)q * 64 + lane;
     int id = -1;
     if (i < n) {
       id = drop[i] ? -1 : (int)ids[i];
       if (id >= nb) id = -1;
     }
+    idb[q] = id;
+  }
+#pragma unroll
+  for (int q = 0; q < kSegBlock / 64; ++q) {
+    const size_t i = base + (size_t)q * 64 + lane;
+    const int id = idb[q];
     unsigned long long todo = __ballot(id >= 0);
     while (todo) {   // one round per distinct bbox id of this batch
       const int leader = __ffsll((long long)todo) - 1;
@@ -796,12 +823,14 @@ __device__ __forceinline__ double lane_f64(double v, int l)
 __global__ void __launch_bounds__(64) k_pca_bbox(const float *__restrict__ gx, const float *__restrict__ gy,
                                                  const float *__restrict__ gz, const int32_t *__restrict__ seg_start, int nb,
                                                  const RansacState *__restrict__ st, int use_plane, uint32_t n_cloud,
-                                                 gv_lshape_pose *__restrict__ poses, uint8_t *__restrict__ valid)
+                                                 gv_lshape_pose *__restrict__ poses, uint8_t *__restrict__ valid,
+                                                 RansacState *__restrict__ st_copy)
 {
   __shared__ __attribute__((aligned(16))) float s_t[2][3][kPcaTile];    // [buffer][y | z | x][point]
   __shared__ __attribute__((aligned(16))) double s_p[2][3][kPcaTile];   // [buffer][aa | ab | bb][point]
   const int b = blockIdx.x, lane = threadIdx.x;
   if (b >= nb) return;
+  if (b == 0 && lane == 0 && st_copy) *st_copy = *st;   // the state rides home in the same block as the poses
   int s0 = seg_start[b], s1 = seg_start[b + 1];
   // computeBBoxPose :307-309: an empty segmented cloud (no plane found, or everything is ground) -> no poses
   if (use_plane && (st->best_count == 0 || st->n_inliers == 0ull || st->n_inliers == (unsigned long long)n_cloud)) s1 = s0;
@@ -941,10 +970,11 @@ void launch_split_kept(const int16_t *ids, const uint8_t *drop, const float *x, 
 }
 
 void launch_pca_bbox(const float *gx, const float *gy, const float *gz, const int32_t *seg_start, int nb, const RansacState *st,
-                     bool use_plane, uint32_t n_cloud, gv_lshape_pose *poses, uint8_t *valid, hipStream_t s)
+                     bool use_plane, uint32_t n_cloud, gv_lshape_pose *poses, uint8_t *valid, RansacState *st_copy, hipStream_t s)
 {
   if (nb <= 0) return;
-  hipLaunchKernelGGL(k_pca_bbox, dim3(nb), dim3(64), 0, s, gx, gy, gz, seg_start, nb, st, use_plane ? 1 : 0, n_cloud, poses, valid);
+  hipLaunchKernelGGL(k_pca_bbox, dim3(nb), dim3(64), 0, s, gx, gy, gz, seg_start, nb, st, use_plane ? 1 : 0, n_cloud, poses, valid,
+                     st_copy);
 }
 
 }  // namespace gv

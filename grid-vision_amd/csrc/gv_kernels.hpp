@@ -231,7 +231,8 @@ void launch_radius_filter(const float *x, const float *y, const float *z, uint32
 // stable split of the kept points by bbox id: seg_start[nb + 1], camera coordinates in segment order
 void launch_split_kept(const int16_t *ids, const uint8_t *drop, const float *x, const float *y, const float *z, const Mat34f &m_cam,
                        uint32_t n, int nb, uint32_t *block_counts, int32_t *seg_start, float *gx, float *gy, float *gz, hipStream_t s);
+// st_copy (optional): *st is copied there by the kernel (one read-back block for poses, flags and state)
 void launch_pca_bbox(const float *gx, const float *gy, const float *gz, const int32_t *seg_start, int nb, const RansacState *st,
-                     bool use_plane, uint32_t n_cloud, gv_lshape_pose *poses, uint8_t *valid, hipStream_t s);
+                     bool use_plane, uint32_t n_cloud, gv_lshape_pose *poses, uint8_t *valid, RansacState *st_copy, hipStream_t s);
 
 }  // namespace gv

@@ -16,7 +16,7 @@
 #include <tf2_ros/transform_listener.h>
 #include <visualization_msgs/msg/marker_array.hpp>
 
-#include <grid_vision/hip_backend.hpp>
+#include <grid_vision/frame_flow.hpp>
 
 namespace {
 gv_transform toGv(const geometry_msgs::msg::Transform &t)
@@ -68,7 +68,15 @@ public:
 
     ctx_ = std::make_unique<GridVisionContext>(grid_x, grid_y, resolution, cam);   // OccupancyGridMap ctor, K, K^-1
     occ_grid_ = std::make_unique<OccupancyGridMap>(*ctx_);
-    vision_ = std::make_unique<VisionOrientation>(*ctx_);
+    grid_vision::FlowParams fp;
+    fp.conf_threshold = conf_threshold_;
+    fp.iou_threshold = iou_threshold_;
+    fp.resize = resize_;
+    fp.k_near = k_near_;
+    fp.use_vision_orientation = use_vision_orientation_;
+    fp.lidar_binning = lidar_binning_;
+    fp.lidar_raymarch = lidar_raymarch_;
+    flow_ = std::make_unique<grid_vision::FrameFlow>(*ctx_, *occ_grid_, fp);
 
     if (image_topic_.empty() || lidar_topic_.empty()) {
       RCLCPP_ERROR(get_logger(), "Check if topic name or weight file is assigned");
@@ -111,58 +119,42 @@ private:
     }
   }
 
+  // The decisions of the reference's timerCallback (grid_vision_node.cpp:108-244) live in grid_vision::FrameFlow
+  // (grid-vision_amd/include/grid_vision/frame_flow.hpp, compiled and tested without ROS); this callback only
+  // converts: subscriptions -> TickInput, tf -> gv_transform, TickResult -> publishers.
   void timerCallback()
   {
-    if (!image_ && !have_cloud_) {   // same guard as the reference (&&, grid_vision_node.cpp:111)
-      publishOccupancyGrid();
-      return;
-    }
+    grid_vision::TickInput in;
+    in.have_image = static_cast<bool>(image_);
+    in.have_cloud = have_cloud_;
     std::vector<float> boxes, scores;
     int n = 0, c = 0;
-    std::vector<BoundingBox> bboxes;
-    if (image_ && detector_ && detector_(*image_, boxes, scores, n, c))
-      bboxes = object_detection::extract_bboxes(boxes.data(), scores.data(), n, c, conf_threshold_, iou_threshold_,
-                                                image_->width, image_->height, resize_);
-    if (bboxes.empty() && !lidar_binning_) {
-      occ_grid_->updateMap();
-      publishOccupancyGrid();
-      return;
+    if (image_) {
+      in.image_w = static_cast<int>(image_->width);
+      in.image_h = static_cast<int>(image_->height);
+      if (detector_ && detector_(*image_, boxes, scores, n, c)) {   // run_inference (:124-125)
+        in.det_boxes = boxes.data();
+        in.det_scores = scores.data();
+        in.n_det = n;
+        in.n_classes = c;
+      }
+      in.orientation_net = [this](const std::vector<BoundingBox> &dyn, std::vector<float> &orient, std::vector<float> &conf,
+                                  std::vector<float> &dims) {
+        if (!orientation_ || !orientation_(*image_, dyn, orient, conf, dims)) { orient.clear(); conf.clear(); dims.clear(); }
+      };
     }
     gv_transform cl{}, bc{}, bl{};
-    if (!lookup(camera_frame_, lidar_frame_, cl) || !lookup(base_frame_, camera_frame_, bc)
-        || !lookup(base_frame_, lidar_frame_, bl)) {
-      publishOccupancyGrid();   // tf failure: publish the stale grid (:160-164)
-      return;
-    }
-    ctx_->setTransforms(&cl, &bc, &bl);
-    auto [static_bboxes, dynamic_bboxes] = object_detection::filterBBoxes(bboxes);
-    if (!static_bboxes.empty()) {
-      depth_vec_ = cloud_detections::computeDepthForBoundingBoxes(*ctx_, static_bboxes, k_near_);
-      static_points_ = cloud_detections::convertPixelsTo3D(*ctx_, static_bboxes, depth_vec_);
-    }
-    std::vector<LShapePose> bboxes_pose;
-    if (!dynamic_bboxes.empty()) {
-      if (use_vision_orientation_) {
-        std::vector<float> orient, conf, dims;
-        if (orientation_ && orientation_(*image_, dynamic_bboxes, orient, conf, dims))
-          bboxes_pose = vision_->postProcessOutputs(orient.data(), conf.data(), dims.data(), dynamic_bboxes);
-      } else {
-        bboxes_pose = cloud_detections::computeBBoxPose(*ctx_, bboxes);   // the reference passes ALL bboxes (:215-216)
-      }
-      vision_->transformLShapeObjects(bboxes_pose);
-    }
-    if (lidar_binning_) {   // [EXTENSION] one fused frame: bin + ray-march + rectangles + grid pass
-      gv_frame_desc d{};
-      d.flags = GV_FRAME_BIN | (lidar_raymarch_ ? GV_FRAME_RAYMARCH : 0u);
-      d.poses = bboxes_pose.data();
-      d.n_poses = static_cast<int32_t>(bboxes_pose.size());
-      gv::check(gv_process_frame(ctx_->handle(), &d), ctx_->handle(), "gv_process_frame");
-    } else if (!bboxes_pose.empty()) {
-      occ_grid_->updateMap(bboxes_pose);
-    } else {
-      occ_grid_->updateMap();
-    }
-    publishOccupancyGrid();
+    const bool tf_ok = lookup(camera_frame_, lidar_frame_, cl) && lookup(base_frame_, camera_frame_, bc)
+                       && lookup(base_frame_, lidar_frame_, bl);
+    if (tf_ok) ctx_->setTransforms(&cl, &bc, &bl);
+    flow_->setTransformsAvailable(tf_ok);
+    const grid_vision::TickResult r = flow_->tick(in);
+    if (!r.warning.empty()) RCLCPP_WARN(get_logger(), "%s", r.warning.c_str());
+    depth_vec_ = r.depth_vec;
+    static_points_ = r.cam_points;
+    if (r.publish_grid) publishOccupancyGrid();
+    // (publishObjectDetections / publishObjectVisualizations, :246-263,405-523: r.publish_detections, r.bboxes,
+    //  r.bboxes_pose, r.cam_points carry what they draw)
   }
 
   void publishOccupancyGrid()
@@ -190,7 +182,7 @@ private:
   bool use_vision_orientation_ = false, lidar_binning_ = false, lidar_raymarch_ = false, have_cloud_ = false;
   std::unique_ptr<GridVisionContext> ctx_;
   std::unique_ptr<OccupancyGridMap> occ_grid_;
-  std::unique_ptr<VisionOrientation> vision_;
+  std::unique_ptr<grid_vision::FrameFlow> flow_;
   sensor_msgs::msg::Image::ConstSharedPtr image_;
   std::vector<float> depth_vec_;
   std::vector<geometry::Point> static_points_;

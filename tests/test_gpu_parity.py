@@ -754,6 +754,80 @@ def test_cpp_demo(gvamd, tmp_path):
     h.close()
 
 
+def test_cpp_flow_demo(gvamd, tmp_path):
+    """grid-vision_amd/include/grid_vision/frame_flow.hpp: the decision flow of the reference's timerCallback
+    (grid_vision_node.cpp:108-244) as a ROS-free class, driven through all six branches by examples/flow_demo.cpp
+    (plain g++ over the C ABI).  Branch taken, box / pose counts, first static depth and the published grid's
+    checksum after every tick must equal the same sequence replayed through the ctypes binding."""
+    import re
+    import subprocess
+    root = os.path.dirname(HERE)
+    pkg = os.path.join(root, "grid-vision_amd")
+    exe = str(tmp_path / "flow_demo")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", os.path.join(pkg, "examples", "flow_demo.cpp"), "-o", exe,
+                           "-L" + pkg, "-lgridvision_hip", "-Wl,-rpath," + pkg])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    ticks = []
+    for ln in out.stdout.splitlines():
+        m = re.match(r"tick (\d+) branch (\S+) bboxes (\d+) static (\d+) dynamic (\d+) depths (\d+) poses (\d+) "
+                     r"publish_detections (\d) sum_i8 (-?\d+) depth0 (\S+)", ln)
+        assert m, ln
+        ticks.append(m.groups())
+    assert [t[1] for t in ticks] == ["missing_inputs", "no_detections", "no_transform", "vision_orientation", "cloud_pca",
+                                     "no_dynamic_objects"]
+    # the same cloud and ticks from python
+    n = 60000
+    with np.errstate(over="ignore"):
+        zz = synth._mix64(np.uint64(7) + np.arange(1, 3 * n + 1, dtype=np.uint64) * synth.GOLDEN)
+    u = ((zz >> np.uint64(40)).astype(np.float32) * np.float32(2.0 ** -24)).reshape(n, 3)
+    a, b_, c = u[:, 0], u[:, 1], u[:, 2]
+    f = np.float32
+    x, y, z = np.empty(n, f), np.empty(n, f), np.empty(n, f)
+    s0, s1, s2, s3 = slice(0, 30000), slice(30000, 40000), slice(40000, 50000), slice(50000, n)
+    x[s0] = f(2) + f(38) * a[s0]; y[s0] = f(-9) + f(18) * b_[s0]; z[s0] = f(-1.7) + f(0.02) * (c[s0] - f(0.5))
+    x[s1] = f(11) + f(2.4) * a[s1]; y[s1] = f(-2.6) + f(1.2) * b_[s1]; z[s1] = f(-1.2) + f(1.3) * c[s1]
+    x[s2] = f(17) + f(1.0) * a[s2]; y[s2] = f(2.5) + f(3.0) * b_[s2]; z[s2] = f(-1.2) + f(1.3) * c[s2]
+    x[s3] = f(-8) + f(48) * a[s3]; y[s3] = f(-9.5) + f(19) * b_[s3]; z[s3] = f(-1.5) + f(4) * c[s3]
+    h = gvamd.GridVisionHIP(50, 20, 0.1)
+    h.upload_xyz(x, y, z)
+    full = np.array([(330, 200, 460, 330, 0.95, 9), (150, 180, 280, 330, 0.9, 2), (420, 100, 470, 160, 0.8, 5),
+                     (40, 60, 100, 120, 0.7, 7)], dtype=synth.BBOX_DTYPE)
+    only_static = full[2:]
+
+    def grid_sum():
+        return int(h.to_occupancy_grid()[0].astype(np.int64).sum())
+
+    def expect(t, bboxes, nst, ndy, ndepth, nposes, pub, depth0=None):
+        assert (int(t[2]), int(t[3]), int(t[4]), int(t[5]), int(t[6]), int(t[7])) == (bboxes, nst, ndy, ndepth, nposes, pub), t
+        assert int(t[8]) == grid_sum(), t
+        if depth0 is not None:
+            assert abs(float(t[9]) - depth0) < 1e-5, t
+
+    expect(ticks[0], 0, 0, 0, 0, 0, 0)                     # nothing happened: the initial grid
+    h.update_map()
+    expect(ticks[1], 0, 0, 0, 0, 0, 0)
+    expect(ticks[2], 4, 2, 2, 0, 0, 0)                     # tf failure: stale grid
+    h.set_transforms([0.5, -0.5, 0.5, 0.5, 0.0, 0.4, -0.3], [0.5, -0.5, 0.5, -0.5, 0.3, 0.0, 2.2], [0, 0, 0, 1, 0, 0, 1.8])
+    st, dy = gvamd.filter_bboxes(full)
+    depths, _ = h.compute_depth_for_bboxes(st, 4)
+    orient = np.tile(np.array([0.8, 0.6, -0.6, 0.8], np.float32), (len(dy), 1))
+    conf = np.tile(np.array([0.3, 0.7], np.float32), (len(dy), 1))
+    dims = np.full((len(dy), 3), 0.1, np.float32)
+    poses = h.transform_lshape_objects(h.vision_post_process(orient, conf, dims, dy))
+    h.update_map_poses(poses)
+    expect(ticks[3], 4, 2, 2, 2, len(poses), 1, float(depths[0]))
+    pp, valid, npz = h.compute_bbox_pose_ground_removed(full)
+    kept = pp[valid.astype(bool)] if npz >= 0 else pp[:0]
+    h.update_map_poses(h.transform_lshape_objects(kept))
+    expect(ticks[4], 4, 2, 2, 2, len(kept), 1, float(depths[0]))
+    assert len(kept) >= 2                                   # the two blobs give poses once the ground is gone
+    d2, _ = h.compute_depth_for_bboxes(only_static, 4)
+    h.update_map()
+    expect(ticks[5], 2, 2, 0, 2, 0, 1, float(d2[0]))
+    h.close()
+
+
 @pytest.mark.timeout(600)
 def test_config5_full_size(gvamd):
     """BASELINE configs[4] at full size on one GPU: 10M points, 4000x4000 @ 0.05 m
