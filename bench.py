@@ -58,6 +58,8 @@ def parse():
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 child passes (traffic = null)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--min-reps", type=int, default=5, help="repetitions of the K-step timed region (median reported)")
+    ap.add_argument("--force-sharded", action="store_true",
+                    help="config 5 through the sharded (RCCL) frame even with one rank: rehearses the code path on one GPU")
     ap.add_argument("--rehearsal", action="store_true",
                     help="allow more ranks than GPUs (ranks share devices, gloo barrier): reported as rehearsal")
     return ap.parse_args()
@@ -588,7 +590,7 @@ def main():
     tfs = synth.transforms(perturbed=True)
     bboxes = synth.detections(config)
     poses = synth.lshape_poses(config)
-    sharded = (config == 5 and world > 1)
+    sharded = config == 5 and (world > 1 or a.force_sharded)
     if config == 5:
         # configs[4]: ONE 10M-point frame (half lidar-like, half uniform); with world > 1 the points are
         # partitioned N/world per rank and the exchange happens inside the library (RCCL)
@@ -610,7 +612,8 @@ def main():
     h.set_detections(flags, bboxes=bboxes, poses=poses)
     if sharded:
         uid = [gvamd.GridVisionHIP.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(uid, src=0)
+        if dist is not None:
+            dist.broadcast_object_list(uid, src=0)
         h.comm_init(uid[0], rank, world)
 
     def barrier():
@@ -622,7 +625,7 @@ def main():
 
     def step():
         if sharded:
-            h.process_frame_sharded(flags, bboxes=bboxes, poses=poses)   # synchronous, collective
+            h.enqueue_frame_sharded()   # asynchronous, collective: exchanges of frame f overlap the binning of f + 1
         else:
             h.enqueue_frame()
 
@@ -648,6 +651,37 @@ def main():
     dt = float(np.median(reps))
     frames = a.steps if sharded else a.steps * world   # sharded: all ranks work on the same frame
     fps = frames / dt
+    shard_extra = None
+    if sharded:
+        # collective extras: per-step device times (frames one at a time) and the H2D-inclusive rate -- every rank
+        # uploads only ITS N / world slice per frame, so the ingest bandwidth of the job is `world` PCIe links
+        steps_ms = h.time_frame_sharded_stages(5)
+        blk = gvamd.PinnedF32(3 * N)
+        blk.array[:N], blk.array[N:2 * N], blk.array[2 * N:] = x, y, z
+
+        def one_h2d():
+            h.upload_xyz_async(blk.array[:N], blk.array[N:2 * N], blk.array[2 * N:])
+            h.enqueue_frame_sharded()
+        for _ in range(8):
+            one_h2d()
+        barrier()
+        th0 = time.perf_counter()
+        nh = 30
+        for _ in range(nh):
+            one_h2d()
+        barrier()
+        dth = time.perf_counter() - th0
+        if dist is not None:
+            t = torch.tensor([dth], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dth = float(t.item())
+        h.synchronize()
+        blk.close()
+        shard_extra = {"steps_ms": steps_ms, "steps_ms_sum": sum(steps_ms.values()),
+                       "with_h2d_frames_per_s": nh / dth, "with_h2d_ms_per_frame": dth / nh * 1e3,
+                       "h2d_bytes_per_rank_per_frame": 12 * N,
+                       "note": "steps: device time of each step with frames run one at a time (no overlap); with_h2d: a fresh "
+                               "cloud slice from pinned host memory per rank and frame, asynchronous"}
 
     out = None
     if rank == 0:
@@ -689,10 +723,12 @@ def main():
         }
         if rehearsal:
             out["rehearsal"] = True
+        if shard_extra:
+            out["sharded"] = shard_extra
         pmc, pmc_err = (None, "skipped")
         if not a.plain and not a.no_pmc and world == 1:
             h.synchronize()
-            pmc, pmc_err = pmc_child_passes(config, "")
+            pmc, pmc_err = pmc_child_passes(config, "") if not sharded else (None, "skipped for the sharded frame")
         kernels = []
         for st, ms in stages.items():
             if st == "detections":

@@ -189,6 +189,9 @@ struct gv_context {
   int32_t rank = 0, world = 1;
   uint32_t *sh_xchg = nullptr;    // exchange scratch: `world` received slices / packed bands
   size_t sh_xchg_cap = 0;
+  hipStream_t stream_x = nullptr; // the exchanges of the sharded frame (created by gv_comm_init)
+  hipEvent_t ev_sh[kRing][5]{};   // per frame slot: binning, exchange 1, sectors + packing, exchange 2, grid pass done
+  hipEvent_t sh_t[7]{};           // stage timing of the sharded frame (gv_time_frame_sharded_stages)
 
   hipEvent_t ev[kNumStages + 1]{};
   // stage timing (gv_time_frame_stages): start / end of the partition, tile-pass, sector and grid-pass kernels,
@@ -243,6 +246,7 @@ int drain(gv_context *h)
   GV_HIP(hipStreamSynchronize(h->stream));
   GV_HIP(hipStreamSynchronize(h->stream2));
   GV_HIP(hipStreamSynchronize(h->stream3));
+  if (h->stream_x) GV_HIP(hipStreamSynchronize(h->stream_x));
   h->pipe_busy = false;
   h->last_fin_slot = -1;
   for (int &q : h->set_fin_slot) q = -1;
@@ -541,8 +545,6 @@ int enqueue_plain_update(gv_context *h, int32_t n_rects)
   return GV_OK;
 }
 
-int sharded_tail(gv_context *h, const Rect *rects, int32_t n_rects);
-
 // sector-kernel launch parameters for the resident cloud and grid, buffer set p
 int fill_sector_args(gv_context *h, SectorArgs &sa, int p)
 {
@@ -796,7 +798,7 @@ int wait_inputs(gv_context *h, CloudSet &C, DetSet &D, int k)
 // back on one in-order stream, then the grid pass on the public stream.  pipelined: the stream of lane
 // n % 2 and buffer set 1 + n % 4 (n = lane frames so far), the grid pass behind one event.  Serial
 // (GV_PIPELINE=0, stage timing, the sharded frame): everything on the public stream, buffer set 0.
-int enqueue_frame_tiles(gv_context *h, bool pipelined, bool stage_events, bool sharded = false)
+int enqueue_frame_tiles(gv_context *h, bool pipelined, bool stage_events)
 {
   DetSet &D = h->det[h->det_cur];
   const uint32_t fl = D.flags;
@@ -804,7 +806,6 @@ int enqueue_frame_tiles(gv_context *h, bool pipelined, bool stage_events, bool s
   const bool keep_cell = fl & GV_FRAME_KEEP_CELL_IDX;
   int rc = check_frame_flags(h, fl);
   if (rc) return rc;
-  if (sharded && (!do_bin || !h->comm)) return GV_ERR_STATE;
   const int p = pipelined ? 1 + (int)(h->lane_frames % 4u) : 0;
   const int k = pipelined ? 1 + (int)(h->lane_frames % 2u) : 0;
   hipStream_t s = h->streams[k];
@@ -867,7 +868,6 @@ int enqueue_frame_tiles(gv_context *h, bool pipelined, bool stage_events, bool s
   h->cell_idx = h->cell_idx_s[k];
   h->have_cell_idx = do_bin && keep_cell;
   h->have_bbox_id = do_bbox;
-  if (sharded) return sharded_tail(h, rects, n_rects);
 
   // --- free-space ray stage.  On a lane its completion event rides the kernel's own dispatch packet.
   const int slot = (int)(h->frame_no % (uint64_t)gv_context::kRing);
@@ -1052,7 +1052,7 @@ int shard_all_to_all(const ShardLink &L, const uint32_t *send, uint32_t *recv, s
 
 size_t shard_ends_slice(const gv_context *h, int world)
 {
-  return (((h->ends_words + (size_t)world - 1) / (size_t)world) + 3) & ~(size_t)3;
+  return (size_t)gv_shard_slice_words((int64_t)h->ends_words, world);
 }
 
 int ensure_shard_scratch(gv_context *h, int world)
@@ -1087,28 +1087,69 @@ int shard_or_free_band(const ShardLink &L, int p, const uint32_t *packed, hipStr
   return GV_OK;
 }
 
-int sharded_tail(gv_context *h, const Rect *rects, int32_t n_rects)
+// The asynchronous sharded frame.  Three queues work on it: the frame's lane (binning, this rank's share of the
+// sector stage, band packing), the exchange stream X (RCCL: ends exchange, free-band exchange, band broadcast,
+// count reduce) and the public stream (the band's grid pass -- grid passes stay one in-order sequence).  Events
+// chain the steps of ONE frame; nothing orders frame f + 1's binning (the other lane) behind frame f's
+// exchanges, so they overlap.  RCCL calls are issued on X in the same order on every rank (x1, x2, x3 of frame
+// f, then of f + 1).  te (optional, 7 timing events): start, binning, x1, sectors, x2, grid pass, x3 done.
+int enqueue_frame_sharded(gv_context *h, hipEvent_t *te)
 {
-  hipStream_t s = h->stream;
-  const DetSet &D = h->det[h->det_cur];
-  const bool do_ray = D.flags & GV_FRAME_RAYMARCH, keep_counts = D.flags & GV_FRAME_KEEP_COUNTS;
-  ShardLink L{h, h->rank, h->world};
-  int rc = ensure_shard_scratch(h, h->world);
+  DetSet &D = h->det[h->det_cur];
+  const uint32_t fl = D.flags;
+  const bool do_bin = fl & GV_FRAME_BIN, do_ray = fl & GV_FRAME_RAYMARCH, do_bbox = fl & GV_FRAME_BBOX_TEST;
+  const bool keep_cell = fl & GV_FRAME_KEEP_CELL_IDX, keep_counts = fl & GV_FRAME_KEEP_COUNTS;
+  int rc = check_frame_flags(h, fl);
   if (rc) return rc;
+  if (!do_bin || !h->comm || !h->stream_x) return GV_ERR_STATE;
+  const int p = 1 + (int)(h->lane_frames % 4u);
+  const int k = 1 + (int)(h->lane_frames % 2u);
+  hipStream_t s = h->streams[k], X = h->stream_x;
+  if (h->set_fin_slot[p] >= 0) GV_HIP(hipEventSynchronize(h->ev_fin[h->set_fin_slot[p]]));   // back-pressure: four frames in flight
+  CloudSet &CS = h->cloud[h->cloud_cur];
+  if ((rc = wait_inputs(h, CS, D, k))) return rc;
+  if ((rc = ensure_shard_scratch(h, h->world))) return rc;
+  const int slot = (int)(h->frame_no % (uint64_t)gv_context::kRing);
+  hipEvent_t *ev = h->ev_sh[slot];
+  if (te) GV_HIP(hipEventRecord(te[0], s));
+  // --- lane: rectangles + binning of this rank's points into private end bitmaps
+  Rect *rects = h->x_rects[p];
+  const bool fold_rects = !(fl & GV_FRAME_VISION_ORIENT) && D.n_poses > 0;
+  const int32_t n_rects = fold_rects ? D.n_poses : enqueue_rects(h, D, rects, h->d_vout_s[k], s);
+  if ((rc = enqueue_binning(h, D, p, k, 0, h->n, keep_cell, do_ray, do_bbox, keep_counts, nullptr, fold_rects ? rects : nullptr)))
+    return rc;
+  if (te) GV_HIP(hipEventRecord(te[1], s));
+  GV_HIP(hipEventRecord(ev[0], s));
+  // --- X: complete end bitmaps everywhere (slices all-to-all + OR, then all-gather)
+  ShardLink L{h, h->rank, h->world};
   const size_t slice = shard_ends_slice(h, h->world);
-  // 1. complete end bitmaps everywhere
-  if ((rc = shard_or_ends_slice(L, h->x_ends[0], s))) return rc;
-  GV_NCCL(ncclAllGather(h->x_ends[0] + (size_t)h->rank * slice, h->x_ends[0], slice, ncclUint32, h->comm, s));
-  // 2. this rank's share of the ray stage, then the free cells of its band from everyone
-  if (do_ray && (rc = enqueue_sectors(h, 0, h->rank, h->world, s))) return rc;
+  GV_HIP(hipStreamWaitEvent(X, ev[0], 0));
+  if ((rc = shard_or_ends_slice(L, h->x_ends[p], X))) return rc;
+  GV_NCCL(ncclAllGather(h->x_ends[p] + (size_t)h->rank * slice, h->x_ends[p], slice, ncclUint32, h->comm, X));
+  if (te) GV_HIP(hipEventRecord(te[2], X));
+  GV_HIP(hipEventRecord(ev[1], X));
+  // --- lane: this rank's share of the ray stage, its free cells packed by band
+  GV_HIP(hipStreamWaitEvent(s, ev[1], 0));
+  if (do_ray && (rc = enqueue_sectors(h, p, h->rank, h->world, s))) return rc;
   const size_t chunk = free_band_chunk_words(h->nxw, h->nx_pad, h->ny_pad, h->world);
-  launch_pack_free_bands(h->x_freeN[0], h->x_freeT[0], h->nxw, h->nx_pad, h->ny_pad, h->world, chunk, h->sh_xchg, s);
+  launch_pack_free_bands(h->x_freeN[p], h->x_freeT[p], h->nxw, h->nx_pad, h->ny_pad, h->world, chunk, h->sh_xchg, s);
   GV_HIP(hipGetLastError());
-  if ((rc = shard_or_free_band(L, 0, h->sh_xchg, s))) return rc;
-  // 3. grid pass on the band, packed bands to everyone: band r sits at data[G - e_r, G - b_r)
+  if (te) GV_HIP(hipEventRecord(te[3], s));
+  GV_HIP(hipEventRecord(ev[2], s));
+  // --- X: the free cells of MY band from everyone
+  GV_HIP(hipStreamWaitEvent(X, ev[2], 0));
+  if ((rc = shard_or_free_band(L, p, h->sh_xchg, X))) return rc;
+  if (te) GV_HIP(hipEventRecord(te[4], X));
+  GV_HIP(hipEventRecord(ev[3], X));
+  // --- public stream: grid pass on the band (whole 64-row blocks)
   int32_t y0, y1;
   shard_band_rows(h->rank, h->world, h->g.ny, h->ny_pad, y0, y1);
-  if ((rc = enqueue_grid_pass(h, 0, rects, n_rects, true, y0, y1, s))) return rc;
+  GV_HIP(hipStreamWaitEvent(h->stream, ev[3], 0));
+  if ((rc = enqueue_grid_pass(h, p, rects, n_rects, true, y0, y1, h->stream))) return rc;
+  if (te) GV_HIP(hipEventRecord(te[5], h->stream));
+  GV_HIP(hipEventRecord(ev[4], h->stream));
+  // --- X: packed bands to everyone (band r sits at data[G - e_r, G - b_r)); band totals of the hit counts
+  GV_HIP(hipStreamWaitEvent(X, ev[4], 0));
   const size_t G = (size_t)h->g.G;
   ncclResult_t first_err = ncclGroupStart();
   for (int r = 0; r < h->world && first_err == ncclSuccess; ++r) {
@@ -1116,20 +1157,64 @@ int sharded_tail(gv_context *h, const Rect *rects, int32_t n_rects)
     shard_band_rows(r, h->world, h->g.ny, h->ny_pad, r0, r1);
     const size_t b = (size_t)r0 * h->g.nx, e = (size_t)r1 * h->g.nx;
     if (e > b) {
-      const ncclResult_t br = ncclBroadcast(h->occ_i8 + (G - e), h->occ_i8 + (G - e), e - b, ncclInt8, r, h->comm, s);
+      const ncclResult_t br = ncclBroadcast(h->occ_i8 + (G - e), h->occ_i8 + (G - e), e - b, ncclInt8, r, h->comm, X);
       if (br != ncclSuccess) first_err = br;
     }
   }
-  const ncclResult_t ge = ncclGroupEnd();   // always closed, also on the error path
+  ncclResult_t ge = ncclGroupEnd();   // always closed, also on the error path
   if (first_err == ncclSuccess) first_err = ge;
+  if (first_err == ncclSuccess && keep_counts) {
+    // reduce-scatter by band -- rank q ends with the summed counts of band q (in place, at the
+    // band's rows of its hits[]; the other rows keep this rank's partial counts).  Bands are whole 64-row blocks
+    // and may differ in length: equal bands are one ncclReduceScatter, otherwise one grouped ncclReduce per band.
+    int32_t *hk = h->hits_s[k];
+    bool equal = true;
+    size_t cnt0 = 0;
+    for (int r = 0; r < h->world; ++r) {
+      int32_t r0, r1;
+      shard_band_rows(r, h->world, h->g.ny, h->ny_pad, r0, r1);
+      const size_t c = (size_t)(r1 - r0) * h->g.nx;
+      if (r == 0) cnt0 = c;
+      equal = equal && c == cnt0 && (size_t)r0 * h->g.nx == (size_t)r * cnt0;
+    }
+    if (equal && cnt0) {
+      first_err = ncclReduceScatter(hk, hk + (size_t)h->rank * cnt0, cnt0, ncclInt32, ncclSum, h->comm, X);
+    } else {
+      first_err = ncclGroupStart();
+      for (int r = 0; r < h->world && first_err == ncclSuccess; ++r) {
+        int32_t r0, r1;
+        shard_band_rows(r, h->world, h->g.ny, h->ny_pad, r0, r1);
+        const size_t b = (size_t)r0 * h->g.nx, e = (size_t)r1 * h->g.nx;
+        if (e > b) first_err = ncclReduce(hk + b, hk + b, e - b, ncclInt32, ncclSum, r, h->comm, X);
+      }
+      ge = ncclGroupEnd();
+      if (first_err == ncclSuccess) first_err = ge;
+    }
+  }
   if (first_err != ncclSuccess) {
     h->err = std::string("sharded band exchange -> ") + ncclGetErrorString(first_err);
     return GV_ERR_RCCL;
   }
-  // hit counts are per-rank partial sums; the total only on request
-  if (keep_counts) GV_NCCL(ncclAllReduce(h->hits, h->hits, G, ncclInt32, ncclSum, h->comm, s));
-  h->have_hits = keep_counts;
-  h->have_miss = false;    // free-cell bitmaps are complete for this rank's band only
+  if (te) GV_HIP(hipEventRecord(te[6], X));
+  GV_HIP(hipEventRecord(h->ev_fin[slot], X));
+  // what the frame produced (the gathered packed grid) is visible on the public stream right behind it
+  GV_HIP(hipStreamWaitEvent(h->stream, h->ev_fin[slot], 0));
+  h->last_fin_slot = slot;
+  h->set_fin_slot[p] = slot;
+  CS.release_slot = slot;
+  D.release_slot = slot;
+  D.readers |= (1u << k) | 1u;
+  h->frame_no++;
+  h->lane_frames++;
+  h->pipe_busy = true;
+  h->last_set = p;
+  h->hits = h->hits_s[k];
+  h->bbox_id = h->bbox_id_s[k];
+  h->cell_idx = h->cell_idx_s[k];
+  h->have_cell_idx = keep_cell;
+  h->have_bbox_id = do_bbox;
+  h->have_hits = keep_counts;   // band totals at this rank's band rows (gv_comm_band)
+  h->have_miss = false;         // free-cell bitmaps are complete for this rank's band only
   return GV_OK;
 }
 
@@ -1137,7 +1222,7 @@ int sharded_tail(gv_context *h, const Rect *rects, int32_t n_rects)
 
 extern "C" {
 
-int gv_abi_version(void) { return 2; }
+int gv_abi_version(void) { return 3; }
 
 int gv_create(gv_handle *out, uint8_t grid_x, uint8_t grid_y, double resolution, const gv_cam_params *cam,
               int device_id)
@@ -1315,9 +1400,15 @@ int gv_destroy(gv_handle h)
 {
   if (!h) return GV_ERR_BAD_ARG;
   (void)hipSetDevice(h->device);
-  for (hipStream_t s : {h->stream_copy, h->stream, h->stream2, h->stream3})
+  for (hipStream_t s : {h->stream_copy, h->stream, h->stream2, h->stream3, h->stream_x})
     if (s) (void)hipStreamSynchronize(s);
   if (h->comm) { ncclCommDestroy(h->comm); h->comm = nullptr; }
+  for (auto &row : h->ev_sh)
+    for (auto &e : row)
+      if (e) (void)hipEventDestroy(e);
+  for (auto &e : h->sh_t)
+    if (e) (void)hipEventDestroy(e);
+  if (h->stream_x) (void)hipStreamDestroy(h->stream_x);
   void *bufs[] = {h->log_odds, h->occupancy, h->occ_i8, h->clip_end, h->miss8, h->sh_xchg, h->ray_list, h->ray_count, h->scratch_i32,
                   h->tx, h->ty, h->tz, h->d_pts, h->knn_partial, h->d_depths,
                   h->d_knn_d2, h->d_segstart, h->gx, h->gy, h->gz, h->d_nodes, h->d_drop, h->d_cellcnt, h->d_cellpre, h->d_celloff, h->d_planes,
@@ -2390,6 +2481,13 @@ int gv_comm_init(gv_handle h, const uint8_t id[128], int32_t rank, int32_t world
   GV_NCCL(ncclCommInitRank(&h->comm, world, uid, rank));
   h->rank = rank;
   h->world = world;
+  // the exchange stream of the sharded frame and the events that chain its steps (ordering only)
+  if (!h->stream_x) GV_HIP(hipStreamCreateWithFlags(&h->stream_x, hipStreamNonBlocking));
+  for (auto &row : h->ev_sh)
+    for (auto &e : row)
+      if (!e) GV_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  for (auto &e : h->sh_t)
+    if (!e) GV_HIP(hipEventCreate(&e));
   return GV_OK;
   GV_CATCH
 }
@@ -2399,12 +2497,24 @@ int gv_comm_destroy(gv_handle h)
   if (!h) return GV_ERR_BAD_ARG;
   if (!h->comm) return GV_OK;
   (void)hipSetDevice(h->device);
-  (void)hipStreamSynchronize(h->stream);
+  (void)drain(h);
   ncclCommDestroy(h->comm);
   h->comm = nullptr;
   h->rank = 0;
   h->world = 1;
   return GV_OK;
+}
+
+int gv_frame_enqueue_sharded(gv_handle h)
+{
+  if (!h) return GV_ERR_BAD_ARG;
+  if (!h->comm || !sector_path(h)) return GV_ERR_STATE;
+  GV_TRY
+  if (!h->det[h->det_cur].valid) return GV_ERR_STATE;   // no gv_frame_set_detections yet
+  int rc = set_device_only(h);
+  if (rc) return rc;
+  return enqueue_frame_sharded(h, nullptr);
+  GV_CATCH
 }
 
 int gv_process_frame_sharded(gv_handle h, const gv_frame_desc *desc)
@@ -2414,12 +2524,45 @@ int gv_process_frame_sharded(gv_handle h, const gv_frame_desc *desc)
   if (!sector_path(h)) return GV_ERR_STATE;
   int rc = gv_frame_set_detections(h, desc);
   if (rc) return rc;
+  if ((rc = gv_frame_enqueue_sharded(h))) return rc;
+  return gv_synchronize(h);
+}
+
+int gv_time_frame_sharded_stages(gv_handle h, int32_t frames, float stage_ms[6])
+{
+  if (!h || frames <= 0 || !stage_ms) return GV_ERR_BAD_ARG;
+  if (!h->comm || !sector_path(h)) return GV_ERR_STATE;
   GV_TRY
-  if ((rc = use_device(h))) return rc;
-  if ((rc = enqueue_frame_tiles(h, false, false, true))) return rc;
-  GV_HIP(hipStreamSynchronize(h->stream));
+  if (!h->det[h->det_cur].valid) return GV_ERR_STATE;
+  int rc = use_device(h);
+  if (rc) return rc;
+  for (int s = 0; s < 6; ++s) stage_ms[s] = 0.0f;
+  for (int32_t i = 0; i < frames; ++i) {   // one frame at a time: every step alone on the device
+    if ((rc = enqueue_frame_sharded(h, h->sh_t))) return rc;
+    if ((rc = drain(h))) return rc;
+    for (int s = 0; s < 6; ++s) {
+      float ms = 0.0f;
+      GV_HIP(hipEventElapsedTime(&ms, h->sh_t[s], h->sh_t[s + 1]));
+      stage_ms[s] += ms;
+    }
+  }
+  for (int s = 0; s < 6; ++s) stage_ms[s] /= (float)frames;
   return GV_OK;
   GV_CATCH
+}
+
+int gv_shard_band_rows(int32_t rank, int32_t world, int32_t ny, int32_t *y0, int32_t *y1)
+{
+  if (world < 1 || rank < 0 || rank >= world || ny < 1 || !y0 || !y1) return GV_ERR_BAD_ARG;
+  const int ny_pad = kBinTile * ((ny + kBinTile - 1) / kBinTile);
+  shard_band_rows(rank, world, ny, ny_pad, *y0, *y1);
+  return GV_OK;
+}
+
+int64_t gv_shard_slice_words(int64_t words, int32_t world)
+{
+  if (words < 0 || world < 1) return -1;
+  return (int64_t)(((((size_t)words + (size_t)world - 1) / (size_t)world) + 3) & ~(size_t)3);
 }
 
 // Test hook: the sharded frame for every rank of a `world`-GPU job, run on THIS device with the RCCL

@@ -43,7 +43,8 @@ ABI_SYMBOLS = [
     "gv_process_frame_sharded", "gv_comm_band",
     "gv_cloud_upload_xyz_async", "gv_cloud_upload_pointcloud2_async", "gv_cloud_upload_wait", "gv_host_alloc",
     "gv_host_free", "gv_frame_set_detections_async", "gv_frame_fence", "gv_debug_frame_sharded_emulated",
-    "gv_to_occupancy_grid_async",
+    "gv_to_occupancy_grid_async", "gv_frame_enqueue_sharded", "gv_time_frame_sharded_stages", "gv_shard_band_rows",
+    "gv_shard_slice_words",
 ]
 
 
@@ -132,6 +133,21 @@ def filter_bboxes(bboxes):
     if rc:
         raise GVError(rc, "gv_filter_bboxes")
     return st[:ns.value].copy(), dy[:nd.value].copy()
+
+
+def shard_band_rows(rank, world, ny):
+    """rows [y0, y1) rank `rank` of `world` finalises (the product's own band function; needs no GPU)"""
+    y0, y1 = C.c_int32(), C.c_int32()
+    rc = load().gv_shard_band_rows(C.c_int32(rank), C.c_int32(world), C.c_int32(ny), C.byref(y0), C.byref(y1))
+    if rc:
+        raise GVError(rc, "gv_shard_band_rows")
+    return y0.value, y1.value
+
+
+def shard_slice_words(words, world):
+    lib = load()
+    lib.gv_shard_slice_words.restype = C.c_int64
+    return int(lib.gv_shard_slice_words(C.c_int64(words), C.c_int32(world)))
 
 
 class PinnedF32:
@@ -441,6 +457,14 @@ class GridVisionHIP:
         b, e = C.c_int64(), C.c_int64()
         self._ck(self._lib.gv_comm_band(self._h, C.byref(b), C.byref(e)), "gv_comm_band")
         return b.value, e.value
+
+    def enqueue_frame_sharded(self):
+        self._ck(self._lib.gv_frame_enqueue_sharded(self._h), "frame_enqueue_sharded")
+
+    def time_frame_sharded_stages(self, frames):
+        ms = (C.c_float * 6)()
+        self._ck(self._lib.gv_time_frame_sharded_stages(self._h, C.c_int32(frames), ms), "time_frame_sharded_stages")
+        return dict(zip(("bin", "exchange_ends", "sectors", "exchange_free", "grid_pass", "gather"), [float(v) for v in ms]))
 
     def process_frame_sharded(self, flags, bboxes=None, poses=None, net=None):
         d = self._desc(flags, bboxes, poses, net)

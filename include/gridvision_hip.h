@@ -322,17 +322,32 @@ int gv_time_frame_stages(gv_handle h, int32_t frames, float *stage_ms);
  * slice into private ray-end bitmaps; the bitmaps are OR-ed across ranks (all-to-all of slices +
  * local OR + all-gather); every rank runs every world-th workgroup of the ray stage; the free-cell
  * bitmaps are OR-ed by row band (rank r receives band r), each rank finalises its band and the
- * packed int8 bands are broadcast.  After the call log_odds/occupancy are valid for the rank's own
- * band only (gv_comm_band), the int8 grid everywhere; gv_get_hits needs GV_FRAME_KEEP_COUNTS
- * (all-reduce of the per-rank counts), gv_get_miss returns GV_ERR_STATE.
+ * packed int8 bands are broadcast.  After the frame log_odds/occupancy are valid for the rank's own
+ * band only (gv_comm_band), the int8 grid everywhere.  With GV_FRAME_KEEP_COUNTS the hit counts are
+ * reduce-scattered by band: gv_get_hits then holds the SUMMED counts at the rank's band
+ * and this rank's partial counts elsewhere; gv_get_miss returns GV_ERR_STATE.
  * gv_comm_unique_id fills a 128-byte RCCL id on rank 0 (broadcast it by any
- * means); gv_comm_init joins the communicator. */
+ * means); gv_comm_init joins the communicator (and creates the handle's exchange stream). */
 int gv_comm_unique_id(uint8_t id_out[128]);
 int gv_comm_init(gv_handle h, const uint8_t id[128], int32_t rank, int32_t world);
 int gv_comm_destroy(gv_handle h);
-/* Sharded frame: same inputs as gv_frame_enqueue, but the resident cloud is
- * this rank's slice.  Synchronous. */
+/* Sharded frame, asynchronous: the counterpart of gv_frame_enqueue (same detection sets, same back-pressure of
+ * four frames in flight, results on the public stream behind it) for a resident cloud that is this rank's
+ * slice.  Binning, sector share and band packing run on the frame's lane, the RCCL exchanges on the handle's
+ * exchange stream, the band's grid pass on the public stream: frame f's exchanges overlap frame f+1's binning.
+ * Collective: every rank of the communicator must enqueue the same sequence of frames. */
+int gv_frame_enqueue_sharded(gv_handle h);
+/* = gv_frame_set_detections + gv_frame_enqueue_sharded + gv_synchronize */
 int gv_process_frame_sharded(gv_handle h, const gv_frame_desc *desc);
+/* Device time of the six steps of the sharded frame -- binning, ends exchange, sector share + packing, free-band
+ * exchange, band grid pass, band broadcast (+ count reduce) -- averaged over `frames` frames run one at a time.
+ * Collective. */
+int gv_time_frame_sharded_stages(gv_handle h, int32_t frames, float stage_ms[6]);
+/* Pure host helpers (no handle, no GPU): rows [*y0, *y1) rank `rank` of `world` finalises in a grid of `ny` rows
+ * (whole 64-row blocks of the grid padded to 128 rows, clipped to ny), and the words of one of the `world`
+ * equal slices a bitmap of `words` words is exchanged in.  The multi-rank CPU tests use the same functions. */
+int gv_shard_band_rows(int32_t rank, int32_t world, int32_t ny, int32_t *y0, int32_t *y1);
+int64_t gv_shard_slice_words(int64_t words, int32_t world);
 /* Band of cells [begin,end) this rank finalises (linear cell indices): whole 64-row blocks. */
 int gv_comm_band(gv_handle h, int64_t *begin, int64_t *end);
 /* Test hook (no RCCL, one device): runs the sharded frame for EVERY rank of a `world`-GPU job on

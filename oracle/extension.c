@@ -110,6 +110,22 @@ static uint64_t march(const gvo_grid *g, int32_t sx, int32_t sy, int32_t ex, int
   return (uint64_t)(nmark > 0 ? nmark : 0);
 }
 
+/* [EXTENSION] X2 for ray ends that are already known (ex, ey, kind as gvo_ray_end returns them; kind 0 entries
+ * are skipped): the march of gvo_raymarch without the points.  The multi-rank tests use it: after the first
+ * exchange of the sharded frame a rank holds END BITMAPS, not points. */
+void gvo_march_ends(const gvo_grid *g, double ox, double oy, const int32_t *ex, const int32_t *ey,
+                    const uint8_t *kind, size_t n, uint8_t *miss, uint64_t *visits)
+{
+  uint64_t v = 0;
+  int32_t ocx, ocy;
+  if (!gvo_get_index(g, ox, oy, &ocx, &ocy)) { if (visits) *visits = 0; return; }
+  for (size_t i = 0; i < n; ++i) {
+    if (!kind[i]) continue;
+    v += march(g, ocx, ocy, ex[i], ey[i], kind[i] == 2, miss);
+  }
+  if (visits) *visits = v;
+}
+
 void gvo_raymarch(const gvo_grid *g, const float m_base[16], const float *x, const float *y,
                   const float *z, size_t n, uint8_t *miss, int dedupe, uint64_t *visits)
 {

@@ -210,6 +210,9 @@ int gvo_ray_end(const gvo_grid *g, double ox, double oy, float px, float py, flo
  * each distinct (end cell, end kind) once (same result). */
 void gvo_raymarch(const gvo_grid *g, const float m_base[16], const float *x, const float *y,
                   const float *z, size_t n, uint8_t *miss, int dedupe, uint64_t *visits);
+/* [EXTENSION] X2 for known ray ends (kind 0 = none, 1 = hit end, 2 = clipped end); origin = (ox, oy) in the base frame */
+void gvo_march_ends(const gvo_grid *g, double ox, double oy, const int32_t *ex, const int32_t *ey,
+                    const uint8_t *kind, size_t n, uint8_t *miss, uint64_t *visits);
 /* [EXTENSION] one fused frame:  decay -> rectangles(poses) -> hit/miss rule ->
  * clamp -> sigmoid.  hits/miss are per-frame scratch (may be NULL => skipped). */
 void gvo_frame_update(gvo_grid *g, const gvo_lshape *poses, int32_t n_poses,

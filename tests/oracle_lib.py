@@ -157,6 +157,32 @@ class OGrid:
                            C.c_int(1 if dedupe else 0), C.byref(visits))
         return miss, visits.value
 
+    def ray_ends(self, m_base, x, y, z):
+        """(kind, ex, ey) of every point: kind 0 none, 1 hit end, 2 clipped end"""
+        bx, by, bz = transform_cloud(m_base, x, y, z)
+        ox, oy = float(f32(m_base).reshape(16)[3]), float(f32(m_base).reshape(16)[7])
+        n = len(bx)
+        kind = np.zeros(n, np.uint8)
+        ex, ey = np.zeros(n, np.int32), np.zeros(n, np.int32)
+        if not self.get_index(ox, oy)[0]:
+            return kind, ex, ey
+        cx, cy = C.c_int32(), C.c_int32()
+        L = lib()
+        for i in range(n):
+            kind[i] = L.gvo_ray_end(C.byref(self.g), C.c_double(ox), C.c_double(oy), C.c_float(bx[i]), C.c_float(by[i]),
+                                    C.c_float(bz[i]), C.byref(cx), C.byref(cy))
+            ex[i], ey[i] = cx.value, cy.value
+        return kind, ex, ey
+
+    def march_ends(self, m_base, ex, ey, kind):
+        m = f32(m_base).reshape(16)
+        miss = np.zeros(self.G, dtype=np.uint8)
+        ex, ey = np.ascontiguousarray(ex, np.int32), np.ascontiguousarray(ey, np.int32)
+        kind = np.ascontiguousarray(kind, np.uint8)
+        lib().gvo_march_ends(C.byref(self.g), C.c_double(float(m[3])), C.c_double(float(m[7])), _p(ex, C.c_int32),
+                             _p(ey, C.c_int32), _p(kind, C.c_uint8), C.c_size_t(len(ex)), _p(miss, C.c_uint8), None)
+        return miss
+
     def ray_end(self, ox, oy, px, py, pz=0.0):
         ex, ey = C.c_int32(), C.c_int32()
         k = lib().gvo_ray_end(C.byref(self.g), C.c_double(ox), C.c_double(oy), C.c_float(px),

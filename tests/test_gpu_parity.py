@@ -641,6 +641,28 @@ def test_sharded_frame_world1_matches_plain(gvamd):
         assert np.array_equal(ha.occupancy(), hb.occupancy())
         assert np.array_equal(ha.to_occupancy_grid()[0], hb.to_occupancy_grid()[0])
         assert np.array_equal(ha.bbox_id(), hb.bbox_id())
+    # asynchronous form: frames in flight on the lanes / the exchange stream / the public stream, detections changing
+    # in between, counts reduced by band (one band = the whole grid here)
+    kf = flags | gvamd.FRAME_KEEP_COUNTS
+    for frame in range(7):
+        bb, pp = synth.detections(3, 10 + 3 * frame, seed_extra=frame), synth.lshape_poses(config, 5 + 2 * frame, seed_extra=frame)
+        ha.set_detections(kf, bboxes=bb, poses=pp)
+        hb.set_detections_async(kf, bboxes=bb, poses=pp)
+        ha.enqueue_frame()
+        hb.enqueue_frame_sharded()
+        if frame % 3 == 2:
+            hb.enqueue_frame_sharded()
+            ha.enqueue_frame()
+    ha.synchronize(); hb.synchronize()
+    assert np.array_equal(ha.log_odds(), hb.log_odds())
+    assert np.array_equal(ha.to_occupancy_grid()[0], hb.to_occupancy_grid()[0])
+    assert np.array_equal(ha.hits(), hb.hits())
+    assert np.array_equal(ha.bbox_id(), hb.bbox_id())
+    st = hb.time_frame_sharded_stages(3)
+    assert set(st) == {"bin", "exchange_ends", "sectors", "exchange_free", "grid_pass", "gather"} and all(v >= 0 for v in st.values())
+    assert st["bin"] > 0 and st["grid_pass"] > 0
+    ha.enqueue_frame(); ha.enqueue_frame(); ha.enqueue_frame(); ha.synchronize()   # the three timed frames
+    assert np.array_equal(ha.log_odds(), hb.log_odds())
     hb.comm_destroy()
     ha.close(); hb.close()
 
