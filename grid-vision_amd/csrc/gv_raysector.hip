@@ -259,6 +259,25 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
     return mx;
   };
 
+  // largest reach among the ends [e0, e1) of one bucket whose slope b/a lies in [Plo/Q, Phi/Q) (a bound of
+  // +-0x7FFFFFFF = no bound on that side: a * 0x7FFFFFFF would overflow, so the unbounded sides are flags).
+  // Four ends per step: the LDS reads of a step are issued together instead of one dependent read per end.
+  auto walk_bucket = [&](unsigned e0, unsigned e1, int Q, int Plo, int Phi) -> unsigned {
+    const bool lo_open = Plo == -0x7FFFFFFF, hi_open = Phi == 0x7FFFFFFF;
+    unsigned mx = 0;
+    for (unsigned e = e0; e < e1; e += 4) {
+      unsigned p[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) p[q] = abv[min(e + (unsigned)q, e1 - 1u)];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int a = ab_a(p[q]), bq = ab_b(p[q]) * Q;
+        const bool in = (e + (unsigned)q < e1) && (lo_open || bq >= Plo * a) && (hi_open || bq < Phi * a);
+        mx = in ? max(mx, (unsigned)(a + (int)(p[q] & 1u))) : mx;
+      }
+    }
+    return mx;
+  };
   // one cell (column i, minor offset jc), exactly: whole buckets between its two boundary buckets by
   // range-max, the boundary buckets themselves end by end
   auto cell_exact = [&](int i, int Q, int jc) -> bool {
@@ -269,20 +288,10 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
     if (l <= r) mx = rmq(l, r);
     // a boundary bucket is only walked when its own max reach (level 0 of the range-max table) says that
     // one of its ends could decide the cell: beyond the threshold column most buckets hold short rays only
-    if (mx <= (unsigned)i && lo >= 0 && lo < M && (unsigned)lvl[lo] > (unsigned)i) {
-      for (unsigned e = bstart[lo]; e < bstart[lo + 1]; ++e) {
-        const unsigned p = abv[e];
-        const int a = ab_a(p), bq = ab_b(p) * Q;
-        if (bq >= Plo * a && (hi != lo || bq < Phi * a)) mx = max(mx, (unsigned)(a + (int)(p & 1u)));
-      }
-    }
-    if (mx <= (unsigned)i && hi >= 0 && hi < M && hi != lo && (unsigned)lvl[hi] > (unsigned)i) {
-      for (unsigned e = bstart[hi]; e < bstart[hi + 1]; ++e) {
-        const unsigned p = abv[e];
-        const int a = ab_a(p);
-        if (ab_b(p) * Q < Phi * a) mx = max(mx, (unsigned)(a + (int)(p & 1u)));
-      }
-    }
+    if (mx <= (unsigned)i && lo >= 0 && lo < M && (unsigned)lvl[lo] > (unsigned)i)
+      mx = max(mx, walk_bucket(bstart[lo], bstart[lo + 1], Q, Plo, (hi != lo) ? 0x7FFFFFFF : Phi));
+    if (mx <= (unsigned)i && hi >= 0 && hi < M && hi != lo && (unsigned)lvl[hi] > (unsigned)i)
+      mx = max(mx, walk_bucket(bstart[hi], bstart[hi + 1], Q, -0x7FFFFFFF, Phi));
     return mx > (unsigned)i;
   };
   // minor-offset range [blo, bhi] of the wedge in column a (empty when blo > bhi)
@@ -734,20 +743,10 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
         const unsigned e0l = bstart[loc], e1l = bstart[loc + 1];
         unsigned mxh = (hi >= 1) ? max(pf, bpf) : 0u;
         unsigned mxl = (lo + 1 <= M - 1) ? max(sf, bsf) : 0u;
-        if (mxh <= (unsigned)i && hi >= 0 && hi < M && (unsigned)lvl[hic] > (unsigned)i) {
-          for (unsigned e = e0h; e < e1h; ++e) {
-            const unsigned p = abv[e];
-            const int a = ab_a(p);
-            if (ab_b(p) * Q < Phi * a) mxh = max(mxh, (unsigned)(a + (int)(p & 1u)));
-          }
-        }
-        if (mxl <= (unsigned)i && lo >= 0 && lo < M && (unsigned)lvl[loc] > (unsigned)i) {
-          for (unsigned e = e0l; e < e1l; ++e) {
-            const unsigned p = abv[e];
-            const int a = ab_a(p);
-            if (ab_b(p) * Q >= Plo * a) mxl = max(mxl, (unsigned)(a + (int)(p & 1u)));
-          }
-        }
+        if (mxh <= (unsigned)i && hi >= 0 && hi < M && (unsigned)lvl[hic] > (unsigned)i)
+          mxh = max(mxh, walk_bucket(e0h, e1h, Q, -0x7FFFFFFF, Phi));
+        if (mxl <= (unsigned)i && lo >= 0 && lo < M && (unsigned)lvl[loc] > (unsigned)i)
+          mxl = max(mxl, walk_bucket(e0l, e1l, Q, Plo, 0x7FFFFFFF));
         if (mxh > (unsigned)i) mask |= 1u;
         if (mxl > (unsigned)i) mask |= 1u << (w - 1);
         // sectors with a lattice-gap run: the cell next to the edge cell is not covered by the level test
