@@ -128,6 +128,7 @@ struct gv_context {
   bool tile_path = false;                   // nx % 4 == 0 and the grid fits the packed (a,b) fields
   bool force_simple = false;                // GV_RAY_IMPL=simple
   int env_reorder = 1;                      // GV_SECTOR_REORDER=0: workgroups in natural (octant, sector) order
+  int env_helpers = -1;                     // GV_SECTOR_HELPERS: -1 automatic, 0 off, 1 on
   size_t stat_slots = 1;                    // ray statistics slots written by the last frame
   int32_t env_log2s_oct[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // GV_LOG2S_OCT="a,b,..." per octant index (sweeps)
   uint32_t env_march_limit = 64u * 512u;     // GV_MARCH_LIMIT
@@ -602,7 +603,10 @@ int fill_sector_args(gv_context *h, SectorArgs &sa, int p)
     sa.wg_base[k] = (uint16_t)base;
     base += 1u << sa.log2s_oct[sa.reorder ? ord[k] : k];
   }
-  if (base > kMaxStatSlots || base > 65535u) { h->err = "too many sector workgroups"; return GV_ERR_BAD_ARG; }
+  // second workgroups for the axis / diagonal sectors of every octant once the wedges are long enough to have
+  // heavy tails (GV_SECTOR_HELPERS=0 / 1 forces them off / on)
+  sa.n_helpers = (h->env_helpers >= 0) ? (h->env_helpers ? 16 : 0) : (imax >= 512 ? 16 : 0);
+  if (base + 16 > kMaxStatSlots || base > 65535u) { h->err = "too many sector workgroups"; return GV_ERR_BAD_ARG; }
   sa.wg_base[8] = (uint16_t)base;
   sa.hitN = h->x_hitN[p]; sa.clipN = h->x_clipN[p]; sa.hitT = h->x_hitT[p]; sa.clipT = h->x_clipT[p];
   sa.nxw = h->nxw; sa.nyw = h->nyw; sa.nx_pad = h->nx_pad; sa.ny_pad = h->ny_pad;
@@ -611,7 +615,7 @@ int fill_sector_args(gv_context *h, SectorArgs &sa, int p)
   sa.stats = h->x_stats[p];
   sa.wg_first = 0;
   sa.wg_stride = 1;
-  h->stat_slots = (size_t)sa.wg_base[8];
+  h->stat_slots = (size_t)sa.wg_base[8] + (size_t)sa.n_helpers;
   return GV_OK;
 }
 
@@ -1308,6 +1312,7 @@ int gv_create(gv_handle *out, uint8_t grid_x, uint8_t grid_y, double resolution,
       }
     }
     if (const char *e = std::getenv("GV_SECTOR_REORDER")) h->env_reorder = std::atoi(e) != 0;
+    if (const char *e = std::getenv("GV_SECTOR_HELPERS")) h->env_helpers = std::atoi(e) != 0;
     if (const char *e = std::getenv("GV_CAP")) h->env_cap = std::atoi(e);
     if (const char *e = std::getenv("GV_FLAT_K")) h->env_flat_k = std::max(0, std::atoi(e));
     if (const char *e = std::getenv("GV_MARCH_LIMIT")) h->env_march_limit = (uint32_t)std::max(0, std::atoi(e));

@@ -149,6 +149,7 @@ struct SectorArgs {
   uint32_t *freeT;        // free-cell bitmap, bits along y (written for x-major octants); same layout as hitT
   unsigned long long *stats;
   int32_t wg_first, wg_stride;   // this launch runs workgroups wg_first, wg_first + wg_stride, ... of the dispatch order
+  int32_t n_helpers;      // 0 or 16: second workgroups for the first / last sector of every octant, first in the dispatch order
   uint32_t march_limit;   // most ray cells beyond the threshold column a sector will march (else: exact per cell)
   int32_t flat_k;         // cost ratio exact-cell evaluation : marched cell for the choice beyond T (0: always march when possible)
   int32_t ablate;         // timing experiments only: 2 skip gather, 4 skip flush, 8/16/32 early exits

@@ -150,12 +150,19 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   // position in the dispatch order: a multi-GPU rank runs every wg_stride-th workgroup
-  const int bid = A.wg_first + (int)blockIdx.x * A.wg_stride;
+  const int bid_all = A.wg_first + (int)blockIdx.x * A.wg_stride;
   // Dispatch order (workgroups start roughly in blockIdx order and the launch is ~2 rounds deep):
-  // octants with the longest wedges first, and inside an octant the sectors next to the slopes
-  // 0, 1/2, 1 first (they run longest).  Every octant has its own sector count: a short wedge
+  // helpers first (below), then octants with the longest wedges, and inside an octant the sectors next to
+  // the slopes 0, 1/2, 1 first (they run longest).  Every octant has its own sector count: a short wedge
   // (origin close to that map edge) split into as many sectors as a long one would be all
   // fixed per-workgroup cost and no ends.
+  // Helpers: the first and the last sector of an octant (next to the axis / the diagonal) are the heaviest by
+  // far -- the ends there sit on few rational slopes, the "every bucket group holds a long ray" run ends early
+  // and hundreds of columns are evaluated cell by cell (70 k cycles against a 36 k mean: they set the kernel's
+  // makespan).  Each of them is run by TWO workgroups that build the same tables and take every second column
+  // of the evaluation.  Helper 2q + e = octant q of the dispatch order, sector e ? S - 1 : 0, odd columns.
+  const bool helper = bid_all < A.n_helpers;
+  const int bid = helper ? (int)A.wg_base[bid_all >> 1] : bid_all - A.n_helpers;   // (helpers: only k_oct is taken from it)
   int k_oct = 0;
 #pragma unroll
   for (int k = 1; k < 8; ++k) k_oct += (bid >= (int)A.wg_base[k]) ? 1 : 0;
@@ -168,15 +175,23 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
     if (r < 4) s = (r == 0) ? 0 : (r == 1) ? (S >> 1) - 1 : (r == 2) ? S - 1 : (S >> 1);
     else s = (r - 4 < (S >> 1) - 2) ? r - 3 : r - 1;
   }
-  const int wg = bid;   // diagnostics slot
+  if (helper) {
+    s = (bid_all & 1) ? S - 1 : 0;
+    if (S < 2 && (bid_all & 1)) return;   // one sector only: it has one helper
+  }
+  // column share: workgroup `part` of `nparts` evaluates the columns i with i % nparts == part
+  const int nparts = (A.n_helpers > 0 && (s == 0 || s == S - 1)) ? 2 : 1;
+  const int part = helper ? 1 : 0;
+  const int stat_slot = helper ? (int)A.wg_base[8] + bid_all : bid;
+  const int wg = stat_slot;   // diagnostics slot
   // a clipped ray that ends in the origin cell itself (a == 0, inclusive end)
-  if (bid == 0 && threadIdx.x == 0) {
+  if (bid == 0 && !helper && threadIdx.x == 0) {
     const size_t wo = (size_t)(A.org.cx >> 5) * A.ny_pad + A.org.cy;
     if ((A.clipN[wo] >> (A.org.cx & 31)) & 1u) atomicOr(&A.freeN[wo], 1u << (A.org.cx & 31));
   }
   const Oct oc = make_octant(o, A.g, A.org);
   if (oc.imax < 1) {
-    if (threadIdx.x == 0 && A.stats) { A.stats[2 * bid] = 0; A.stats[2 * bid + 1] = 0; }
+    if (threadIdx.x == 0 && A.stats) { A.stats[2 * stat_slot] = 0; A.stats[2 * stat_slot + 1] = 0; }
     return;
   }
   const int cap = A.cap;
@@ -379,7 +394,7 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
   stamp();   // 2: scan done
   if GV_ABL(16) return;   // timing experiment: + scan
   if (total == 0) {
-    if (tid == 0 && A.stats) { A.stats[2 * bid] = 0; A.stats[2 * bid + 1] = 0; }
+    if (tid == 0 && A.stats) { A.stats[2 * stat_slot] = 0; A.stats[2 * stat_slot + 1] = 0; }
     return;
   }
 
@@ -688,6 +703,7 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
           const int rch = a + (int)(p & 1u);
           const int half = a >> 1;
           for (int i = T + 1 + lane; i < rch; i += 64) {
+            if (nparts > 1 && (i & 1) != part) continue;   // the other workgroup of this sector marks that column
             // LineIterator stepping in closed form: j = (a/2 + i*b) / a
             const int num = half + i * b;
             int q = (int)((float)num * __builtin_amdgcn_rcpf((float)a));
@@ -707,7 +723,7 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
     // gather: one lane per column of the wedge
     const bool flat_tail = !march_tail && T < oc.imax && !GV_ABL(512);   // columns beyond T, every cell exactly
     const int gather_hi = (march_tail || flat_tail) ? T : oc.imax;
-    for (int i = tid; i <= (GV_ABL(2) ? -1 : gather_hi); i += NT) {
+    for (int i = tid * nparts + part; i <= (GV_ABL(2) ? -1 : gather_hi); i += NT * nparts) {
       if (i == 0) {
         marks[0] |= 1u;   // every ray (reach >= 1) starts in the origin cell
         continue;
@@ -769,16 +785,18 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
       // Too many long rays to march them: every cell of the columns T+1 .. (largest reach - 1) is
       // evaluated exactly, one (column, cell) pair per lane -- balanced over the 512 lanes, where a
       // lane per column would leave 60 % of them idle and walk ~16 cells in sequence.
-      const int first = T + 1;
+      const int first0 = T + 1;
+      const int first = first0 + ((nparts > 1 && (first0 & 1) != part) ? 1 : 0);   // this workgroup's first column
       const int last = min(oc.imax, (int)maxreach - 1);
       if (last >= first) {
         const int wlast = ((2 * last * (s + 1) + S) >> (log2s + 1)) - ((2 * last * s + S) >> (log2s + 1)) + 1;
         const int wfirst = ((2 * first * (s + 1) + S) >> (log2s + 1)) - ((2 * first * s + S) >> (log2s + 1)) + 1;
         const int wmax = max(wlast, wfirst) + 1;                 // w(i) grows with i, +-1 by rounding
         const int lw = 32 - __clz(max(wmax - 1, 1));             // cells per column rounded up to a power of two
-        const int ntask = (last - first + 1) << lw;
+        const int ncol = (last - first) / nparts + 1;
+        const int ntask = ncol << lw;
         for (int t = tid; t < ntask; t += NT) {
-          const int i = first + (t >> lw), k = t & ((1 << lw) - 1);
+          const int i = first + nparts * (t >> lw), k = t & ((1 << lw) - 1);
           const int jlo = (2 * i * s + S) >> (log2s + 1);
           const int jhi = (2 * i * (s + 1) + S) >> (log2s + 1);
           if (k > jhi - jlo) continue;
@@ -848,8 +866,8 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
     if (A.stats) {
       unsigned long long vsum = 0;
       for (int wv = 0; wv < NT / 64; ++wv) vsum += s_wvis[wv];
-      A.stats[2 * bid] = (unsigned long long)total;
-      A.stats[2 * bid + 1] = vsum;
+      A.stats[2 * stat_slot] = helper ? 0ull : (unsigned long long)total;   // a helper's rays are its partner's
+      A.stats[2 * stat_slot + 1] = helper ? 0ull : vsum;
     }
   }
 }
@@ -869,7 +887,7 @@ bool launch_ray_sectors(const SectorArgs &a, hipStream_t s, hipEvent_t done, hip
   const size_t lds = sector_lds_bytes(a.cap, a.marks_words, a.log2m);
   const int imax = std::max(std::max(a.org.cx, a.g.nx - 1 - a.org.cx), std::max(a.org.cy, a.g.ny - 1 - a.org.cy));
   // every wedge column lives in a register slot of one thread: CH * 512 >= imax
-  const int total = a.wg_base[8];
+  const int total = a.wg_base[8] + a.n_helpers;
   if (a.wg_first >= total) return false;
   const int grid = (total - a.wg_first + a.wg_stride - 1) / a.wg_stride;
   if (imax <= 4 * kSecThreads)
