@@ -103,14 +103,27 @@ __device__ __forceinline__ double rcp_newton(double d)
   r = fma(fma(-d, r, 1.0), r, r);
   return r;
 }
-__device__ __forceinline__ float div_to_float(double n, double d, double r)
+__device__ __forceinline__ bool div_risky(double q)
 {
-  const double q = n * r;
   const unsigned long long bits = (unsigned long long)__double_as_longlong(q);
   const unsigned low = (unsigned)bits & 0x1FFFFFFFu;
   const unsigned ex = (unsigned)(bits >> 52) & 0x7FFu;
-  const bool risky = (low - (0x10000000u - 128u)) <= 256u || ex < 1023u - 120u || ex > 1023u + 120u;
-  return risky ? (float)(n / d) : (float)q;
+  return (low - (0x10000000u - 128u)) <= 256u || ex < 1023u - 120u || ex > 1023u + 120u;
+}
+// (float)(n0 / d), (float)(n1 / d) given r ~ 1/d.  The exact divisions sit behind a WAVEFRONT-uniform branch: a
+// per-lane select lets the compiler speculate both divisions into the common path (13 fp64 instructions each,
+// executed for every point -- seen in the ISA of round 2's k_bin_partition); about one wavefront in 10^4 has a
+// risky lane.
+__device__ __forceinline__ void div2_to_float(double n0, double n1, double d, double r, float &o0, float &o1)
+{
+  const double q0 = n0 * r, q1 = n1 * r;
+  const bool k0 = div_risky(q0), k1 = div_risky(q1);
+  o0 = (float)q0;
+  o1 = (float)q1;
+  if (__ballot(k0 || k1) != 0ull) {
+    if (k0) o0 = (float)(n0 / d);
+    if (k1) o1 = (float)(n1 / d);
+  }
 }
 
 // [EXTENSION] X2 ray end of an out-of-map point: fp64 slab clip of
@@ -195,8 +208,8 @@ __device__ __forceinline__ int first_bbox(const CamK &cam, const BBoxTest &t, fl
     const double X = (double)cx, Y = (double)cy, Z = (double)cz;
     const double iz = Z;
     const double riz = rcp_newton(iz);
-    const float u = div_to_float(cam.k[0] * X + cam.k[2] * Z, iz, riz);   // :268-272  (float)(n / iz)
-    const float v = div_to_float(cam.k[4] * Y + cam.k[5] * Z, iz, riz);   // :273
+    float u, v;
+    div2_to_float(cam.k[0] * X + cam.k[2] * Z, cam.k[4] * Y + cam.k[5] * Z, iz, riz, u, v);   // :268-273  (float)(n / iz)
     if (!(u < 0 || u >= (float)cam.W || v < 0 || v >= (float)cam.H)) {   // :276
       // :280-288 first match wins
       const int tx = (int)u >> 4, ty = (int)v >> 4;

@@ -1,10 +1,10 @@
-"""Diagnostic (needs the -DGV_DIAG build: tools/build_diag.sh, GV_LIB_AB=gpurun_out/libgv_diag.so):
+"""Diagnostic (needs the -DGV_DIAG build: tools/build_diag.sh, GV_LIB_AB=tools/_diag/libgv_diag.so):
 per-phase shader-clock cycles of the binning kernels (GV_BIN_DBG=1)."""
 import ctypes as C, os, sys
 os.environ["GV_BIN_DBG"] = "1"
 os.environ["GV_PIPELINE"] = "0"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-os.environ.setdefault("GV_LIB_AB", os.path.join(ROOT, "gpurun_out", "libgv_diag.so"))
+os.environ.setdefault("GV_LIB_AB", os.path.join(ROOT, "tools", "_diag", "libgv_diag.so"))
 sys.path.insert(0, os.path.join(ROOT, "grid-vision_amd"))
 import numpy as np
 import gvamd

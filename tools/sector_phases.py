@@ -3,7 +3,7 @@ import ctypes as C, os, sys
 os.environ["GV_SECTOR_DBG"] = "1"
 os.environ["GV_PIPELINE"] = "0"   # one launch at a time writes the stamp buffer
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-os.environ.setdefault("GV_LIB_AB", os.path.join(ROOT, "gpurun_out", "libgv_diag.so"))   # -DGV_DIAG build: tools/build_diag.sh
+os.environ.setdefault("GV_LIB_AB", os.path.join(ROOT, "tools", "_diag", "libgv_diag.so"))   # -DGV_DIAG build: tools/build_diag.sh
 sys.path.insert(0, os.path.join(ROOT, "grid-vision_amd"))
 import numpy as np
 import gvamd
