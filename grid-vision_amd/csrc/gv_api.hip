@@ -801,7 +801,8 @@ int wait_inputs(gv_context *h, CloudSet &C, DetSet &D, int k)
 // The tile-path frame: rectangles + partition, tile histogram + end bitmaps, sector ray stage back to
 // back on one in-order stream, then the grid pass on the public stream.  pipelined: the stream of lane
 // n % 2 and buffer set 1 + n % 4 (n = lane frames so far), the grid pass behind one event.  Serial
-// (GV_PIPELINE=0, stage timing, the sharded frame): everything on the public stream, buffer set 0.
+// (GV_PIPELINE=0, stage timing): everything on the public stream, buffer set 0.  The sharded frame has its own
+// enqueue (enqueue_frame_sharded).
 int enqueue_frame_tiles(gv_context *h, bool pipelined, bool stage_events)
 {
   DetSet &D = h->det[h->det_cur];
