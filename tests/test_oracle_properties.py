@@ -272,3 +272,23 @@ def test_bench_refuses_to_shrink_a_multi_gpu_job():
     assert p.returncode != 0
     assert b'"n_gpus"' not in p.stdout
     assert b"refusing" in p.stderr
+
+
+def test_shard_band_and_slice_helpers_partition_the_grid():
+    """gv_shard_band_rows / gv_shard_slice_words (pure host functions of the C ABI, the ones the sharded frame and
+    the multi-rank CPU test use): bands are whole 64-row blocks, contiguous, cover [0, ny) exactly once for every
+    world size; slices are multiples of 4 words and `world` of them cover the bitmap."""
+    import gvamd
+    for ny in (1, 63, 64, 65, 200, 800, 1000, 2000, 4000, 8000):
+        for world in (1, 2, 3, 5, 8, 16):
+            bands = [gvamd.shard_band_rows(r, world, ny) for r in range(world)]
+            assert bands[0][0] == 0 and bands[-1][1] == ny
+            for r in range(world):
+                y0, y1 = bands[r]
+                assert 0 <= y0 <= y1 <= ny and (y0 % 64 == 0 or y0 == ny) and (y1 % 64 == 0 or y1 == ny)
+                if r + 1 < world:
+                    assert bands[r + 1][0] == y1
+    for words in (0, 1, 5, 1000, 2_097_152 + 3):
+        for world in (1, 2, 3, 8):
+            sl = gvamd.shard_slice_words(words, world)
+            assert sl % 4 == 0 and sl * world >= words and (sl - 4) * world < max(words, 1) + 4 * world
