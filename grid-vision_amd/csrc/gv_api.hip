@@ -2157,6 +2157,15 @@ int gv_debug_pipeline_trace(gv_handle h, int32_t frames, float *out)
 
 void *gv_stream(gv_handle h) { return h ? (void *)h->stream : nullptr; }
 
+int gv_device_layers(gv_handle h, int8_t **occ_i8, float **log_odds, float **occupancy)
+{
+  if (!h) return GV_ERR_BAD_ARG;
+  if (occ_i8) *occ_i8 = h->occ_i8;
+  if (log_odds) *log_odds = h->log_odds;
+  if (occupancy) *occupancy = h->occupancy;
+  return GV_OK;
+}
+
 int gv_time_frames(gv_handle h, int32_t frames, float *ms_total)
 {
   if (!h || frames <= 0 || !ms_total) return GV_ERR_BAD_ARG;

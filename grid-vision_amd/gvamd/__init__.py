@@ -44,7 +44,7 @@ ABI_SYMBOLS = [
     "gv_cloud_upload_xyz_async", "gv_cloud_upload_pointcloud2_async", "gv_cloud_upload_wait", "gv_host_alloc",
     "gv_host_free", "gv_frame_set_detections_async", "gv_frame_fence", "gv_debug_frame_sharded_emulated",
     "gv_to_occupancy_grid_async", "gv_frame_enqueue_sharded", "gv_time_frame_sharded_stages", "gv_shard_band_rows",
-    "gv_shard_slice_words",
+    "gv_shard_slice_words", "gv_device_layers",
 ]
 
 
@@ -401,6 +401,12 @@ class GridVisionHIP:
 
     def stream(self):
         return self._lib.gv_stream(self._h)
+
+    def device_layers(self):
+        """device addresses (ints) of occ_i8, log_odds, occupancy"""
+        a, b, c = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        self._ck(self._lib.gv_device_layers(self._h, C.byref(a), C.byref(b), C.byref(c)), "device_layers")
+        return a.value, b.value, c.value
 
     def enqueue_frame(self):
         self._ck(self._lib.gv_frame_enqueue(self._h), "frame_enqueue")

@@ -300,6 +300,10 @@ int gv_get_ray_stats(gv_handle h, uint64_t *n_rays, uint64_t *n_visits);
  * events around gv_frame_enqueue or consume the grid layers on the device: every frame's grid pass
  * runs on it, behind the frame's other kernels. */
 void *gv_stream(gv_handle h);
+/* Device pointers of the resident grid for consumers on the device (stream-ordered behind a frame on gv_stream):
+ * the packed OccupancyGrid.data bytes (G int8, `OccupancyGrid.data` order) and the two float layers (G floats,
+ * grid_map order).  Any of the three may be null.  Read-only for the caller. */
+int gv_device_layers(gv_handle h, int8_t **occ_i8, float **log_odds, float **occupancy);
 /* Time `frames` back-to-back gv_frame_enqueue calls with HIP events on the
  * handle's stream; *ms_total is the elapsed device time. */
 int gv_time_frames(gv_handle h, int32_t frames, float *ms_total);
