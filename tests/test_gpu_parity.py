@@ -1361,6 +1361,24 @@ def test_stream_contract_public_stream(gvamd):
         p.close()
 
 
+def test_device_layers_are_the_resident_grid(gvamd):
+    """gv_device_layers: the device pointers a device-side consumer reads behind a frame on gv_stream hold what the
+    host getters return"""
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    h, tfs = make_handle(gvamd, 1, perturbed=True)
+    x, y, z, _ = synth.cloud_uniform(1)
+    h.upload_xyz(x, y, z)
+    h.process_frame(gvamd.FRAME_BIN | gvamd.FRAME_RAYMARCH, poses=synth.lshape_poses(1, 6))
+    occ, lo, pr = h.device_layers()
+    assert occ and lo and pr
+    for ptr, want in ((occ, h.to_occupancy_grid()[0]), (lo, h.log_odds()), (pr, h.occupancy())):
+        got = np.empty_like(want)
+        assert hip.hipMemcpy(C.c_void_p(got.ctypes.data), C.c_void_p(ptr), C.c_size_t(got.nbytes), 2) == 0
+        assert np.array_equal(got, want)
+    h.close()
+
+
 def test_standalone_calls_keep_frame_detections(gvamd):
     """The reference-surface calls (extractCloudPerBBox, updateMap(poses), ...) must not change what the
     next gv_frame_enqueue uses: set_detections(50 boxes) -> extract_cloud_per_bbox(3 other boxes) ->
