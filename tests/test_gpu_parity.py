@@ -729,6 +729,36 @@ def test_gpu_matches_frozen_fixture(gvamd):
     h.close()
 
 
+def test_gpu_matches_pca_fixture(gvamd):
+    """tests/golden/pca_small.npz: kNN depths / distances and the ground mask bit for bit, the plane coefficients
+    equal, the PCA poses of computeBBoxPose (with and without ground removal) within the tolerances of _check_pose"""
+    import sys
+    sys.path.insert(0, os.path.join(HERE, "golden"))
+    import make_pca_fixture as mk
+    gold = np.load(os.path.join(HERE, "golden", "pca_small.npz"))
+    tfs, x, y, z, _, b = mk.scene()
+    h = gvamd.GridVisionHIP(50, 20, 0.1)
+    h.set_transforms(tfs["cam_lidar"], tfs["base_cam"], tfs["base_lidar"])
+    h.upload_xyz(x, y, z)
+    for k in (4, 10):
+        depths, d2 = h.compute_depth_for_bboxes(b, k)
+        assert np.array_equal(depths, gold[f"knn_depth_{k}"])
+        assert np.array_equal(d2, gold[f"knn_d2_{k}"])
+    m, mask, coeff = h.segment_ground_plane()
+    assert m == int(gold["ground_n"][0])
+    assert np.array_equal(np.packbits(mask), gold["ground_mask_bits"])
+    assert np.array_equal(coeff, gold["ground_coeff"])
+    for call, vkey, pkey in ((lambda: h.compute_bbox_pose(b), "pose_valid", "poses"),
+                             (lambda: h.compute_bbox_pose_ground_removed(b)[:2], "pose_valid_ground_removed", "poses_ground_removed")):
+        poses, valid = call()
+        assert np.array_equal(valid, gold[vkey])
+        for i in range(len(b)):
+            if valid[i]:
+                _check_pose(poses[i], dict(zip(mk.POSE_FIELDS, gold[pkey][i])), (pkey, i))
+    assert np.array_equal(h.bbox_id()[mask == 0].astype(np.int8), gold["bbox_id"][mask == 0])
+    h.close()
+
+
 def test_cpp_demo(gvamd, tmp_path):
     """grid-vision_amd/examples/frame_demo.cpp: the reference's timerCallback flow in plain
     g++ host code over the C ABI (no hipcc, no torch).  Its checksums must equal the same

@@ -292,3 +292,19 @@ def test_shard_band_and_slice_helpers_partition_the_grid():
         for world in (1, 2, 3, 8):
             sl = gvamd.shard_slice_words(words, world)
             assert sl % 4 == 0 and sl * world >= words and (sl - 4) * world < max(words, 1) + 4 * world
+
+
+def test_oracle_reproduces_pca_fixture():
+    """tests/golden/pca_small.npz (made by tests/golden/make_pca_fixture.py from the oracle): kNN depths, the RANSAC
+    ground plane and the PCA poses of a small seeded scene.  Freezes the oracle's arithmetic on the reference's other
+    per-frame loops against accidental change."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_pca_fixture", os.path.join(HERE, "golden", "make_pca_fixture.py"))
+    mk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mk)
+    gold = np.load(os.path.join(HERE, "golden", "pca_small.npz"))
+    now = mk.compute()
+    assert sorted(gold.files) == sorted(now.keys())
+    for k in gold.files:
+        assert np.array_equal(gold[k], now[k]), k
+    assert int(gold["ground_n"][0]) > 8000 and gold["pose_valid"].sum() >= 6
