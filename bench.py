@@ -765,6 +765,9 @@ def main():
         out["roofline_hbm"] = {k: dom_hbm.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic")}
         out["roofline_hbm"]["kernel_ms"] = dom_hbm["ms"]
         out["roofline_hbm"]["algorithmic_bytes"] = dom_hbm["algorithmic_bytes"]
+        # two lanes x ~50 MB per frame sit in the 256 MiB Infinity Cache at config 3 (FETCH_SIZE counts its hits): the
+        # fraction is then an L3-resident one; config 5 (beyond_l3 leg, ~0.5 GB per frame) is the HBM figure
+        out["roofline_hbm"]["l3_resident"] = bool(bytes_frame * 4 < 256 * 2 ** 20)
         if not a.plain:
             try:
                 copy_gbps = measured_copy_rate(torch)
