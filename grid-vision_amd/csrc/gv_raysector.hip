@@ -300,13 +300,17 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
     const int lo = bucket_of_boundary(Plo, Q), hi = bucket_of_boundary(Phi, Q);   // lo < hi unless both outside
     unsigned mx = 0;
     const int l = lo + 1, r = min(hi - 1, M - 1);
+    // the boundary buckets' bounds and own maxima are requested together with the range-max reads
+    const int loc = min(max(lo, 0), M - 1), hic = min(max(hi, 0), M - 1);
+    const unsigned e0l = bstart[loc], e1l = bstart[loc + 1], e0h = bstart[hic], e1h = bstart[hic + 1];
+    const unsigned lvlo = lvl[loc], lvh = lvl[hic];
     if (l <= r) mx = rmq(l, r);
     // a boundary bucket is only walked when its own max reach (level 0 of the range-max table) says that
     // one of its ends could decide the cell: beyond the threshold column most buckets hold short rays only
-    if (mx <= (unsigned)i && lo >= 0 && lo < M && (unsigned)lvl[lo] > (unsigned)i)
-      mx = max(mx, walk_bucket(bstart[lo], bstart[lo + 1], Q, Plo, (hi != lo) ? 0x7FFFFFFF : Phi));
-    if (mx <= (unsigned)i && hi >= 0 && hi < M && hi != lo && (unsigned)lvl[hi] > (unsigned)i)
-      mx = max(mx, walk_bucket(bstart[hi], bstart[hi + 1], Q, -0x7FFFFFFF, Phi));
+    if (mx <= (unsigned)i && lo >= 0 && lo < M && lvlo > (unsigned)i)
+      mx = max(mx, walk_bucket(e0l, e1l, Q, Plo, (hi != lo) ? 0x7FFFFFFF : Phi));
+    if (mx <= (unsigned)i && hi >= 0 && hi < M && hi != lo && lvh > (unsigned)i)
+      mx = max(mx, walk_bucket(e0h, e1h, Q, -0x7FFFFFFF, Phi));
     return mx > (unsigned)i;
   };
   // minor-offset range [blo, bhi] of the wedge in column a (empty when blo > bhi)
@@ -757,11 +761,12 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
         const unsigned sf = sfx[l], bsf = s_blksfx[l >> 6];
         const unsigned e0h = bstart[hic], e1h = bstart[hic + 1];
         const unsigned e0l = bstart[loc], e1l = bstart[loc + 1];
+        const unsigned lvh = lvl[hic], lvlo = lvl[loc];   // read with the rest: one LDS round trip less on the walk path
         unsigned mxh = (hi >= 1) ? max(pf, bpf) : 0u;
         unsigned mxl = (lo + 1 <= M - 1) ? max(sf, bsf) : 0u;
-        if (mxh <= (unsigned)i && hi >= 0 && hi < M && (unsigned)lvl[hic] > (unsigned)i)
+        if (mxh <= (unsigned)i && hi >= 0 && hi < M && lvh > (unsigned)i)
           mxh = max(mxh, walk_bucket(e0h, e1h, Q, -0x7FFFFFFF, Phi));
-        if (mxl <= (unsigned)i && lo >= 0 && lo < M && (unsigned)lvl[loc] > (unsigned)i)
+        if (mxl <= (unsigned)i && lo >= 0 && lo < M && lvlo > (unsigned)i)
           mxl = max(mxl, walk_bucket(e0l, e1l, Q, Plo, 0x7FFFFFFF));
         if (mxh > (unsigned)i) mask |= 1u;
         if (mxl > (unsigned)i) mask |= 1u << (w - 1);
@@ -779,7 +784,7 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
         todo &= todo - 1;
         if (cell_exact(i, Q, jlo + k)) mask |= 1u << k;
       }
-      if (mask) marks[i] |= mask;
+      if (mask) atomicOr(&marks[i], mask);   // no-return LDS OR: the lane does not wait for a read of the old word
     }
     if (flat_tail) {
       // Too many long rays to march them: every cell of the columns T+1 .. (largest reach - 1) is
