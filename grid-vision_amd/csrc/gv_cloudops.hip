@@ -762,9 +762,9 @@ __global__ void __launch_bounds__(64) k_seg_scatter(const int16_t *__restrict__ 
                                                     const uint32_t *__restrict__ block_off, const int32_t *__restrict__ seg_start,
                                                     float *__restrict__ gx, float *__restrict__ gy, float *__restrict__ gz)
 {
-  extern __shared__ unsigned s_cur[];   // slots this block has already filled, per bbox
+  extern __shared__ unsigned s_cur[];   // next slot of every bbox for this block (absolute position in the output)
   const int lane = threadIdx.x;
-  for (int b = lane; b < nb; b += 64) s_cur[b] = 0;
+  for (int b = lane; b < nb; b += 64) s_cur[b] = (unsigned)seg_start[b] + block_off[(size_t)blockIdx.x * nb + b];
   __syncthreads();
   const size_t base = (size_t)blockIdx.x * kSegBlock;
   int idb[kSegBlock / 64];   // this lane's ids of all 16 batches, requested together
@@ -778,26 +778,29 @@ __global__ void __launch_bounds__(64) k_seg_scatter(const int16_t *__restrict__ 
     }
     idb[q] = id;
   }
+  // One wavefront walks the block's 16 batches in order; per batch one round per distinct bbox id.  The cursor
+  // of a bbox is advanced by the round's leader lane with a returning LDS add (LDS operations of one wavefront
+  // complete in order) and handed to the other lanes through a lane read: no barrier, so the stores of one
+  // round are still in flight while the next one runs (round 3: each round used to end in two barriers, i.e. in
+  // a wait for its global stores).
 #pragma unroll
   for (int q = 0; q < kSegBlock / 64; ++q) {
     const size_t i = base + (size_t)q * 64 + lane;
     const int id = idb[q];
+    float cx = 0.f, cy = 0.f, cz = 0.f;
+    if (id >= 0) xform34(m, x[i], y[i], z[i], cx, cy, cz);
     unsigned long long todo = __ballot(id >= 0);
-    while (todo) {   // one round per distinct bbox id of this batch
+    while (todo) {
       const int leader = __ffsll((long long)todo) - 1;
       const int idl = __builtin_amdgcn_readlane(id, leader);
       const unsigned long long same = __ballot(id == idl);
-      const unsigned cur = s_cur[idl];
+      unsigned cur = 0;
+      if (lane == leader) cur = atomicAdd(&s_cur[idl], (unsigned)__popcll(same));
+      cur = (unsigned)__builtin_amdgcn_readlane((int)cur, leader);
       if (id == idl) {
-        const unsigned rank = (unsigned)__popcll(same & ((1ull << lane) - 1ull));
-        const unsigned pos = (unsigned)seg_start[idl] + block_off[(size_t)blockIdx.x * nb + idl] + cur + rank;
-        float cx, cy, cz;
-        xform34(m, x[i], y[i], z[i], cx, cy, cz);
+        const unsigned pos = cur + (unsigned)__popcll(same & ((1ull << lane) - 1ull));
         gx[pos] = cx; gy[pos] = cy; gz[pos] = cz;
       }
-      __syncthreads();   // (one wavefront: orders the cursor read above against the update below)
-      if (lane == leader) s_cur[idl] = cur + (unsigned)__popcll(same);
-      __syncthreads();
       todo &= ~same;
     }
   }
