@@ -727,9 +727,11 @@ def main():
         if shard_extra:
             out["sharded"] = shard_extra
         pmc, pmc_err = (None, "skipped")
-        if not a.plain and not a.no_pmc and world == 1:
+        if not a.plain and not a.no_pmc and not rehearsal:
+            # (at N > 1 too: the other ranks idle at the closing barrier while rank 0's children profile the same
+            #  workload on its own GPU, so that the roofline object is filled at every N)
             h.synchronize()
-            pmc, pmc_err = pmc_child_passes(config, "") if not sharded else (None, "skipped for the sharded frame")
+            pmc, pmc_err = pmc_child_passes(3 if config == 4 else config, "") if not sharded else (None, "skipped for the sharded frame")
         kernels = []
         for st, ms in stages.items():
             if st == "detections":
