@@ -132,6 +132,7 @@ struct gv_context {
   size_t stat_slots = 1;                    // ray statistics slots written by the last frame
   int32_t env_log2s_oct[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // GV_LOG2S_OCT="a,b,..." per octant index (sweeps)
   uint32_t env_march_limit = 64u * 512u;     // GV_MARCH_LIMIT
+  uint32_t env_flat_direct = 2048;           // GV_FLAT_DIRECT
   int32_t env_flat_k = 8;                   // GV_FLAT_K: exact-cell : marched-cell cost ratio (0 = always march)
   int32_t env_log2s = 0, env_cap = 0, env_log2m = 0;     // GV_LOG2S / GV_CAP / GV_LOG2M (sweeps)
 
@@ -592,6 +593,7 @@ int fill_sector_args(gv_context *h, SectorArgs &sa, int p)
 #endif
   sa.flat_k = h->env_flat_k;
   sa.march_limit = h->env_march_limit;
+  sa.flat_direct = h->env_flat_direct;
   sa.log2m = h->env_log2m > 0 ? h->env_log2m : 9;
   sa.marks_words = (imax + 3) & ~1;   // one word per wedge column, 0..imax
   std::stable_sort(ord, ord + 8, [&](int a, int b) { return len[a] > len[b]; });
@@ -1316,6 +1318,7 @@ int gv_create(gv_handle *out, uint8_t grid_x, uint8_t grid_y, double resolution,
     if (const char *e = std::getenv("GV_SECTOR_HELPERS")) h->env_helpers = std::atoi(e) != 0;
     if (const char *e = std::getenv("GV_CAP")) h->env_cap = std::atoi(e);
     if (const char *e = std::getenv("GV_FLAT_K")) h->env_flat_k = std::max(0, std::atoi(e));
+    if (const char *e = std::getenv("GV_FLAT_DIRECT")) h->env_flat_direct = (uint32_t)std::max(0, std::atoi(e));
     if (const char *e = std::getenv("GV_MARCH_LIMIT")) h->env_march_limit = (uint32_t)std::max(0, std::atoi(e));
     if (const char *e = std::getenv("GV_LOG2M")) h->env_log2m = std::min(9, std::max(4, std::atoi(e)));
 #ifdef GV_DIAG

@@ -152,6 +152,7 @@ struct SectorArgs {
   int32_t n_helpers;      // 0 or 16: second workgroups for the first / last sector of every octant, first in the dispatch order
   uint32_t march_limit;   // most ray cells beyond the threshold column a sector will march (else: exact per cell)
   int32_t flat_k;         // cost ratio exact-cell evaluation : marched cell for the choice beyond T (0: always march when possible)
+  uint32_t flat_direct;   // a tail of at most this many cells is evaluated exactly without looking at the long rays at all
   int32_t ablate;         // timing experiments only: 2 skip gather, 4 skip flush, 8/16/32 early exits
   unsigned long long *dbg; // diagnostic phase stamps, 16 per workgroup (null in production)
 };

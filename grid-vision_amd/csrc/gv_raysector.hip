@@ -72,6 +72,12 @@ __device__ __forceinline__ unsigned wave_shift_down(unsigned v, unsigned fill)
   return v;
 }
 
+// Products of small non-negative / small signed integers (wedge offsets, sector numbers, slopes: all far below
+// 2^23): v_mul_u32_u24 / v_mul_i32_i24 issue at the full vector rate, v_mul_lo_u32 at half of it (measured,
+// tools/microbench/valu_rate.hip: 590 against 1010 G wavefront-instructions/s).
+__device__ __forceinline__ int m24(int a, int b) { return __mul24(a, b); }
+__device__ __forceinline__ unsigned um24(unsigned a, unsigned b) { return __umul24(a, b); }
+
 // ------------------------------------------------------- sector gather -----
 struct Oct {
   int xmaj, smaj, smin;   // major axis is x?; signs of the major / minor step
@@ -244,7 +250,7 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
   // exact floor(N / Q) for 0 <= N < 2^24, 0 < Q: float estimate + one integer correction
   auto idiv = [](int N, int Q) -> int {
     int q = (int)((float)N * __builtin_amdgcn_rcpf((float)Q));
-    const int r = N - q * Q;
+    const int r = N - m24(q, Q);
     if (r < 0) --q;
     else if (r >= Q) ++q;
     return q;
@@ -254,12 +260,12 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
   auto wave_min = [](unsigned v) -> unsigned { return wave_reduce<OpMin>(v); };
   // slope bucket of an end: floor((b*S - a*s) * M / a); slope 1 (last sector) -> M-1
   auto bucket_of_end = [&](int a, int b) -> int {
-    const int rel = b * S - a * s;
+    const int rel = m24(b, S) - m24(a, s);
     return (rel >= a) ? (M - 1) : idiv(rel << LM, a);
   };
   // bucket holding the boundary slope P/Q: -1 below the sector, M at/above its end
   auto bucket_of_boundary = [&](int P, int Q) -> int {
-    const int relb = P * S - s * Q;
+    const int relb = m24(P, S) - m24(s, Q);
     return (relb <= 0) ? -1 : (relb >= Q) ? M : idiv(relb << LM, Q);
   };
   // max reach over whole buckets [l, r] (l <= r)
@@ -267,18 +273,17 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
     const int bl = l >> 6, br = r >> 6;
     if (bl == br) {
       const int lev = 31 - __clz(r - l + 1);
-      return max((unsigned)lvl[lev * M + l], (unsigned)lvl[lev * M + r - (1 << lev) + 1]);
+      return max((unsigned)lvl[(lev << LM) + l], (unsigned)lvl[(lev << LM) + r - (1 << lev) + 1]);
     }
     unsigned mx = max((unsigned)sfx[l], (unsigned)pfx[r]);
     for (int bk = bl + 1; bk < br; ++bk) mx = max(mx, s_blkmax[bk]);
     return mx;
   };
 
-  // largest reach among the ends [e0, e1) of one bucket whose slope b/a lies in [Plo/Q, Phi/Q) (a bound of
-  // +-0x7FFFFFFF = no bound on that side: a * 0x7FFFFFFF would overflow, so the unbounded sides are flags).
+  // largest reach among the ends [e0, e1) of one bucket whose slope b/a lies in [Plo/Q, Phi/Q); lo_open / hi_open:
+  // no bound on that side.
   // Four ends per step: the LDS reads of a step are issued together instead of one dependent read per end.
-  auto walk_bucket = [&](unsigned e0, unsigned e1, int Q, int Plo, int Phi) -> unsigned {
-    const bool lo_open = Plo == -0x7FFFFFFF, hi_open = Phi == 0x7FFFFFFF;
+  auto walk_bucket = [&](unsigned e0, unsigned e1, int Q, bool lo_open, int Plo, bool hi_open, int Phi) -> unsigned {
     unsigned mx = 0;
     for (unsigned e = e0; e < e1; e += 4) {
       unsigned p[4];
@@ -286,8 +291,8 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
       for (int q = 0; q < 4; ++q) p[q] = abv[min(e + (unsigned)q, e1 - 1u)];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const int a = ab_a(p[q]), bq = ab_b(p[q]) * Q;
-        const bool in = (e + (unsigned)q < e1) && (lo_open || bq >= Plo * a) && (hi_open || bq < Phi * a);
+        const int a = ab_a(p[q]), bq = m24(ab_b(p[q]), Q);
+        const bool in = (e + (unsigned)q < e1) && (lo_open || bq >= m24(Plo, a)) && (hi_open || bq < m24(Phi, a));
         mx = in ? max(mx, (unsigned)(a + (int)(p[q] & 1u))) : mx;
       }
     }
@@ -308,16 +313,16 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
     // a boundary bucket is only walked when its own max reach (level 0 of the range-max table) says that
     // one of its ends could decide the cell: beyond the threshold column most buckets hold short rays only
     if (mx <= (unsigned)i && lo >= 0 && lo < M && lvlo > (unsigned)i)
-      mx = max(mx, walk_bucket(e0l, e1l, Q, Plo, (hi != lo) ? 0x7FFFFFFF : Phi));
+      mx = max(mx, walk_bucket(e0l, e1l, Q, false, Plo, hi != lo, Phi));
     if (mx <= (unsigned)i && hi >= 0 && hi < M && hi != lo && lvh > (unsigned)i)
-      mx = max(mx, walk_bucket(e0h, e1h, Q, -0x7FFFFFFF, Phi));
+      mx = max(mx, walk_bucket(e0h, e1h, Q, true, 0, false, Phi));
     return mx > (unsigned)i;
   };
   // minor-offset range [blo, bhi] of the wedge in column a (empty when blo > bhi)
   auto col_bounds = [&](int a, int &blo, int &bhi) {
     const int bmaxa = oc.xmaj ? a : a - 1;
-    blo = (a * s + S - 1) >> log2s;
-    bhi = ((a * (s + 1) + S - 1) >> log2s) - 1;
+    blo = (m24(a, s) + S - 1) >> log2s;
+    bhi = ((m24(a, s + 1) + S - 1) >> log2s) - 1;
     if (s == S - 1) bhi = bmaxa;
     blo = max(blo, oc.bmin);
     bhi = min(min(bhi, bmaxa), oc.jmaxo);
@@ -338,10 +343,10 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
       col_bounds(ac, blo, bhi);
       const bool ok = in && blo <= bhi;
       const int w = ok ? bhi - blo + 1 : 0;   // <= 32 (host guarantees imax <= 30*S)
-      const int major_abs = oc_major + oc.smaj * ac;
+      const int major_abs = oc_major + m24(oc.smaj, ac);
       const int m_lo = ok ? ((oc.smin > 0) ? oc_minor + blo : oc_minor - bhi) : 0;
       const int w0 = m_lo >> 5;
-      const unsigned base = (unsigned)w0 * major_pad + (unsigned)major_abs;   // < 2^21 words
+      const unsigned base = um24((unsigned)w0, major_pad) + (unsigned)major_abs;   // < 2^21 words
       const unsigned base1 = (w0 + 1 < roww) ? base + major_pad : base;
       h0[c] = bmH[base]; c0[c] = bmC[base];
       h1[c] = bmH[base1]; c1[c] = bmC[base1];
@@ -367,10 +372,10 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
     col_bounds(a, blo, bhi);
     if (a <= oc.imax && blo <= bhi) {
       const int w = bhi - blo + 1;
-      const int major_abs = oc_major + oc.smaj * a;
+      const int major_abs = oc_major + m24(oc.smaj, a);
       const int m_lo = (oc.smin > 0) ? oc_minor + blo : oc_minor - bhi;
       const int w0 = m_lo >> 5;
-      const unsigned base = (unsigned)w0 * major_pad + (unsigned)major_abs;
+      const unsigned base = um24((unsigned)w0, major_pad) + (unsigned)major_abs;
       const unsigned base1 = (w0 + 1 < roww) ? base + major_pad : base;
       const unsigned long long h64 = ((unsigned long long)bmH[base1] << 32) | bmH[base];
       const unsigned long long c64 = ((unsigned long long)bmC[base1] << 32) | bmC[base];
@@ -551,7 +556,7 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
           if (lane + h >= 64) up = 0u;
         }
         v = max(v, up);
-        if (m < M) lvl[l * M + m] = (unsigned short)v;
+        if (m < M) lvl[(l << LM) + m] = (unsigned short)v;
         if (l <= LM && LM - l <= lv_max) {
           const unsigned mn = wave_min(((lane & ((1 << l) - 1)) == 0 && m < M && !gap_group(m, 1 << l)) ? v : 0xFFFFFFFFu);
           if (lane == 0) s_lvlmin[(LM - l) * 8 + wave] = mn;
@@ -655,7 +660,19 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
 #endif
     // long rays (reach > T+1) -> compact list in the (now free) cursor array `cnt`
     bool march_tail = false;
-    if (T < oc.imax && !GV_ABL(256)) {
+    // A short tail (few columns beyond T, all of them narrow) is cheaper to evaluate cell by cell than to find
+    // the long rays for: the compaction below is a pass over all ends plus a barrier.
+    bool direct_flat = false;
+    {
+      const int first = T + 1, last = min(oc.imax, (int)maxreach - 1);
+      if (last >= first) {
+        const int wl = ((2 * last * (s + 1) + S) >> (log2s + 1)) - ((2 * last * s + S) >> (log2s + 1)) + 1;
+        direct_flat = (unsigned)(last - first + 1) * (unsigned)wl <= A.flat_direct * (unsigned)nparts;
+      } else {
+        direct_flat = true;   // no ray reaches beyond T: nothing to do there either way
+      }
+    }
+    if (T < oc.imax && !direct_flat && !GV_ABL(256)) {
       unsigned st = 0;
       for (unsigned k0 = 0; k0 < n; k0 += NT) {
         const unsigned k = k0 + tid;
@@ -709,12 +726,12 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
           for (int i = T + 1 + lane; i < rch; i += 64) {
             if (nparts > 1 && (i & 1) != part) continue;   // the other workgroup of this sector marks that column
             // LineIterator stepping in closed form: j = (a/2 + i*b) / a
-            const int num = half + i * b;
+            const int num = half + m24(i, b);
             int q = (int)((float)num * __builtin_amdgcn_rcpf((float)a));
-            const int rem = num - q * a;
+            const int rem = num - m24(q, a);
             if (rem < 0) --q;
             else if (rem >= a) ++q;
-            const int bit = q - ((2 * i * s + S) >> (log2s + 1));
+            const int bit = q - ((m24(2 * i, s) + S) >> (log2s + 1));
             atomicOr(&marks[i], 1u << bit);
           }
         }
@@ -733,8 +750,8 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
         continue;
       }
       if ((unsigned)i >= maxreach) continue;   // no ray of this group gets this far
-      const int jlo = (2 * i * s + S) >> (log2s + 1);
-      const int jhi = (2 * i * (s + 1) + S) >> (log2s + 1);
+      const int jlo = (m24(2 * i, s) + S) >> (log2s + 1);
+      const int jhi = (m24(2 * i, s + 1) + S) >> (log2s + 1);
       const int w = jhi - jlo + 1;
       const int Q = 2 * i;
       // a cell interval (width 1/i in slope) fully contains an aligned group of level Lv
@@ -764,10 +781,10 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
         const unsigned lvh = lvl[hic], lvlo = lvl[loc];   // read with the rest: one LDS round trip less on the walk path
         unsigned mxh = (hi >= 1) ? max(pf, bpf) : 0u;
         unsigned mxl = (lo + 1 <= M - 1) ? max(sf, bsf) : 0u;
-        if (mxh <= (unsigned)i && hi >= 0 && hi < M && lvh > (unsigned)i)
-          mxh = max(mxh, walk_bucket(e0h, e1h, Q, -0x7FFFFFFF, Phi));
-        if (mxl <= (unsigned)i && lo >= 0 && lo < M && lvlo > (unsigned)i)
-          mxl = max(mxl, walk_bucket(e0l, e1l, Q, Plo, 0x7FFFFFFF));
+        if (!GV_ABL(1024) && mxh <= (unsigned)i && hi >= 0 && hi < M && lvh > (unsigned)i)
+          mxh = max(mxh, walk_bucket(e0h, e1h, Q, true, 0, false, Phi));
+        if (!GV_ABL(1024) && mxl <= (unsigned)i && lo >= 0 && lo < M && lvlo > (unsigned)i)
+          mxl = max(mxl, walk_bucket(e0l, e1l, Q, false, Plo, true, 0));
         if (mxh > (unsigned)i) mask |= 1u;
         if (mxl > (unsigned)i) mask |= 1u << (w - 1);
         // sectors with a lattice-gap run: the cell next to the edge cell is not covered by the level test
@@ -779,6 +796,7 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
         // beyond T: every cell exactly
         todo = (w >= 32) ? 0xFFFFFFFFu : ((1u << w) - 1u);
       }
+      if GV_ABL(2048) todo = 0;
       while (todo) {
         const int k = __ffs(todo) - 1;
         todo &= todo - 1;
@@ -801,9 +819,9 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
         const int ncol = (last - first) / nparts + 1;
         const int ntask = ncol << lw;
         for (int t = tid; t < ntask; t += NT) {
-          const int i = first + nparts * (t >> lw), k = t & ((1 << lw) - 1);
-          const int jlo = (2 * i * s + S) >> (log2s + 1);
-          const int jhi = (2 * i * (s + 1) + S) >> (log2s + 1);
+          const int i = first + m24(nparts, t >> lw), k = t & ((1 << lw) - 1);
+          const int jlo = (m24(2 * i, s) + S) >> (log2s + 1);
+          const int jhi = (m24(2 * i, s + 1) + S) >> (log2s + 1);
           if (k > jhi - jlo) continue;
           if (cell_exact(i, 2 * i, jlo + k)) atomicOr(&marks[i], 1u << k);
         }
@@ -849,18 +867,18 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
     const unsigned pad = (unsigned)(oc.xmaj ? A.nx_pad : A.ny_pad);
     for (int i = tid; i <= (GV_ABL(4) ? -1 : oc.imax); i += NT) {
       unsigned w = marks[i];
-      const int jlo = (2 * i * s + S) >> (log2s + 1);
+      const int jlo = (m24(2 * i, s) + S) >> (log2s + 1);
       const int tmax = oc.jmaxo - jlo;                        // bits beyond it are outside the map
       if (tmax < 31) w &= (tmax < 0) ? 0u : ((2u << tmax) - 1u);
       if (!w) continue;
-      const int mb = oc_minor + oc.smin * jlo;                // minor coordinate of bit 0 of w
+      const int mb = oc_minor + m24(oc.smin, jlo);                // minor coordinate of bit 0 of w
       const int b0 = (oc.smin > 0) ? mb : mb - 31;            // minor coordinate of bit 0 of v
       const unsigned v = (oc.smin > 0) ? w : __brev(w);
       const int wi = b0 >> 5, sh = b0 & 31;                   // arithmetic shift: floor for b0 < 0
       const unsigned lo = v << sh, hi = sh ? (v >> (32 - sh)) : 0u;
-      const unsigned col = (unsigned)(oc_major + oc.smaj * i);
-      if (lo) atomicOr(&bm[(unsigned)wi * pad + col], lo);    // set bits are in-map cells: wi >= 0 whenever lo != 0
-      if (hi) atomicOr(&bm[(unsigned)(wi + 1) * pad + col], hi);
+      const unsigned col = (unsigned)(oc_major + m24(oc.smaj, i));
+      if (lo) atomicOr(&bm[um24((unsigned)wi, pad) + col], lo);    // set bits are in-map cells: wi >= 0 whenever lo != 0
+      if (hi) atomicOr(&bm[um24((unsigned)(wi + 1), pad) + col], hi);
     }
   }
   __syncthreads();

@@ -1,5 +1,5 @@
-"""Sweep of the sector kernel's tail policy (GV_MARCH_LIMIT, GV_FLAT_K, GV_FLAT_DIRECT; read at gv_create): the kernel alone
-(stage timing) and the pipelined frame rate, config 3.  python3 tools/sector_sweep.py [lidar]"""
+"""Sweep of the sectors per octant (GV_LOG2S_OCT, read at gv_create) with the helper workgroups in place:
+the sector kernel alone (stage timing) and the pipelined frame, config 3.  python3 tools/sector_oct_sweep.py"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "grid-vision_amd"))
@@ -13,10 +13,11 @@ x, y, z, _ = (synth.cloud_lidar_like if "lidar" in sys.argv else synth.cloud_uni
 bb, pp = synth.detections(config), synth.lshape_poses(config)
 flags = gvamd.FRAME_BIN | gvamd.FRAME_RAYMARCH | gvamd.FRAME_BBOX_TEST
 ref = None
-for ml, fk, fd in ((32768, 8, 0), (32768, 8, 1024), (32768, 8, 2048), (32768, 8, 3072)):
-    os.environ["GV_MARCH_LIMIT"] = str(ml)
-    os.environ["GV_FLAT_K"] = str(fk)
-    os.environ["GV_FLAT_DIRECT"] = str(fd)
+for spec in ("", "6,6,6,6,6,6,5,5", "6,6,6,6,7,7,6,6", "6,6,6,6,6,6,6,6", "7,7,7,7,7,7,5,5", "6,6,6,6,7,7,4,4", "6,6,6,6,6,6,4,4"):
+    if spec:
+        os.environ["GV_LOG2S_OCT"] = spec
+    else:
+        os.environ.pop("GV_LOG2S_OCT", None)
     h = gvamd.GridVisionHIP(g.grid_x, g.grid_y, g.resolution)
     h.set_transforms(tfs["cam_lidar"], tfs["base_cam"], tfs["base_lidar"])
     h.upload_xyz(x, y, z)
@@ -35,5 +36,5 @@ for ml, fk, fd in ((32768, 8, 0), (32768, 8, 1024), (32768, 8, 2048), (32768, 8,
     m = h.miss()
     if ref is None:
         ref = m
-    print(f"march_limit {ml:7d} flat_k {fk:2d} flat_direct {fd:10d}: sectors alone {st['ray_march']*1e3:6.1f} us, pipelined frame {best:6.1f} us, miss equal {np.array_equal(m, ref)}")
+    print(f"log2s_oct {spec or 'default':18s}: sectors alone {st['ray_march']*1e3:6.1f} us, pipelined frame {best:6.1f} us, miss equal {np.array_equal(m, ref)}", flush=True)
     h.close()
