@@ -23,6 +23,8 @@
 // an out-of-map point's ray on the map border, counts as traversed), bit 15 unused.
 #include "gv_kernels.hpp"
 
+#include <cstdlib>
+
 #include <hip/hip_ext.h>
 #include "gv_device.hpp"
 
@@ -33,6 +35,12 @@ namespace gv {
 constexpr unsigned kKeyClip = 1u << 14;
 constexpr unsigned kStagedNone = 0xFFFFFFFFu;      // dropped point (non-finite, or outside with no ray)
 constexpr unsigned kStagedOutside = 0xFFFFFFFEu;   // out-of-map point waiting for the clip
+#ifndef GV_PART_BATCH
+#define GV_PART_BATCH 4                       // points per lane and step of the partition pass
+#endif
+#ifndef GV_PART_WPE
+#define GV_PART_WPE 7                         // wavefronts per SIMD the partition pass is compiled for
+#endif
 constexpr int kPartThreads = 512;             // 8 wavefronts per chunk (fits beside a sector workgroup)
 constexpr int kTileThreads = 1024;
 constexpr uint32_t kInLaneKeys = 128;         // tile pass: a segment up to this long is histogrammed by its own lane
@@ -61,7 +69,7 @@ __device__ __forceinline__ unsigned wave_incl_scan_add(unsigned v)
 // ------------------------------------------------------------- partition -----
 #define GV_KARG(field) load_karg<decltype(BinArgs::field)>(offsetof(BinArgs, field))
 template <bool RAY, bool BBOX, bool KEEPCELL>
-__global__ void __launch_bounds__(kPartThreads, 8) k_bin_partition(BinArgs a)
+__global__ void __launch_bounds__(kPartThreads, GV_PART_WPE) k_bin_partition(BinArgs a)
 {
   extern __shared__ __align__(16) unsigned char smem[];
   if (blockIdx.x >= a.n_wg) {
@@ -98,70 +106,157 @@ __global__ void __launch_bounds__(kPartThreads, 8) k_bin_partition(BinArgs a)
   }
   __syncthreads();
 
-  // two points per lane and step, both loads issued before either is used (chunk % (2 * kPartThreads) == 0)
-  for (uint32_t k0 = tid; k0 < a.chunk; k0 += 2 * kPartThreads) {
-    float px[2], py[2], pz[2];
+  // PP points per lane and step, handled phase by phase over all PP of them in straight-line code: the loads,
+  // then the base transform and the cell of every point, then (bbox test) the camera transform and the
+  // projection of every point, then one candidate loop over all of them.  Nothing per point sits behind a branch
+  // except the side effects (LDS count, stores), so the PP dependency chains interleave, and the constants of a
+  // phase are fetched once per step instead of once per point (chunk % (PP * kPartThreads) == 0).  The rare exact
+  // divisions are taken by the whole wavefront when any of its PP * 64 quotients needs one.
+  constexpr int PP = GV_PART_BATCH;
+  for (uint32_t k0 = tid; k0 < a.chunk; k0 += PP * kPartThreads) {
+    float px[PP], py[PP], pz[PP];
+    bool live[PP];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < PP; ++u) {
       const uint32_t k = k0 + (uint32_t)u * kPartThreads;
-      px[u] = py[u] = pz[u] = 0.0f;
-      if (k < npts) { px[u] = a.x[base + k]; py[u] = a.y[base + k]; pz[u] = a.z[base + k]; }
+      live[u] = k < npts;
+      const uint32_t i = base + (live[u] ? k : 0u);   // base < n: a valid address for the idle lanes of the last chunk
+      px[u] = a.x[i]; py[u] = a.y[i]; pz[u] = a.z[i];
     }
+    // ---- base frame: cell, tile, key
+    {
+      const Mat34f mb = GV_KARG(m_base);   // constants are fetched where they are used (gv_device.hpp, load_karg)
+      const GridParams g = GV_KARG(g);
+      double dx[PP], dy[PP], qx[PP], qy[PP];
+      bool fin[PP], in0[PP], rx[PP], ry[PP];
+      bool any_risky = false;
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const uint32_t k = k0 + (uint32_t)u * kPartThreads;
-      unsigned st = kStagedNone;
-      if (k < npts) {
-        const uint32_t i = base + k;
+      for (int u = 0; u < PP; ++u) {
         float bx, by, bz;
-        {
-          const Mat34f mb = GV_KARG(m_base);   // constants are fetched where they are used (gv_device.hpp, load_karg)
-          xform34(mb, px[u], py[u], pz[u], bx, by, bz);
-        }
-        int cell = -1;
-        if (isfinite(bx) && isfinite(by) && isfinite(bz)) {
-          int ix, iy;
-          const GridParams g = GV_KARG(g);
-          if (get_index_fast(g, (double)bx, (double)by, ix, iy)) {
-            cell = iy * g.nx + ix;
-            const unsigned tile = (unsigned)((iy >> kBinTileLog) * a.tiles_x + (ix >> kBinTileLog));
-            st = (tile << 16) | (unsigned)(((iy & (kBinTile - 1)) << kBinTileLog) | (ix & (kBinTile - 1)));
-            atomicAdd(&hist[tile], 1u);
-          } else if (RAY && a.org.valid) {
-            st = kStagedOutside;
-          }
-        }
-        if (KEEPCELL) a.cell_idx[i] = cell;
-        if (BBOX) {
-          float cx, cy, cz;
-          {
-            const Mat34f mc = GV_KARG(m_cam);
-            xform34(mc, px[u], py[u], pz[u], cx, cy, cz);
-          }
-          const CamK ck = GV_KARG(cam);
-          __builtin_nontemporal_store((int16_t)first_bbox(ck, lbt, cx, cy, cz), &a.bbox_id[i]);   // host-read output
+        xform34(mb, px[u], py[u], pz[u], bx, by, bz);
+        fin[u] = live[u] & isfinite(bx) & isfinite(by) & isfinite(bz);   // (bitwise: no short-circuit branches)
+        // get_index_fast (gv_device.hpp), flattened
+        const double x = (double)bx, y = (double)by;
+        const double tx = -((x - g.pos_x) - g.off_x);
+        const double ty = -((y - g.pos_y) - g.off_y);
+        in0[u] = fin[u] & (tx >= 0.0) & (ty >= 0.0) & (tx < g.len_x) & (ty < g.len_y);
+        dx[u] = (x - g.off_x) - g.pos_x;
+        dy[u] = (y - g.off_y) - g.pos_y;
+        qx[u] = -dx[u] * g.inv_res;
+        qy[u] = -dy[u] * g.inv_res;
+        rx[u] = in0[u] & (fabs(qx[u] - rint(qx[u])) < 1e-6);
+        ry[u] = in0[u] & (fabs(qy[u] - rint(qy[u])) < 1e-6);
+        any_risky = any_risky | rx[u] | ry[u];
+      }
+      if (__ballot(any_risky) != 0ull) {
+#pragma unroll
+        for (int u = 0; u < PP; ++u) {
+          if (rx[u]) qx[u] = -(dx[u] / g.res);
+          if (ry[u]) qy[u] = -(dy[u] / g.res);
         }
       }
-      staged[k] = st;
+#pragma unroll
+      for (int u = 0; u < PP; ++u) {
+        const uint32_t k = k0 + (uint32_t)u * kPartThreads;
+        const int jx = (int)(in0[u] ? qx[u] : 0.0);
+        const int jy = (int)(in0[u] ? qy[u] : 0.0);
+        const bool inside = in0[u] & (jx >= 0) & (jy >= 0) & (jx < g.nx) & (jy < g.ny);
+        const unsigned tile = (unsigned)((jy >> kBinTileLog) * a.tiles_x + (jx >> kBinTileLog));
+        const unsigned key = (tile << 16) | (unsigned)(((jy & (kBinTile - 1)) << kBinTileLog) | (jx & (kBinTile - 1)));
+        const unsigned st = inside ? key : ((RAY & fin[u] & (a.org.valid != 0)) ? kStagedOutside : kStagedNone);
+        if (inside) atomicAdd(&hist[tile], 1u);
+        staged[k] = st;
+        if (RAY) {
+          // out-of-map points (a minority) need the fp64 slab clip, ~10x the work of an in-map point: their
+          // positions in the chunk are collected here so that the clip below runs on dense lanes
+          const bool o = st == kStagedOutside;
+          const unsigned long long bm = __ballot(o);
+          if (bm) {
+            unsigned wbase = 0;
+            if (lane == 0) wbase = atomicAdd(&s_nout, (unsigned)__popcll(bm));
+            wbase = (unsigned)__builtin_amdgcn_readfirstlane((int)wbase);
+            if (o) outl[wbase + (unsigned)__popcll(bm & ((1ull << lane) - 1ull))] = (unsigned short)k;
+          }
+        }
+        if (KEEPCELL && live[u]) a.cell_idx[base + k] = inside ? jy * g.nx + jx : -1;
+      }
+    }
+    // ---- camera frame: index of the first bbox containing the projection (first_bbox, gv_device.hpp, flattened)
+    if (BBOX) {
+      const Mat34f mc = GV_KARG(m_cam);
+      const CamK ck = GV_KARG(cam);
+      float uu[PP], vv[PP];
+      double n0[PP], n1[PP], zz[PP];
+      bool ok[PP], k0r[PP], k1r[PP];
+      bool any_risky = false;
+#pragma unroll
+      for (int u = 0; u < PP; ++u) {
+        float cx, cy, cz;
+        xform34(mc, px[u], py[u], pz[u], cx, cy, cz);
+        ok[u] = live[u] & isfinite(cx) & isfinite(cy) & isfinite(cz) & !(cz <= 0.001f);   // :264
+        const double X = (double)cx, Y = (double)cy, Z = (double)cz;
+        zz[u] = ok[u] ? Z : 1.0;
+        const double riz = rcp_newton(zz[u]);
+        n0[u] = ck.k[0] * X + ck.k[2] * Z;   // K's zero and unit entries dropped: see first_bbox
+        n1[u] = ck.k[4] * Y + ck.k[5] * Z;
+        const double q0 = n0[u] * riz, q1 = n1[u] * riz;
+        k0r[u] = ok[u] & div_risky(q0);
+        k1r[u] = ok[u] & div_risky(q1);
+        any_risky = any_risky | k0r[u] | k1r[u];
+        uu[u] = (float)q0;
+        vv[u] = (float)q1;
+      }
+      if (__ballot(any_risky) != 0ull) {
+#pragma unroll
+        for (int u = 0; u < PP; ++u) {
+          if (k0r[u]) uu[u] = (float)(n0[u] / zz[u]);
+          if (k1r[u]) vv[u] = (float)(n1[u] / zz[u]);
+        }
+      }
+      int id[PP];
+      unsigned moff[PP];
+      bool img[PP];
+#pragma unroll
+      for (int u = 0; u < PP; ++u) {
+        img[u] = ok[u] & !((uu[u] < 0) | (uu[u] >= (float)ck.W) | (vv[u] < 0) | (vv[u] >= (float)ck.H));   // :276
+        const int tx = (int)(img[u] ? uu[u] : 0.0f) >> 4, ty = (int)(img[u] ? vv[u] : 0.0f) >> 4;
+        moff[u] = (unsigned)((ty * lbt.tiles_x + tx) * lbt.mask_words);
+        id[u] = -1;
+      }
+      for (int wd = 0; wd < lbt.mask_words; ++wd) {   // :280-288 first match wins; one word = 64 boxes
+        unsigned long long m[PP];
+        bool more = false;
+#pragma unroll
+        for (int u = 0; u < PP; ++u) {
+          const unsigned long long mw = lbt.tile_mask[moff[u] + (unsigned)wd];
+          m[u] = (img[u] & (id[u] < 0)) ? mw : 0ull;
+          more = more | (m[u] != 0ull);
+        }
+        while (__ballot(more) != 0ull) {
+          more = false;
+#pragma unroll
+          for (int u = 0; u < PP; ++u) {
+            const bool have = m[u] != 0ull;
+            const int b = have ? wd * 64 + (__ffsll((long long)m[u]) - 1) : 0;
+            const float4 f = lbt.bbox_f[b];
+            const bool hit = have & (uu[u] >= f.x) & (uu[u] <= f.z) & (vv[u] >= f.y) & (vv[u] <= f.w);
+            id[u] = hit ? b : id[u];
+            m[u] = hit ? 0ull : (m[u] & (m[u] - 1ull));
+            more = more | (m[u] != 0ull);
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < PP; ++u) {
+        const uint32_t k = k0 + (uint32_t)u * kPartThreads;
+        if (live[u]) __builtin_nontemporal_store((int16_t)id[u], &a.bbox_id[base + k]);   // host-read output
+      }
     }
   }
   __syncthreads();
   GV_STAMP(a.dbg, 1);   // points done
 
   if (RAY) {
-    // Out-of-map points (a minority) need the fp64 slab clip, ~10x the work of an in-map point:
-    // their positions in the chunk are compacted so that the clip runs on dense lanes.
-    for (uint32_t k = tid; k < a.chunk; k += kPartThreads) {   // chunk % kPartThreads == 0: uniform trip count
-      const bool o = staged[k] == kStagedOutside;
-      const unsigned long long bm = __ballot(o);
-      if (bm) {
-        unsigned wbase = 0;
-        if (lane == 0) wbase = atomicAdd(&s_nout, (unsigned)__popcll(bm));
-        wbase = (unsigned)__builtin_amdgcn_readfirstlane((int)wbase);
-        if (o) outl[wbase + (unsigned)__popcll(bm & ((1ull << lane) - 1ull))] = (unsigned short)k;
-      }
-    }
-    __syncthreads();
     const unsigned nout = s_nout;
     for (unsigned j = tid; j < nout; j += kPartThreads) {
       const unsigned k = outl[j];
@@ -529,6 +624,10 @@ uint32_t bin_chunk_for(size_t n)
   // that a tile's gather (one segment descriptor per chunk) stays short
   uint32_t chunk = 2048;
   while ((n + chunk - 1) / chunk > 1536 && chunk < 8192) chunk *= 2;
+#ifdef GV_DIAG
+  static const int forced = [] { const char *e = std::getenv("GV_BIN_CHUNK"); return e ? std::atoi(e) : 0; }();
+  if (forced >= GV_PART_BATCH * kPartThreads && forced % (GV_PART_BATCH * kPartThreads) == 0) chunk = (uint32_t)forced;
+#endif
   return chunk;
 }
 

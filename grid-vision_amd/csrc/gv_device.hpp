@@ -135,10 +135,10 @@ __device__ __forceinline__ void clip_ray_end(const GridParams &g, const RayOrigi
   const double lox = hix - g.len_x, loy = hiy - g.len_y;
   const double dx = px - o.ox, dy = py - o.oy;
   double t = 1.0;
-  if (dx > 0.0) { const double tx = (hix - o.ox) / dx; if (tx < t) t = tx; }
-  if (dx < 0.0) { const double tx = (lox - o.ox) / dx; if (tx < t) t = tx; }
-  if (dy > 0.0) { const double ty = (hiy - o.oy) / dy; if (ty < t) t = ty; }
-  if (dy < 0.0) { const double ty = (loy - o.oy) / dy; if (ty < t) t = ty; }
+  // one division per axis: the slab a ray can leave through is chosen by the sign of its direction first (the
+  // quotient is the same one the two-branch form computes; dx == 0 constrains nothing)
+  if (dx != 0.0) { const double tx = ((dx > 0.0 ? hix : lox) - o.ox) / dx; if (tx < t) t = tx; }
+  if (dy != 0.0) { const double ty = ((dy > 0.0 ? hiy : loy) - o.oy) / dy; if (ty < t) t = ty; }
   if (t < 0.0) t = 0.0;
   const double qx = o.ox + t * dx;
   const double qy = o.oy + t * dy;

@@ -13,7 +13,7 @@ SOURCES = ["gv_api.hip", "gv_kernels.hip", "gv_binning.hip", "gv_raysector.hip",
 # -ffp-contract=off: cell indices must be bit-exact with the reference's separate
 # multiply/add roundings; no fast-math anywhere.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math",
-         "-fPIC", "-shared", "-Wall", "-Wno-unused-function"]
+         "-fPIC", "-shared", "-Wall", "-Wno-unused-function", "-Wno-bitwise-instead-of-logical"]
 
 
 def hipcc() -> str:
