@@ -236,7 +236,11 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
   if (tid < NT / 64) s_wvis[tid] = 0;
   for (int m = tid; m < M; m += NT) { cnt[m] = 0; bmax32[m] = 0; }
   if (tid == 0) s_nlong = 0;
-  __syncthreads();
+  // (no barrier here: nothing reads what was just cleared before the barrier behind the column scan below, and
+  //  the scan's bitmap loads go out without waiting for the slowest wavefront's stores)
+#ifdef GV_DIAG
+  if (A.dbg || A.ablate) __syncthreads();
+#endif
   stamp();   // 1: init done
   if GV_ABL(8) return;    // timing experiment: launch + init only
 
