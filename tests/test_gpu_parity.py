@@ -1684,3 +1684,78 @@ def test_streaming_growth_reallocates_under_load(gvamd):
     for p3 in pins:
         for p in p3:
             p.close()
+
+
+@pytest.mark.parametrize("n", [1, 63, 511, 2047, 2048, 2049, 4097, 6145])
+def test_partition_ragged_cloud_sizes(gvamd, n):
+    """The partition pass takes four points per lane and step (chunks of 2048): cloud sizes around the chunk and
+    step boundaries, with non-finite points, points behind the camera and points outside the map mixed in, every
+    per-point output kept (KEEP_CELL_IDX: the <ray, bbox, cell ids> instance of the kernel) -- cell ids, bbox ids,
+    hit counts and the free cells bit-exact against the oracle."""
+    gx, gy, res = 120, 80, 0.25
+    h = gvamd.GridVisionHIP(gx, gy, res)
+    og = ol.OGrid(gx, gy, res)
+    tfs = synth.transforms(True)
+    h.set_transforms(tfs["cam_lidar"], tfs["base_cam"], tfs["base_lidar"])
+    st = synth.Stream(977, n)
+    x = st.uniform(n, -0.7 * gx, 0.7 * gx)
+    y = st.uniform(n, -0.7 * gy, 0.7 * gy)
+    z = st.uniform(n, -1.5, 1.5)
+    for k, v in ((5, np.nan), (17, np.inf), (40, -np.inf)):   # scattered over x, y, z
+        if n > k:
+            (x, y, z)[k % 3][k] = np.float32(v)
+    if n > 2050:
+        x[2040:2050] = np.float32(1e30)        # far outside, across the chunk boundary: the clip path
+        y[100:140] = np.float32(np.nan)        # a whole run of dropped points
+    bboxes = synth.detections(3, 40)
+    poses = synth.lshape_poses(1, 6)
+    flags = gvamd.FRAME_BIN | gvamd.FRAME_RAYMARCH | gvamd.FRAME_BBOX_TEST | gvamd.FRAME_KEEP_CELL_IDX | gvamd.FRAME_KEEP_COUNTS
+    h.upload_xyz(x, y, z)
+    h.process_frame(flags, bboxes=bboxes, poses=poses)
+    hits, cell, miss, ids, _ = oracle_frame(og, tfs, x, y, z, bboxes, poses)
+    assert np.array_equal(h.cell_idx(), cell)
+    assert np.array_equal(h.bbox_id(), ids)
+    assert np.array_equal(h.hits(), hits)
+    assert np.array_equal(h.miss(), miss)
+    assert check_grid(h, og)[0] == 0
+    h.close()
+
+
+def _walls_scene(og, n, seed):
+    """ends along two walls and a sprinkle elsewhere: the sectors next to the axes and the diagonals get the long
+    tails (hundreds of columns beyond the threshold column) that the tail policies differ on"""
+    st = synth.Stream(seed, n)
+    lx, ly = og.g.len_x, og.g.len_y
+    x = st.uniform(n, -0.49 * lx, 0.49 * lx)
+    y = st.uniform(n, -0.49 * ly, 0.49 * ly)
+    k = n // 3
+    x[:k] = np.float32(0.47 * lx)              # a wall across the +x octants
+    y[k:2 * k] = x[k:2 * k] * np.float32(ly / lx)   # a diagonal wall
+    return x, y, st.uniform(n, -0.5, 0.5)
+
+
+@pytest.mark.parametrize("grid,n", [((200, 200, 0.25), 30_000), ((250, 100, 0.1), 120_000)])
+def test_sector_tail_policies_agree(gvamd, monkeypatch, grid, n):
+    """Beyond the threshold column a sector either marches its long rays, evaluates every cell there exactly after
+    looking at the long rays, or (short tail) evaluates them without looking: GV_FLAT_DIRECT / GV_MARCH_LIMIT /
+    GV_FLAT_K move the choice, the free cells must not move -- all variants equal to the oracle's literal march."""
+    gx, gy, res = grid
+    og = ol.OGrid(gx, gy, res)
+    tfs = synth.transforms(False)
+    x, y, z = _walls_scene(og, n, 31337)
+    m_base = ol.tf_to_matrix4f(tfs["base_lidar"])
+    want, _ = og.raymarch(m_base, x, y, z)
+    assert 0 < int(want.sum()) < og.G
+    for fd, ml, fk in (("0", None, None), ("1000000000", None, None), (None, "0", None), (None, "100000000", "0"), ("300", "3000", "2")):
+        for name, v in (("GV_FLAT_DIRECT", fd), ("GV_MARCH_LIMIT", ml), ("GV_FLAT_K", fk)):
+            if v is None:
+                monkeypatch.delenv(name, raising=False)
+            else:
+                monkeypatch.setenv(name, v)
+        h = gvamd.GridVisionHIP(gx, gy, res)
+        h.set_transforms(tfs["cam_lidar"], tfs["base_cam"], tfs["base_lidar"])
+        h.upload_xyz(x, y, z)
+        h.process_frame(gvamd.FRAME_BIN | gvamd.FRAME_RAYMARCH | gvamd.FRAME_KEEP_COUNTS)
+        got = h.miss()
+        h.close()
+        assert np.array_equal(got, want), (fd, ml, fk, int(np.count_nonzero(got != want)))
