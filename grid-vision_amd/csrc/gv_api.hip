@@ -129,6 +129,13 @@ struct gv_context {
   bool force_simple = false;                // GV_RAY_IMPL=simple
   int env_reorder = 1;                      // GV_SECTOR_REORDER=0: workgroups in natural (octant, sector) order
   int env_helpers = -1;                     // GV_SECTOR_HELPERS: -1 automatic, 0 off, 1 on
+  // A lane's partition pass does not depend on the sector kernel queued in front of it (the previous frame of that
+  // lane: other buffers), only the in-order queue says so.  When nothing else was put on the lane since that
+  // sector kernel -- no wait, no upload, no table kernel -- the partition pass is launched without the barrier
+  // bit (hipExtAnyOrderLaunch) and starts while the sector kernel's last workgroups still run.  lane_clean[k]:
+  // the last packet on lane k is a sector kernel.  GV_ANYORDER=0 switches it off.
+  bool lane_clean[3] = {false, false, false};
+  bool env_anyorder = true;
   size_t stat_slots = 1;                    // ray statistics slots written by the last frame
   int32_t env_log2s_oct[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // GV_LOG2S_OCT="a,b,..." per octant index (sweeps)
   uint32_t env_march_limit = 64u * 512u;     // GV_MARCH_LIMIT
@@ -654,7 +661,8 @@ int check_frame_flags(const gv_context *h, uint32_t fl)
 // (or not), per-point outputs and binning scratch; the end bitmaps of buffer set p; zeroes the set's
 // free-cell bitmaps.  ev_* are stage-timing events or null.
 int enqueue_binning(gv_context *h, const DetSet &D, int p, int k, size_t lo, size_t n, bool keep_cell, bool do_ray,
-                    bool do_bbox, bool write_hits, hipEvent_t ev_points, Rect *fold_rects = nullptr, bool timed = false)
+                    bool do_bbox, bool write_hits, hipEvent_t ev_points, Rect *fold_rects = nullptr, bool timed = false,
+                    bool any_order = false)
 {
   hipStream_t s = h->streams[k];
   const uint32_t chunk = bin_chunk_for(n);
@@ -699,7 +707,8 @@ int enqueue_binning(gv_context *h, const DetSet &D, int p, int k, size_t lo, siz
 #ifdef GV_DIAG
   a.dbg = h->d_bin_dbg[0];
 #endif
-  launch_bin_partition(a, s, timed ? h->kt[0][0] : nullptr, timed ? h->kt[0][1] : nullptr);
+  launch_bin_partition(a, s, timed ? h->kt[0][0] : nullptr, timed ? h->kt[0][1] : nullptr, any_order);
+  h->lane_clean[k] = false;
   if (timed) h->kt_used[0] = n > 0 || fold_rects;
   if (do_bbox && !bbox_fused) {
     PointsArgs pa{};
@@ -792,10 +801,12 @@ int wait_inputs(gv_context *h, CloudSet &C, DetSet &D, int k)
   if (!(C.seen >> k & 1u)) {
     GV_HIP(hipStreamWaitEvent(s, C.ready, 0));
     C.seen |= 1u << k;
+    h->lane_clean[k] = false;
   }
   if (!(D.seen >> k & 1u)) {
     GV_HIP(hipStreamWaitEvent(s, D.ready, 0));
     D.seen |= 1u << k;
+    h->lane_clean[k] = false;
   }
   return GV_OK;
 }
@@ -841,17 +852,24 @@ int enqueue_frame_tiles(gv_context *h, bool pipelined, bool stage_events)
   Rect *rects = h->x_rects[p];
   const bool fold_rects = do_bin && !(fl & GV_FRAME_VISION_ORIENT) && D.n_poses > 0;
   mark(s);
+  if (!fold_rects) h->lane_clean[k] = false;   // (the rectangle / vision kernels go on the lane)
   const int32_t n_rects = fold_rects ? D.n_poses : enqueue_rects(h, D, rects, h->d_vout_s[k], s);
   mark(s);
   if (stage_events) GV_HIP(hipEventRecord(h->ev[kStageDetections + 1], s));
+  bool part_any_order = pipelined && !stage_events && h->env_anyorder && h->lane_clean[k];
+#ifdef GV_DIAG
+  if (h->trace) part_any_order = false;   // the trace markers are packets on the lane
+#endif
 
   // --- points: partition by tile (+ ray ends, bbox test), then the tile histogram: hits[] + end bitmaps
   mark(s);
   if (do_bin) {
     if ((rc = enqueue_binning(h, D, p, k, 0, h->n, keep_cell, do_ray, do_bbox, true,
-                              stage_events ? h->ev[kStagePoints + 1] : nullptr, fold_rects ? rects : nullptr, stage_events)))
+                              stage_events ? h->ev[kStagePoints + 1] : nullptr, fold_rects ? rects : nullptr, stage_events,
+                              part_any_order)))
       return rc;
   } else {
+    h->lane_clean[k] = false;
     if (do_bbox) {
       PointsArgs a{};
       a.x = h->cx; a.y = h->cy; a.z = h->cz;
@@ -884,6 +902,8 @@ int enqueue_frame_tiles(gv_context *h, bool pipelined, bool stage_events)
                                       stage_events ? h->kt[2][0] : nullptr)))
     return rc;
   if (stage_events) h->kt_used[2] = sec_event;
+  // the lane now ends in a sector kernel that carries its own completion event: nothing behind it
+  h->lane_clean[k] = pipelined && do_bin && do_ray && sec_event;
   mark(s);
   if (stage_events) GV_HIP(hipEventRecord(h->ev[kStageRayMarch + 1], s));
 
@@ -1112,6 +1132,7 @@ int enqueue_frame_sharded(gv_context *h, hipEvent_t *te)
   const int p = 1 + (int)(h->lane_frames % 4u);
   const int k = 1 + (int)(h->lane_frames % 2u);
   hipStream_t s = h->streams[k], X = h->stream_x;
+  h->lane_clean[1] = h->lane_clean[2] = false;   // events between the steps: every kernel of this form keeps its barrier bit
   if (h->set_fin_slot[p] >= 0) GV_HIP(hipEventSynchronize(h->ev_fin[h->set_fin_slot[p]]));   // back-pressure: four frames in flight
   CloudSet &CS = h->cloud[h->cloud_cur];
   if ((rc = wait_inputs(h, CS, D, k))) return rc;
@@ -1316,6 +1337,7 @@ int gv_create(gv_handle *out, uint8_t grid_x, uint8_t grid_y, double resolution,
     }
     if (const char *e = std::getenv("GV_SECTOR_REORDER")) h->env_reorder = std::atoi(e) != 0;
     if (const char *e = std::getenv("GV_SECTOR_HELPERS")) h->env_helpers = std::atoi(e) != 0;
+    if (const char *e = std::getenv("GV_ANYORDER")) h->env_anyorder = std::atoi(e) != 0;
     if (const char *e = std::getenv("GV_CAP")) h->env_cap = std::atoi(e);
     if (const char *e = std::getenv("GV_FLAT_K")) h->env_flat_k = std::max(0, std::atoi(e));
     if (const char *e = std::getenv("GV_FLAT_DIRECT")) h->env_flat_direct = (uint32_t)std::max(0, std::atoi(e));
@@ -1634,6 +1656,7 @@ int set_detections(gv_context *h, const gv_frame_desc *d)
   DetSet &D = h->det[target];
   const int k = (sector_path(h) && !h->no_pipeline) ? 1 + (int)(h->lane_frames % 2u) : 0;
   hipStream_t s = h->streams[k];
+  h->lane_clean[k] = false;   // the upload and the table kernels go on this stream, in front of the frame's partition pass
   if (D.release_slot >= 0 && D.readers != (1u << k)) GV_HIP(hipStreamWaitEvent(s, h->ev_fin[D.release_slot], 0));
   const bool net = vision && d->n_bboxes;
   if ((rc = upload_det(h, D, d->bboxes, d->n_bboxes, vision ? nullptr : d->poses, vision ? 0 : d->n_poses,

@@ -643,13 +643,14 @@ bool bin_bbox_fits(int nb, const BBoxTest &bt) { return bin_bbox_lds((nb + 3) & 
 
 // t0 / t1 (optional, timing-enabled events): start and end of the kernel itself, taken from its dispatch packet
 // (hipExtLaunchKernelGGL) -- the per-kernel times of gv_time_frame_stages, free of the event-record overhead
-void launch_bin_partition(const BinArgs &a, hipStream_t s, hipEvent_t t0, hipEvent_t t1)
+void launch_bin_partition(const BinArgs &a, hipStream_t s, hipEvent_t t0, hipEvent_t t1, bool any_order)
 {
+  const unsigned fl = any_order ? hipExtAnyOrderLaunch : 0u;
   const uint32_t grid = a.n_wg + (a.n_rect_poses > 0 ? 1u : 0u);
   if (grid == 0) return;
   const size_t lds = bin_partition_lds(a.chunk, a.n_tiles) + (a.do_bbox ? bin_bbox_lds(a.nb_pad, a.bt) : 0);
   const bool keep = a.cell_idx != nullptr;
-#define GV_BP(R, X, K) hipExtLaunchKernelGGL((k_bin_partition<R, X, K>), dim3(grid), dim3(kPartThreads), (uint32_t)lds, s, t0, t1, 0, a)
+#define GV_BP(R, X, K) hipExtLaunchKernelGGL((k_bin_partition<R, X, K>), dim3(grid), dim3(kPartThreads), (uint32_t)lds, s, t0, t1, fl, a)
   if (a.do_ray && a.do_bbox && keep) GV_BP(true, true, true);
   else if (a.do_ray && a.do_bbox) GV_BP(true, true, false);
   else if (a.do_ray && keep) GV_BP(true, false, true);

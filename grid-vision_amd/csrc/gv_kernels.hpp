@@ -111,7 +111,7 @@ struct BinArgs {
 constexpr size_t kBinBBoxLdsMax = 24 * 1024;   // LDS the partition kernel may spend on the bbox-test tables
 uint32_t bin_chunk_for(size_t n);
 bool bin_bbox_fits(int nb, const BBoxTest &bt);
-void launch_bin_partition(const BinArgs &a, hipStream_t s, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr);
+void launch_bin_partition(const BinArgs &a, hipStream_t s, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr, bool any_order = false);
 
 struct BinTileArgs {
   int32_t nx, ny, tiles_x, tiles_y, n_tiles;

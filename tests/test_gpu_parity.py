@@ -1759,3 +1759,44 @@ def test_sector_tail_policies_agree(gvamd, monkeypatch, grid, n):
         got = h.miss()
         h.close()
         assert np.array_equal(got, want), (fd, ml, fk, int(np.count_nonzero(got != want)))
+
+
+def test_partition_overtakes_sector_tail(gvamd, monkeypatch):
+    """With unchanged inputs the partition pass of frame f + 2 is launched without the barrier bit and starts while
+    the sector kernel of frame f (same lane, other buffers) still runs.  Config-3 size so that the kernels really
+    overlap: a run of frames on one cloud, new detections in the middle (their upload goes on a lane: those frames
+    keep the barrier), a new cloud, more frames -- hit counts, free cells, bbox ids and the grid layers against the
+    oracle after every batch, and the whole sequence once more with GV_ANYORDER=0 for equal layers."""
+    config = 3
+    g = synth.CONFIGS[config]["grid"]
+    flags = gvamd.FRAME_BIN | gvamd.FRAME_RAYMARCH | gvamd.FRAME_BBOX_TEST
+    clouds = [synth.cloud_uniform(config)[:3], synth.cloud_lidar_like(config)[:3]]
+    dets = [(synth.detections(config), synth.lshape_poses(config)), (synth.detections(config, seed_extra=1), synth.lshape_poses(config, seed_extra=1))]
+    plan = [(0, 0, 7), (0, 1, 5), (1, 1, 6), (1, 0, 1), (0, 0, 4)]   # (cloud, detection set, frames)
+    layers = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("GV_ANYORDER", mode)
+        h, tfs = make_handle(gvamd, config, True)
+        og = ol.OGrid(g.grid_x, g.grid_y, g.resolution) if mode == "1" else None
+        cur_cloud = None
+        for ci, di, nf in plan:
+            if ci != cur_cloud:
+                h.upload_xyz(*clouds[ci])
+                cur_cloud = ci
+            bb, pp = dets[di]
+            h.set_detections(flags, bboxes=bb, poses=pp)
+            for _ in range(nf):
+                h.enqueue_frame()
+            h.synchronize()
+            if og is not None:
+                x, y, z = clouds[ci]
+                for _ in range(nf):
+                    hits, _, miss, ids, _ = oracle_frame(og, tfs, x, y, z, bb, pp)
+                assert np.array_equal(h.hits(), hits)
+                assert np.array_equal(h.miss(), miss)
+                assert np.array_equal(h.bbox_id(), ids)
+                assert check_grid(h, og)[0] == 0
+        layers[mode] = (h.log_odds().copy(), h.hits().copy(), h.miss().copy())
+        h.close()
+    for a, b in zip(layers["1"], layers["0"]):
+        assert np.array_equal(a, b)
