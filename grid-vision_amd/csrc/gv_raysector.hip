@@ -651,6 +651,20 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
       if GV_ABL(64) T0 = 0;
     }
     if (lane == 0) { s_T = (unsigned)T0; s_maxreach = maxreach0; }
+    } else {
+      // Meanwhile the other seven wavefronts take the NARROW columns (at most two cells wide: all of them lie
+      // below column 2S): every cell of such a column is evaluated exactly whatever T turns out to be, and the
+      // exact evaluation needs only the tables that are complete by now.  One (column, cell) pair per lane; in
+      // the gather loop below these columns were what made wavefront 0 the last to finish.
+      const int n_narrow = min(oc.imax, 2 * S - 1);
+      for (int t = tid - 64; t < 2 * n_narrow; t += NT - 64) {
+        const int i = 1 + (t >> 1), k = t & 1;
+        if (nparts > 1 && (i & 1) != part) continue;
+        const int jlo = (m24(2 * i, s) + S) >> (log2s + 1);
+        const int jhi = (m24(2 * i, s + 1) + S) >> (log2s + 1);
+        if (jhi - jlo > 1 || k > jhi - jlo) continue;
+        if (cell_exact(i, 2 * i, jlo + k)) atomicOr(&marks[i], 1u << k);
+      }
     }
     __syncthreads();   // s_T, s_maxreach, s_blkpfx, s_blksfx visible
     const int T = (int)s_T;
@@ -762,7 +776,8 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
       // buckets when 2^Lv >= 2i/S; if every such group holds a ray longer than i, every
       // cell that lies inside the sector's slope range (k = 1..w-2) is traversed.
       // columns up to T have every interior cell free (monotone test, computed once above)
-      bool interior_free = (w > 2) && (i <= T);
+      if (w <= 2) continue;                          // narrow column: done beside the threshold computation above
+      bool interior_free = i <= T;
       if GV_ABL(64) interior_free = false;           // timing experiment: always the full loop
       if (GV_ABL(128) && !interior_free) continue;   // timing experiment: skip the full loop
       unsigned mask = 0, todo = 0;   // todo: cells of this column to evaluate exactly
