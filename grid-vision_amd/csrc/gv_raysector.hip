@@ -340,6 +340,11 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
     int shs[CH], ws[CH];
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
+      h0[c] = h1[c] = c0[c] = c1[c] = 0u;
+      shs[c] = ws[c] = 0;
+      // a row of column slots that lies wholly beyond this octant's wedge (the kernel is instantiated for the
+      // longest octant): nothing to load -- a wavefront-uniform skip
+      if (NT * c >= oc.imax) continue;
       const int a = 1 + tid + NT * c;
       const bool in = (a <= oc.imax) && ((rowmask >> c) & 1u);
       const int ac = in ? a : 1;
@@ -473,7 +478,7 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
     // in this lane-unbalanced loop) ...
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
-      if (!((rowmask >> c) & 1u) || !mine_w) continue;
+      if (!((rowmask >> c) & 1u) || !mine_w || NT * c >= oc.imax) continue;
       const int a = 1 + tid + NT * c;
       unsigned e = ends[c];
       int blo, bhi;
