@@ -56,13 +56,16 @@ constexpr uint32_t kInLaneKeys = 128;         // tile pass: a segment up to this
 #define GV_STAMP(dbg, k) do { } while (0)
 #endif
 
+// inclusive add-scan over the 64 lanes as DPP modifiers of six dependent VALU adds (row_shr 1, 2, 4, 8, then
+// row_bcast:15 / :31 into the upper rows) instead of six ds_bpermute round trips
 __device__ __forceinline__ unsigned wave_incl_scan_add(unsigned v)
 {
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    const unsigned u = __shfl_up(v, off);
-    if ((int)(threadIdx.x & 63) >= off) v += u;
-  }
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, false);
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, false);
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, false);
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, false);
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);
   return v;
 }
 
