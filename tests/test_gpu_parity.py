@@ -1800,3 +1800,75 @@ def test_partition_overtakes_sector_tail(gvamd, monkeypatch):
         h.close()
     for a, b in zip(layers["1"], layers["0"]):
         assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("seed", [11, 29])
+def test_random_call_sequences_with_frames_in_flight(gvamd, seed):
+    """A caller that does things in no particular order: runs of frames on unchanged inputs (their partition passes
+    start inside the previous sector kernel), new clouds through the asynchronous upload, new detections through
+    the asynchronous form, both at once, host waits at random points.  300 k points on a 1200 x 1200 grid: long
+    enough kernels for real overlap, short enough for ~60 oracle frames.  Whatever the interleaving, the grid
+    after every wait equals the oracle's and the last frame's per-point outputs are that frame's."""
+    gx, gy, res = 240, 240, 0.2
+    n = 300_000
+    rng = np.random.default_rng(seed)
+    h = gvamd.GridVisionHIP(gx, gy, res)
+    og = ol.OGrid(gx, gy, res)
+    tfs = synth.transforms(True)
+    h.set_transforms(tfs["cam_lidar"], tfs["base_cam"], tfs["base_lidar"])
+    clouds, pins = [], []
+    for c in range(3):
+        st = synth.Stream(seed * 100 + c, n)
+        spread = (0.6, 0.35, 0.8)[c]
+        x = st.uniform(n, -spread * gx, spread * gx)
+        y = st.uniform(n, -spread * gy, spread * gy)
+        z = st.uniform(n, -1.0, 1.0)
+        p3 = tuple(gvamd.PinnedF32(n) for _ in range(3))
+        for p, a in zip(p3, (x, y, z)):
+            p.array[:] = a
+        pins.append(p3)
+        clouds.append((x, y, z))
+    dets = [(synth.detections(3, 12 + 9 * d, seed_extra=d), synth.lshape_poses(1, 5 + 4 * d, seed_extra=d)) for d in range(3)]
+    flags = gvamd.FRAME_BIN | gvamd.FRAME_RAYMARCH | gvamd.FRAME_BBOX_TEST
+    ci, di = 0, 0
+    h.upload_xyz_async(*(p.array for p in pins[ci]))
+    h.set_detections_async(flags, bboxes=dets[di][0], poses=dets[di][1])
+    pending = []          # (cloud, detection set) of the frames enqueued since the last check
+    total = 0
+    while total < 60:
+        op = rng.integers(0, 10)
+        if op <= 4:       # a run of frames on whatever is current
+            for _ in range(int(rng.integers(1, 6))):
+                h.enqueue_frame()
+                pending.append((ci, di))
+                total += 1
+        elif op == 5:
+            ci = int(rng.integers(0, 3))
+            h.upload_xyz_async(*(p.array for p in pins[ci]))
+        elif op == 6:
+            di = int(rng.integers(0, 3))
+            h.set_detections_async(flags, bboxes=dets[di][0], poses=dets[di][1])
+        elif op == 7:     # both, then one frame right behind
+            ci, di = int(rng.integers(0, 3)), int(rng.integers(0, 3))
+            h.upload_xyz_async(*(p.array for p in pins[ci]))
+            h.set_detections_async(flags, bboxes=dets[di][0], poses=dets[di][1])
+            h.enqueue_frame()
+            pending.append((ci, di))
+            total += 1
+        elif pending:     # host wait + check
+            h.synchronize()
+            for c, d in pending:
+                hits, _, miss, ids, _ = oracle_frame(og, tfs, *clouds[c], dets[d][0], dets[d][1])
+            pending = []
+            assert np.array_equal(h.hits(), hits)
+            assert np.array_equal(h.miss(), miss)
+            assert np.array_equal(h.bbox_id(), ids)
+            assert check_grid(h, og)[0] == 0
+    h.synchronize()
+    for c, d in pending:
+        oracle_frame(og, tfs, *clouds[c], dets[d][0], dets[d][1])
+    assert check_grid(h, og)[0] == 0
+    h.close()
+    for p3 in pins:
+        for p in p3:
+            p.close()
