@@ -568,7 +568,7 @@ __global__ void __launch_bounds__(kTileThreads) k_bin_tiles(BinTileArgs a)
 
   // ---- write-out: the tile of hits[] (plain coalesced 16-byte stores) and the hit bits of every row.
   // A lane takes 4 consecutive cells; 8 lanes make one 32-bit word of the row's hit bits: the lane's
-  // nibble is shifted into place and OR-reduced over the 8 lanes with DPP-free shuffles.
+  // nibble is shifted into place and OR-reduced over the 8 lanes with three DPP row shifts.
   const int x0 = (t % a.tiles_x) << kBinTileLog, y0 = (t / a.tiles_x) << kBinTileLog;
 #pragma unroll
   for (int it = 0; it < kBinTileCells / 4 / kTileThreads; ++it) {
@@ -586,9 +586,11 @@ __global__ void __launch_bounds__(kTileThreads) k_bin_tiles(BinTileArgs a)
     }
     unsigned nib = (v.x ? 1u : 0u) | (v.y ? 2u : 0u) | (v.z ? 4u : 0u) | (v.w ? 8u : 0u);
     nib <<= 4 * (tid & 7);
-    nib |= (unsigned)__shfl_xor((int)nib, 1);
-    nib |= (unsigned)__shfl_xor((int)nib, 2);
-    nib |= (unsigned)__shfl_xor((int)nib, 4);
+    // OR over the 8 lanes of a word into its first lane: lane i takes lane i + 1, + 2, + 4 of its row (DPP row_shl,
+    // zero past the row end -- the 8-lane groups are row aligned)
+    nib |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)nib, 0x101, 0xF, 0xF, false);
+    nib |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)nib, 0x102, 0xF, 0xF, false);
+    nib |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)nib, 0x104, 0xF, 0xF, false);
     if ((tid & 7) == 0) bits[0][ly][lx >> 5] = nib;
   }
   __syncthreads();
