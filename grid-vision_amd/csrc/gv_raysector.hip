@@ -12,7 +12,8 @@
 // (reach = a for a hit end, a+1 for a clipped end whose own cell counts).
 // That is a range-max query over the ends ordered by slope.  Each workgroup owns
 // one angular sector of one octant: it collects its ends from end bitmaps,
-// counting-sorts them into M slope buckets in LDS (exact integer bucket index),
+// drops them into M slope buckets in LDS (exact integer bucket index; a row of
+// kSlots per bucket plus one overflow list, no sorting passes),
 // builds a sparse range-max table over the bucket maxima, and answers every cell
 // of its wedge from the table plus exact cross-multiplication tests on the (at
 // most two) buckets its slope interval only partly covers.  Everything is
@@ -119,31 +120,30 @@ constexpr int kSecThreads = 512;   // 8 wavefronts per sector workgroup
 #define GV_SECTOR_WPE 4             // min waves per SIMD the register allocator must allow
 #endif
 
+// Ends of a slope bucket: the first kSlots in the bucket's own row of a table, in arrival order; what a crowded bucket
+// holds beyond that (the buckets of the few rational slopes many ends share) goes to one overflow list.  No count /
+// prefix / placement passes: an end is placed the moment its bucket is known.
+constexpr int kSlotLog = 3, kSlots = 1 << kSlotLog;
+
 // LDS layout of one sector workgroup (bytes), shared by the kernel and the launcher
 struct SectorLds {
-  size_t abv, marks, cnt, bstart, bmax32, un, lvl, pfx, sfx, raw, bkt, total;
+  size_t tab, marks, cnt, bmax32, lvl, pfx, sfx, raw, over, total;
 };
 __host__ __device__ inline SectorLds sector_lds_layout(int cap, int marks_words, int log2m)
 {
   const size_t M = (size_t)1 << log2m;
   SectorLds L;
   size_t o = 0;
-  L.abv = o;    o += (size_t)cap * 4;
+  L.tab = o;    o += M * kSlots * 4;            // [M][kSlots] packed ends (16-byte aligned rows)
+  L.raw = o;    o += (size_t)cap * 4;           // packed ends in scan order (staging list; the long-ray pass reads it too)
+  L.over = o;   o += (size_t)cap * 4;           // overflow entries: bucket << 16 | index into raw
   L.marks = o;  o += (size_t)marks_words * 4;
-  L.cnt = o;    o += M * 4;      // bucket counts, then placement cursors, then (with bmax32 behind it) the long-ray list: 2M entries
-  L.bmax32 = o; o += M * 4;      // dead once the range-max tables are built
-  L.bstart = o; o += (M + 2) * 4;
-  // union: {staging list: raw ends + their bucket ids} is dead once the ends are placed,
-  // which is before {range-max tables} are written
-  L.un = o;
+  L.cnt = o;    o += M * 4;                     // ends per bucket (may exceed kSlots)
+  L.bmax32 = o; o += 2 * M * 4;                 // bucket max reach; dead once the range-max tables are built: then the long-ray list (2M entries)
   L.lvl = o;
-  L.pfx = L.lvl + 7 * M * 2;        // in-block (64 buckets) sparse levels 0..6
+  L.pfx = L.lvl + 7 * M * 2;                    // in-block (64 buckets) sparse levels 0..6
   L.sfx = L.pfx + M * 2;
-  const size_t tables = 9 * M * 2;
-  L.raw = o;
-  L.bkt = L.raw + (size_t)cap * 4;
-  const size_t staging = (size_t)cap * 6;
-  o += (tables > staging ? tables : staging);
+  o += 9 * M * 2;
   L.total = (o + 15) & ~(size_t)15;
   return L;
 }
@@ -204,17 +204,16 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
   const int LM = A.log2m, M = 1 << LM, NB = (M + 63) >> 6;
 
   const SectorLds L = sector_lds_layout(cap, A.marks_words, LM);
-  unsigned *abv = reinterpret_cast<unsigned *>(smem + L.abv);          // packed ends grouped by slope bucket
+  unsigned *tab = reinterpret_cast<unsigned *>(smem + L.tab);          // packed ends by slope bucket: kSlots per bucket
+  unsigned *over = reinterpret_cast<unsigned *>(smem + L.over);        // what does not fit: bucket << 16 | index into raw
   unsigned *marks = reinterpret_cast<unsigned *>(smem + L.marks);      // one word of cell bits per wedge column
-  unsigned *cnt = reinterpret_cast<unsigned *>(smem + L.cnt);          // bucket counts, then placement cursors
-  unsigned *bstart = reinterpret_cast<unsigned *>(smem + L.bstart);    // bucket starts (M+1)
-  unsigned *bmax32 = reinterpret_cast<unsigned *>(smem + L.bmax32);    // bucket max reach
+  unsigned *cnt = reinterpret_cast<unsigned *>(smem + L.cnt);          // ends per bucket
+  unsigned *bmax32 = reinterpret_cast<unsigned *>(smem + L.bmax32);    // bucket max reach; later the long-ray list
   unsigned short *lvl = reinterpret_cast<unsigned short *>(smem + L.lvl);   // lvl[l*M+m] = max of buckets m..m+2^l-1 inside m's 64-block
   unsigned short *pfx = reinterpret_cast<unsigned short *>(smem + L.pfx);   // max from the block start to m
   unsigned short *sfx = reinterpret_cast<unsigned short *>(smem + L.sfx);   // max from m to the block end
-  unsigned *raw = reinterpret_cast<unsigned *>(smem + L.raw);               // staging: packed ends, scan order
-  unsigned short *bkt = reinterpret_cast<unsigned short *>(smem + L.bkt);   // staging: their slope buckets
-  __shared__ unsigned s_wsum[NT / 64], s_wsum2[NT / 64], s_blkmax[8], s_blkpfx[9], s_blksfx[9], s_lvlmin[10 * 8], s_nlong, s_T, s_maxreach;
+  unsigned *raw = reinterpret_cast<unsigned *>(smem + L.raw);               // packed ends, scan order
+  __shared__ unsigned s_wsum[NT / 64], s_blkmax[8], s_blkpfx[9], s_blksfx[9], s_lvlmin[10 * 8], s_nlong, s_nover, s_T, s_maxreach;
   __shared__ unsigned long long s_wvis[NT / 64];
   __shared__ unsigned s_rowpart[CH][NT / 64];   // multi-group path: ends per (row, wavefront)
 
@@ -235,7 +234,7 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
   for (int i = tid; i <= oc.imax; i += NT) marks[i] = 0;
   if (tid < NT / 64) s_wvis[tid] = 0;
   for (int m = tid; m < M; m += NT) { cnt[m] = 0; bmax32[m] = 0; }
-  if (tid == 0) s_nlong = 0;
+  if (tid == 0) { s_nlong = 0; s_nover = 0; }
   // (no barrier here: nothing reads what was just cleared before the barrier behind the column scan below, and
   //  the scan's bitmap loads go out without waiting for the slowest wavefront's stores)
 #ifdef GV_DIAG
@@ -284,20 +283,25 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
     return mx;
   };
 
-  // largest reach among the ends [e0, e1) of one bucket whose slope b/a lies in [Plo/Q, Phi/Q); lo_open / hi_open:
-  // no bound on that side.
-  // Four ends per step: the LDS reads of a step are issued together instead of one dependent read per end.
-  auto walk_bucket = [&](unsigned e0, unsigned e1, int Q, bool lo_open, int Plo, bool hi_open, int Phi) -> unsigned {
+  // largest reach among the c ends of bucket m whose slope b/a lies in [Plo/Q, Phi/Q); lo_open / hi_open: no
+  // bound on that side.  The bucket's row of the table is read whole (two 16-byte reads issued together); the
+  // overflow list is only looked at for a bucket that holds more than its row.
+  auto walk_bucket = [&](int m, unsigned c, int Q, bool lo_open, int Plo, bool hi_open, int Phi) -> unsigned {
     unsigned mx = 0;
-    for (unsigned e = e0; e < e1; e += 4) {
-      unsigned p[4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) p[q] = abv[min(e + (unsigned)q, e1 - 1u)];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int a = ab_a(p[q]), bq = m24(ab_b(p[q]), Q);
-        const bool in = (e + (unsigned)q < e1) && (lo_open || bq >= m24(Plo, a)) && (hi_open || bq < m24(Phi, a));
-        mx = in ? max(mx, (unsigned)(a + (int)(p[q] & 1u))) : mx;
+    auto take = [&](unsigned p, bool valid) {
+      const int a = ab_a(p), bq = m24(ab_b(p), Q);
+      const bool in = valid && (lo_open || bq >= m24(Plo, a)) && (hi_open || bq < m24(Phi, a));
+      mx = in ? max(mx, (unsigned)(a + (int)(p & 1u))) : mx;
+    };
+    const uint4 r0 = *reinterpret_cast<const uint4 *>(tab + ((unsigned)m << kSlotLog));
+    const uint4 r1 = *reinterpret_cast<const uint4 *>(tab + ((unsigned)m << kSlotLog) + 4);
+    take(r0.x, c > 0u); take(r0.y, c > 1u); take(r0.z, c > 2u); take(r0.w, c > 3u);
+    if (c > 4u) { take(r1.x, true); take(r1.y, c > 5u); take(r1.z, c > 6u); take(r1.w, c > 7u); }
+    if (c > (unsigned)kSlots) {
+      const unsigned no = s_nover;
+      for (unsigned e = 0; e < no; ++e) {
+        const unsigned v = over[e];
+        if ((int)(v >> 16) == m) take(raw[v & 0xFFFFu], true);
       }
     }
     return mx;
@@ -311,15 +315,15 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
     const int l = lo + 1, r = min(hi - 1, M - 1);
     // the boundary buckets' bounds and own maxima are requested together with the range-max reads
     const int loc = min(max(lo, 0), M - 1), hic = min(max(hi, 0), M - 1);
-    const unsigned e0l = bstart[loc], e1l = bstart[loc + 1], e0h = bstart[hic], e1h = bstart[hic + 1];
+    const unsigned cl = cnt[loc], ch = cnt[hic];
     const unsigned lvlo = lvl[loc], lvh = lvl[hic];
     if (l <= r) mx = rmq(l, r);
     // a boundary bucket is only walked when its own max reach (level 0 of the range-max table) says that
     // one of its ends could decide the cell: beyond the threshold column most buckets hold short rays only
     if (mx <= (unsigned)i && lo >= 0 && lo < M && lvlo > (unsigned)i)
-      mx = max(mx, walk_bucket(e0l, e1l, Q, false, Plo, hi != lo, Phi));
+      mx = max(mx, walk_bucket(loc, cl, Q, false, Plo, hi != lo, Phi));
     if (mx <= (unsigned)i && hi >= 0 && hi < M && hi != lo && lvh > (unsigned)i)
-      mx = max(mx, walk_bucket(e0h, e1h, Q, true, 0, false, Phi));
+      mx = max(mx, walk_bucket(hic, ch, Q, true, 0, false, Phi));
     return mx > (unsigned)i;
   };
   // minor-offset range [blo, bhi] of the wedge in column a (empty when blo > bhi)
@@ -457,7 +461,7 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
     } else {
       __syncthreads();   // previous group fully done with the tables
       for (int m = tid; m < M; m += NT) { cnt[m] = 0; bmax32[m] = 0; }
-      if (tid == 0) s_nlong = 0;
+      if (tid == 0) { s_nlong = 0; s_nover = 0; }
       mycnt = 0;
 #pragma unroll
       for (int c = 0; c < CH; ++c)
@@ -491,52 +495,27 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
       }
     }
     __syncthreads();
-    // ... then their slope buckets (an integer division each) and the bucket counts over the dense list, one end
-    // per lane and step
-    for (unsigned k = tid; k < n; k += NT) {
-      const unsigned p = raw[k];
-      const int bk = bucket_of_end(ab_a(p), ab_b(p));
-      bkt[k] = (unsigned short)bk;
-      atomicAdd(&cnt[bk], 1u);
-    }
-    __syncthreads();
-    stamp();   // 3: staged + counted
-    // exclusive prefix over the M bucket counts (thread m owns bucket m; M <= NT)
-    {
-      const unsigned bc = (tid < M) ? cnt[tid] : 0u;
-      const unsigned in2 = wave_scan<OpAdd>(bc);
-      if (lane == 63) s_wsum2[wave] = in2;
-      __syncthreads();
-      unsigned base = 0;
-#pragma unroll
-      for (int wv = 0; wv < NT / 64; ++wv) {   // independent reads, selected afterwards
-        const unsigned t = s_wsum2[wv];
-        if (wv < wave) base += t;
-      }
-      if (tid < M) {
-        bstart[tid] = base + in2 - bc;
-        cnt[tid] = base + in2 - bc;   // placement cursor
-      }
-      if (tid == M - 1) bstart[M] = base + in2;
-    }
-    __syncthreads();
-    stamp();   // 4: prefix
-    // place the packed ends into their buckets; bucket max reach; visit statistics
+    // ... then, over the dense list with one end per lane and step: its slope bucket (an integer division), its place
+    // in the bucket's row (or the overflow list), the bucket's max reach, the visit statistics
     {
       unsigned vis = 0;   // <= 9 ends x reach < 2^13 per thread: the wavefront sum fits 32 bits
       for (unsigned k = tid; k < n; k += NT) {
         const unsigned p = raw[k];
-        const unsigned m = bkt[k];
+        const int bk = bucket_of_end(ab_a(p), ab_b(p));
         const unsigned rch = (unsigned)(ab_a(p) + (int)(p & 1u));
-        abv[atomicAdd(&cnt[m], 1u)] = p;
-        atomicMax(&bmax32[m], rch);
+        const unsigned slot_in = atomicAdd(&cnt[bk], 1u);
+        if (slot_in < (unsigned)kSlots) tab[((unsigned)bk << kSlotLog) + slot_in] = p;
+        else over[atomicAdd(&s_nover, 1u)] = ((unsigned)bk << 16) | k;
+        atomicMax(&bmax32[bk], rch);
         vis += rch;
       }
       vis = wave_sum(vis);
       if (lane == 0 && vis) s_wvis[wave] += vis;   // one owner per slot
     }
     __syncthreads();
-    stamp();   // 5: placed
+    stamp();   // 3: staged, placed
+    stamp();   // 4: (the former prefix pass)
+    stamp();   // 5: (the former placement pass)
     // range-max structure: wavefront `wave` owns the 64-bucket block `wave` (cross-lane ops only)
     if (wave < NB) {
       const int m = wave * 64 + lane;
@@ -681,7 +660,7 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
       A.dbg[(size_t)wg * 16 + 12] = ((unsigned long long)T << 48) | ((unsigned long long)mr << 32) | ((unsigned long long)oc.imax << 16) | (unsigned long long)min(n, 65535u);
     }
 #endif
-    // long rays (reach > T+1) -> compact list in the (now free) cursor array `cnt`
+    // long rays (reach > T+1) -> compact list in the (now free) bucket-maximum array
     bool march_tail = false;
     // A short tail (few columns beyond T, all of them narrow) is cheaper to evaluate cell by cell than to find
     // the long rays for: the compaction below is a pass over all ends plus a barrier.
@@ -702,7 +681,7 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
         unsigned p = 0;
         bool lng = false;
         if (k < n) {
-          p = abv[k];
+          p = raw[k];
           const int rch = ab_a(p) + (int)(p & 1u);
           lng = rch > T + 1;
           if (lng) st += (unsigned)(rch - (T + 1));
@@ -713,7 +692,7 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
           if (lane == 0) base = atomicAdd(&s_nlong, (unsigned)__popcll(bm));
           base = __shfl(base, 0);
           const unsigned pos = base + (unsigned)__popcll(bm & ((1ull << lane) - 1ull));
-          if (lng && pos < 2u * (unsigned)M) cnt[pos] = p;   // the list runs on into bmax32 (dead by now)
+          if (lng && pos < 2u * (unsigned)M) bmax32[pos] = p;   // (the bucket maxima are dead by now: 2M entries)
         }
       }
       const unsigned r = wave_sum(st);
@@ -742,7 +721,7 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
       if (march_tail) {
         // one ray per wavefront, lanes over consecutive columns: distinct LDS words
         for (unsigned r0 = wave; r0 < nlong; r0 += NT / 64) {
-          const unsigned p = cnt[r0];
+          const unsigned p = bmax32[r0];
           const int a = ab_a(p), b = ab_b(p);
           const int rch = a + (int)(p & 1u);
           const int half = a >> 1;
@@ -800,15 +779,14 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
         const int hic = min(max(hi, 0), M - 1), loc = min(max(lo, 0), M - 1);
         const unsigned pf = pfx[r], bpf = s_blkpfx[r >> 6];
         const unsigned sf = sfx[l], bsf = s_blksfx[l >> 6];
-        const unsigned e0h = bstart[hic], e1h = bstart[hic + 1];
-        const unsigned e0l = bstart[loc], e1l = bstart[loc + 1];
+        const unsigned ch = cnt[hic], cl = cnt[loc];
         const unsigned lvh = lvl[hic], lvlo = lvl[loc];   // read with the rest: one LDS round trip less on the walk path
         unsigned mxh = (hi >= 1) ? max(pf, bpf) : 0u;
         unsigned mxl = (lo + 1 <= M - 1) ? max(sf, bsf) : 0u;
         if (!GV_ABL(1024) && mxh <= (unsigned)i && hi >= 0 && hi < M && lvh > (unsigned)i)
-          mxh = max(mxh, walk_bucket(e0h, e1h, Q, true, 0, false, Phi));
+          mxh = max(mxh, walk_bucket(hic, ch, Q, true, 0, false, Phi));
         if (!GV_ABL(1024) && mxl <= (unsigned)i && lo >= 0 && lo < M && lvlo > (unsigned)i)
-          mxl = max(mxl, walk_bucket(e0l, e1l, Q, false, Plo, true, 0));
+          mxl = max(mxl, walk_bucket(loc, cl, Q, false, Plo, true, 0));
         if (mxh > (unsigned)i) mask |= 1u;
         if (mxl > (unsigned)i) mask |= 1u << (w - 1);
         // sectors with a lattice-gap run: the cell next to the edge cell is not covered by the level test
@@ -937,12 +915,25 @@ bool launch_ray_sectors(const SectorArgs &a, hipStream_t s, hipEvent_t done, hip
   const int total = a.wg_base[8] + a.n_helpers;
   if (a.wg_first >= total) return false;
   const int grid = (total - a.wg_first + a.wg_stride - 1) / a.wg_stride;
-  if (imax <= 4 * kSecThreads)
+  // more than 64 KB of dynamic LDS has to be announced per kernel (once per size increase)
+  auto allow_lds = [&](const void *fn, size_t &granted) {
+    if (lds > granted && lds > 64u * 1024u) {
+      if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
+      granted = lds;
+    }
+    return true;
+  };
+  static size_t granted[3] = {0, 0, 0};
+  if (imax <= 4 * kSecThreads) {
+    if (!allow_lds(reinterpret_cast<const void *>(&k_ray_sectors<4>), granted[0])) return false;
     hipExtLaunchKernelGGL(k_ray_sectors<4>, dim3(grid), dim3(kSecThreads), (uint32_t)lds, s, t0, done, 0, a);
-  else if (imax <= 8 * kSecThreads)
+  } else if (imax <= 8 * kSecThreads) {
+    if (!allow_lds(reinterpret_cast<const void *>(&k_ray_sectors<8>), granted[1])) return false;
     hipExtLaunchKernelGGL(k_ray_sectors<8>, dim3(grid), dim3(kSecThreads), (uint32_t)lds, s, t0, done, 0, a);
-  else
+  } else {
+    if (!allow_lds(reinterpret_cast<const void *>(&k_ray_sectors<16>), granted[2])) return false;
     hipExtLaunchKernelGGL(k_ray_sectors<16>, dim3(grid), dim3(kSecThreads), (uint32_t)lds, s, t0, done, 0, a);
+  }
   return true;
 }
 
