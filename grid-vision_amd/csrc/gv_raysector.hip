@@ -738,6 +738,8 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
           }
         }
       }
+    } else {
+      stamp();   // 8: (no compaction for this group: the stamp slots stay aligned)
     }
 #ifdef GV_DIAG
     if (A.dbg) __syncthreads();
