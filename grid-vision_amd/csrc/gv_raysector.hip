@@ -23,6 +23,7 @@
 #include <hip/hip_ext.h>
 
 #include <algorithm>
+#include <type_traits>
 
 namespace gv {
 
@@ -124,21 +125,26 @@ constexpr int kSecThreads = 512;   // 8 wavefronts per sector workgroup
 // holds beyond that (the buckets of the few rational slopes many ends share) goes to one overflow list.  No count /
 // prefix / placement passes: an end is placed the moment its bucket is known.
 constexpr int kSlotLog = 3, kSlots = 1 << kSlotLog;
+#ifndef GV_SLOT_TOTAL
+#define GV_SLOT_TOTAL 2048
+#endif
+constexpr int kSlotTotal = GV_SLOT_TOTAL;   // a wedge with more ends than this (4 per bucket: measured, config 3 and config 5) is placed by counting sort instead
 
 // LDS layout of one sector workgroup (bytes), shared by the kernel and the launcher
 struct SectorLds {
-  size_t tab, marks, cnt, bmax32, lvl, pfx, sfx, raw, over, total;
+  size_t tab, marks, cnt, bstart, bmax32, lvl, pfx, sfx, raw, over, total;
 };
 __host__ __device__ inline SectorLds sector_lds_layout(int cap, int marks_words, int log2m)
 {
   const size_t M = (size_t)1 << log2m;
   SectorLds L;
   size_t o = 0;
-  L.tab = o;    o += M * kSlots * 4;            // [M][kSlots] packed ends (16-byte aligned rows)
+  L.tab = o;    o += (M * kSlots > (size_t)cap ? M * kSlots : (size_t)cap) * 4;   // [M][kSlots] packed ends (16-byte aligned rows); a crowded group: cap ends grouped by bucket
   L.raw = o;    o += (size_t)cap * 4;           // packed ends in scan order (staging list; the long-ray pass reads it too)
   L.over = o;   o += (size_t)cap * 4;           // overflow entries: bucket << 16 | index into raw
   L.marks = o;  o += (size_t)marks_words * 4;
-  L.cnt = o;    o += M * 4;                     // ends per bucket (may exceed kSlots)
+  L.cnt = o;    o += M * 4;                     // ends per bucket (may exceed kSlots); a crowded group: the end of every bucket's run
+  L.bstart = o; o += M * 4;                     // a crowded group: the start of every bucket's run
   L.bmax32 = o; o += 2 * M * 4;                 // bucket max reach; dead once the range-max tables are built: then the long-ray list (2M entries)
   L.lvl = o;
   L.pfx = L.lvl + 7 * M * 2;                    // in-block (64 buckets) sparse levels 0..6
@@ -208,12 +214,13 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
   unsigned *over = reinterpret_cast<unsigned *>(smem + L.over);        // what does not fit: bucket << 16 | index into raw
   unsigned *marks = reinterpret_cast<unsigned *>(smem + L.marks);      // one word of cell bits per wedge column
   unsigned *cnt = reinterpret_cast<unsigned *>(smem + L.cnt);          // ends per bucket
+  unsigned *bstart = reinterpret_cast<unsigned *>(smem + L.bstart);    // crowded group: bucket run starts
   unsigned *bmax32 = reinterpret_cast<unsigned *>(smem + L.bmax32);    // bucket max reach; later the long-ray list
   unsigned short *lvl = reinterpret_cast<unsigned short *>(smem + L.lvl);   // lvl[l*M+m] = max of buckets m..m+2^l-1 inside m's 64-block
   unsigned short *pfx = reinterpret_cast<unsigned short *>(smem + L.pfx);   // max from the block start to m
   unsigned short *sfx = reinterpret_cast<unsigned short *>(smem + L.sfx);   // max from m to the block end
   unsigned *raw = reinterpret_cast<unsigned *>(smem + L.raw);               // packed ends, scan order
-  __shared__ unsigned s_wsum[NT / 64], s_blkmax[8], s_blkpfx[9], s_blksfx[9], s_lvlmin[10 * 8], s_nlong, s_nover, s_T, s_maxreach;
+  __shared__ unsigned s_wsum[NT / 64], s_wsum2[NT / 64], s_blkmax[8], s_blkpfx[9], s_blksfx[9], s_lvlmin[10 * 8], s_nlong, s_nover, s_T, s_maxreach;
   __shared__ unsigned long long s_wvis[NT / 64];
   __shared__ unsigned s_rowpart[CH][NT / 64];   // multi-group path: ends per (row, wavefront)
 
@@ -286,13 +293,27 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
   // largest reach among the c ends of bucket m whose slope b/a lies in [Plo/Q, Phi/Q); lo_open / hi_open: no
   // bound on that side.  The bucket's row of the table is read whole (two 16-byte reads issued together); the
   // overflow list is only looked at for a bucket that holds more than its row.
-  auto walk_bucket = [&](int m, unsigned c, int Q, bool lo_open, int Plo, bool hi_open, int Phi) -> unsigned {
+  // `mode`: std::true_type = the group's buckets are contiguous runs of `tab` (counting-sort placement, crowded
+  // wedges), std::false_type = rows of kSlots + overflow list (everything else)
+  auto walk_bucket = [&](auto mode, int m, unsigned e0, unsigned c, int Q, bool lo_open, int Plo, bool hi_open, int Phi) -> unsigned {
+    constexpr bool sorted_mode = decltype(mode)::value;
     unsigned mx = 0;
     auto take = [&](unsigned p, bool valid) {
       const int a = ab_a(p), bq = m24(ab_b(p), Q);
       const bool in = valid && (lo_open || bq >= m24(Plo, a)) && (hi_open || bq < m24(Phi, a));
       mx = in ? max(mx, (unsigned)(a + (int)(p & 1u))) : mx;
     };
+    if constexpr (sorted_mode) {   // c = end of the run: four ends per step, the LDS reads of a step issued together
+      const unsigned e1 = c;
+      for (unsigned e = e0; e < e1; e += 4) {   // (e0 = bstart[m], read by the caller together with its other table reads)
+        unsigned p[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) p[q] = tab[min(e + (unsigned)q, e1 - 1u)];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) take(p[q], e + (unsigned)q < e1);
+      }
+      return mx;
+    } else {
     const uint4 r0 = *reinterpret_cast<const uint4 *>(tab + ((unsigned)m << kSlotLog));
     const uint4 r1 = *reinterpret_cast<const uint4 *>(tab + ((unsigned)m << kSlotLog) + 4);
     take(r0.x, c > 0u); take(r0.y, c > 1u); take(r0.z, c > 2u); take(r0.w, c > 3u);
@@ -305,10 +326,11 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
       }
     }
     return mx;
+    }
   };
   // one cell (column i, minor offset jc), exactly: whole buckets between its two boundary buckets by
   // range-max, the boundary buckets themselves end by end
-  auto cell_exact = [&](int i, int Q, int jc) -> bool {
+  auto cell_exact = [&](auto mode, int i, int Q, int jc) -> bool {
     const int Plo = 2 * jc - 1, Phi = 2 * jc + 1;
     const int lo = bucket_of_boundary(Plo, Q), hi = bucket_of_boundary(Phi, Q);   // lo < hi unless both outside
     unsigned mx = 0;
@@ -316,14 +338,16 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
     // the boundary buckets' bounds and own maxima are requested together with the range-max reads
     const int loc = min(max(lo, 0), M - 1), hic = min(max(hi, 0), M - 1);
     const unsigned cl = cnt[loc], ch = cnt[hic];
+    unsigned sl = 0, sh = 0;
+    if constexpr (decltype(mode)::value) { sl = bstart[loc]; sh = bstart[hic]; }
     const unsigned lvlo = lvl[loc], lvh = lvl[hic];
     if (l <= r) mx = rmq(l, r);
     // a boundary bucket is only walked when its own max reach (level 0 of the range-max table) says that
     // one of its ends could decide the cell: beyond the threshold column most buckets hold short rays only
     if (mx <= (unsigned)i && lo >= 0 && lo < M && lvlo > (unsigned)i)
-      mx = max(mx, walk_bucket(loc, cl, Q, false, Plo, hi != lo, Phi));
+      mx = max(mx, walk_bucket(mode, loc, sl, cl, Q, false, Plo, hi != lo, Phi));
     if (mx <= (unsigned)i && hi >= 0 && hi < M && hi != lo && lvh > (unsigned)i)
-      mx = max(mx, walk_bucket(hic, ch, Q, true, 0, false, Phi));
+      mx = max(mx, walk_bucket(mode, hic, sh, ch, Q, true, 0, false, Phi));
     return mx > (unsigned)i;
   };
   // minor-offset range [blo, bhi] of the wedge in column a (empty when blo > bhi)
@@ -452,7 +476,8 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
   auto gap_group = [&](int g0, int size) -> bool {   // aligned group [g0, g0+size) entirely inside a gap run
     return (g0 >= xb0 && g0 + size <= xb1) || (g0 >= xt0 && g0 + size <= xt1);
   };
-  auto process_group = [&](unsigned rowmask, int wsel, bool first) {
+  auto process_group = [&](auto mode, unsigned rowmask, int wsel, bool first) {
+    constexpr bool sorted_mode = decltype(mode)::value;
     const bool mine_w = (wsel < 0) || (wave == wsel);
     unsigned mycnt, incl;
     if (first) {   // whole wedge in one group: the scan already produced the prefix and s_wsum
@@ -503,9 +528,14 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
         const unsigned p = raw[k];
         const int bk = bucket_of_end(ab_a(p), ab_b(p));
         const unsigned rch = (unsigned)(ab_a(p) + (int)(p & 1u));
-        const unsigned slot_in = atomicAdd(&cnt[bk], 1u);
-        if (slot_in < (unsigned)kSlots) tab[((unsigned)bk << kSlotLog) + slot_in] = p;
-        else over[atomicAdd(&s_nover, 1u)] = ((unsigned)bk << 16) | k;
+        if constexpr (sorted_mode) {
+          reinterpret_cast<unsigned short *>(over)[k] = (unsigned short)bk;   // (the overflow list's space: unused in this mode)
+          atomicAdd(&cnt[bk], 1u);
+        } else {
+          const unsigned slot_in = atomicAdd(&cnt[bk], 1u);
+          if (slot_in < (unsigned)kSlots) tab[((unsigned)bk << kSlotLog) + slot_in] = p;
+          else over[atomicAdd(&s_nover, 1u)] = ((unsigned)bk << 16) | k;
+        }
         atomicMax(&bmax32[bk], rch);
         vis += rch;
       }
@@ -514,8 +544,34 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
     }
     __syncthreads();
     stamp();   // 3: staged, placed
-    stamp();   // 4: (the former prefix pass)
-    stamp();   // 5: (the former placement pass)
+    // A crowded wedge (thousands of ends per group: most buckets hold more than their row) would push half its ends
+    // into the overflow list, which every walk of a full bucket scans: it is placed by counting sort instead --
+    // prefix over the bucket counts, every end into its bucket's contiguous run.
+    if constexpr (sorted_mode) {
+      {
+        const unsigned bc = (tid < M) ? cnt[tid] : 0u;
+        const unsigned in2 = wave_scan<OpAdd>(bc);
+        if (lane == 63) s_wsum2[wave] = in2;
+        __syncthreads();
+        unsigned base = 0;
+#pragma unroll
+        for (int wv = 0; wv < NT / 64; ++wv) {
+          const unsigned t = s_wsum2[wv];
+          if (wv < wave) base += t;
+        }
+        if (tid < M) {
+          bstart[tid] = base + in2 - bc;
+          cnt[tid] = base + in2 - bc;   // placement cursor; ends up as the end of the run
+        }
+      }
+      __syncthreads();
+      for (unsigned k = tid; k < n; k += NT) {
+        tab[atomicAdd(&cnt[reinterpret_cast<const unsigned short *>(over)[k]], 1u)] = raw[k];
+      }
+      __syncthreads();
+    }
+    stamp();   // 4: (crowded groups: prefix + placement)
+    stamp();   // 5
     // range-max structure: wavefront `wave` owns the 64-bucket block `wave` (cross-lane ops only)
     if (wave < NB) {
       const int m = wave * 64 + lane;
@@ -647,7 +703,7 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
         const int jlo = (m24(2 * i, s) + S) >> (log2s + 1);
         const int jhi = (m24(2 * i, s + 1) + S) >> (log2s + 1);
         if (jhi - jlo > 1 || k > jhi - jlo) continue;
-        if (cell_exact(i, 2 * i, jlo + k)) atomicOr(&marks[i], 1u << k);
+        if (cell_exact(mode, i, 2 * i, jlo + k)) atomicOr(&marks[i], 1u << k);
       }
     }
     __syncthreads();   // s_T, s_maxreach, s_blkpfx, s_blksfx visible
@@ -782,13 +838,15 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
         const unsigned pf = pfx[r], bpf = s_blkpfx[r >> 6];
         const unsigned sf = sfx[l], bsf = s_blksfx[l >> 6];
         const unsigned ch = cnt[hic], cl = cnt[loc];
+        unsigned sh = 0, sl = 0;
+        if constexpr (sorted_mode) { sh = bstart[hic]; sl = bstart[loc]; }
         const unsigned lvh = lvl[hic], lvlo = lvl[loc];   // read with the rest: one LDS round trip less on the walk path
         unsigned mxh = (hi >= 1) ? max(pf, bpf) : 0u;
         unsigned mxl = (lo + 1 <= M - 1) ? max(sf, bsf) : 0u;
         if (!GV_ABL(1024) && mxh <= (unsigned)i && hi >= 0 && hi < M && lvh > (unsigned)i)
-          mxh = max(mxh, walk_bucket(hic, ch, Q, true, 0, false, Phi));
+          mxh = max(mxh, walk_bucket(mode, hic, sh, ch, Q, true, 0, false, Phi));
         if (!GV_ABL(1024) && mxl <= (unsigned)i && lo >= 0 && lo < M && lvlo > (unsigned)i)
-          mxl = max(mxl, walk_bucket(loc, cl, Q, false, Plo, true, 0));
+          mxl = max(mxl, walk_bucket(mode, loc, sl, cl, Q, false, Plo, true, 0));
         if (mxh > (unsigned)i) mask |= 1u;
         if (mxl > (unsigned)i) mask |= 1u << (w - 1);
         // sectors with a lattice-gap run: the cell next to the edge cell is not covered by the level test
@@ -804,7 +862,7 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
       while (todo) {
         const int k = __ffs(todo) - 1;
         todo &= todo - 1;
-        if (cell_exact(i, Q, jlo + k)) mask |= 1u << k;
+        if (cell_exact(mode, i, Q, jlo + k)) mask |= 1u << k;
       }
       if (mask) atomicOr(&marks[i], mask);   // no-return LDS OR: the lane does not wait for a read of the old word
     }
@@ -827,7 +885,7 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
           const int jlo = (m24(2 * i, s) + S) >> (log2s + 1);
           const int jhi = (m24(2 * i, s + 1) + S) >> (log2s + 1);
           if (k > jhi - jlo) continue;
-          if (cell_exact(i, 2 * i, jlo + k)) atomicOr(&marks[i], 1u << k);
+          if (cell_exact(mode, i, 2 * i, jlo + k)) atomicOr(&marks[i], 1u << k);
         }
       }
     }
@@ -839,24 +897,48 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
   // Normally the whole wedge is one group.  With more ends than one LDS group holds: one group
   // per row of columns, and per wavefront (64 columns x <= 32 ends <= 2048 <= cap) where a row
   // alone is too big.
-  if (total <= cap) {
-    process_group((1u << CH) - 1u, -1, true);
+  // Two instantiations of the group code: a wedge whose ends fit the bucket rows (at most kSlotTotal: the usual case)
+  // is one group in row mode; a crowded wedge runs the counting-sort mode, one group or several (one call site).
+  if (total <= kSlotTotal && total <= cap) {
+    process_group(std::false_type{}, (1u << CH) - 1u, -1, true);
   } else {
+    const bool single = total <= cap;
+    if (!single) {
 #pragma unroll
-    for (int c = 0; c < CH; ++c) {
-      const unsigned r = wave_sum((unsigned)__popc(ends[c]));
-      if (lane == 0) s_rowpart[c][wave] = r;
-    }
-    __syncthreads();
-    for (int c = 0; c < CH; ++c) {
-      int rt = 0;
-      for (int wv = 0; wv < NT / 64; ++wv) rt += (int)s_rowpart[c][wv];
-      if (rt == 0) continue;
-      const int nw = (rt <= cap) ? 1 : NT / 64;
-      for (int wi = 0; wi < nw; ++wi) {
-        scan_row(c);
-        process_group(1u << c, (nw == 1) ? -1 : wi, false);
+      for (int c = 0; c < CH; ++c) {
+        const unsigned r = wave_sum((unsigned)__popc(ends[c]));
+        if (lane == 0) s_rowpart[c][wave] = r;
       }
+      __syncthreads();
+    }
+    int gc = 0, gw = 0, gnw = 0;   // multi-group enumeration: row gc, wavefront gw of gnw
+    auto next_group = [&]() -> bool {
+      while (gc < CH) {
+        if (gnw == 0) {
+          int rt = 0;
+          for (int wv = 0; wv < NT / 64; ++wv) rt += (int)s_rowpart[gc][wv];
+          if (rt == 0) { ++gc; continue; }
+          gnw = (rt <= cap) ? 1 : NT / 64;
+          gw = 0;
+        }
+        if (gw < gnw) return true;
+        ++gc;
+        gnw = 0;
+      }
+      return false;
+    };
+    bool more = single ? true : next_group();
+    while (more) {
+      unsigned rowmask = (1u << CH) - 1u;
+      int wsel = -1;
+      if (!single) {
+        scan_row(gc);
+        rowmask = 1u << gc;
+        wsel = (gnw == 1) ? -1 : gw;
+        ++gw;
+      }
+      process_group(std::true_type{}, rowmask, wsel, single);
+      more = single ? false : next_group();
     }
   }
 

@@ -1872,3 +1872,43 @@ def test_random_call_sequences_with_frames_in_flight(gvamd, seed):
     for p3 in pins:
         for p in p3:
             p.close()
+
+
+@pytest.mark.parametrize("extra", [0, 30_000, 400_000])
+def test_sector_bucket_rows_overflow_on_shared_slopes(gvamd, extra):
+    """Ends on exact rational slopes through the sensor cell (0, 1/3, 1/2, 2/3, 1, and their mirror images in all
+    eight octants): hundreds of ends share one slope bucket, far more than a bucket's row of eight holds, so the
+    row-mode walks have to go through the overflow list; with 30 k scattered points on top the wedges stay in row
+    mode, with 400 k they switch to counting-sort placement.  Free cells against the literal march."""
+    gx, gy, res = 200, 200, 0.2          # 1000 x 1000 cells
+    h = gvamd.GridVisionHIP(gx, gy, res)
+    og = ol.OGrid(gx, gy, res)
+    tfs = synth.transforms(False)
+    tfs["base_lidar"] = np.array([0.0, 0.0, 0.0, 1.0, float(og.g.pos_x) + 0.1, 0.1, 1.8])   # the middle of a cell near the centre
+    h.set_transforms(tfs["cam_lidar"], tfs["base_cam"], tfs["base_lidar"])
+    xs, ys = [], []
+    steps = np.arange(1, 480, dtype=np.float64)
+    for p, q in ((0, 1), (1, 3), (1, 2), (2, 3), (1, 1)):
+        for sx in (1, -1):
+            for sy in (1, -1):
+                for swap in (False, True):
+                    a = steps * q * res
+                    b = steps * p * res
+                    keep = (a < 0.49 * gx) & (b < 0.49 * gy)
+                    a, b = a[keep][::2], b[keep][::2]          # every second lattice point of the line
+                    xs.append(sx * (b if swap else a))
+                    ys.append(sy * (a if swap else b))
+    x = np.concatenate(xs).astype(np.float32)
+    y = np.concatenate(ys).astype(np.float32)
+    if extra:
+        st = synth.Stream(4711, extra)
+        x = np.concatenate([x, st.uniform(extra, -0.48 * gx, 0.48 * gx)])
+        y = np.concatenate([y, st.uniform(extra, -0.48 * gy, 0.48 * gy)])
+    z = np.zeros(len(x), np.float32)
+    h.upload_xyz(x, y, z)
+    h.process_frame(gvamd.FRAME_BIN | gvamd.FRAME_RAYMARCH | gvamd.FRAME_KEEP_COUNTS)
+    hits, _, miss, _, _ = oracle_frame(og, tfs, x, y, z)
+    assert int(miss.sum()) > 1000
+    assert np.array_equal(h.hits(), hits)
+    assert np.array_equal(h.miss(), miss.astype(np.int32)), int(np.count_nonzero(h.miss() != miss))
+    h.close()
