@@ -101,6 +101,12 @@ struct gv_context {
   unsigned long long *d_dbg = nullptr;        // GV_SECTOR_DBG=1: phase stamps of the sector kernel
   unsigned long long *d_bin_dbg[2] = {nullptr, nullptr};   // GV_BIN_DBG=1: phase stamps of the partition / tile kernels
   int32_t env_ablate = 0;                     // GV_ABLATE
+  unsigned long long *d_tl = nullptr;         // GV_TIMELINE=1: {begin, end} of the four kernels of the last kTlFrames frames
+  static constexpr uint64_t kTlFrames = 4096;
+  unsigned long long *tl_slot(int kernel) const
+  {
+    return d_tl ? d_tl + ((frame_no % kTlFrames) * 4 + (uint64_t)kernel) * 2 : nullptr;
+  }
 #endif
   GridParams g{};
   gv_cam_params cam{};
@@ -597,6 +603,7 @@ int fill_sector_args(gv_context *h, SectorArgs &sa, int p)
 #ifdef GV_DIAG
   sa.ablate = h->env_ablate;
   sa.dbg = h->d_dbg;
+  sa.tl = h->tl_slot(2);
 #endif
   sa.flat_k = h->env_flat_k;
   sa.march_limit = h->env_march_limit;
@@ -706,6 +713,7 @@ int enqueue_binning(gv_context *h, const DetSet &D, int p, int k, size_t lo, siz
   }
 #ifdef GV_DIAG
   a.dbg = h->d_bin_dbg[0];
+  a.tl = h->tl_slot(0);
 #endif
   launch_bin_partition(a, s, timed ? h->kt[0][0] : nullptr, timed ? h->kt[0][1] : nullptr, any_order);
   h->lane_clean[k] = false;
@@ -742,6 +750,7 @@ int enqueue_binning(gv_context *h, const DetSet &D, int p, int k, size_t lo, siz
   t.nxw = h->nxw; t.nyw = h->nyw; t.nx_pad = h->nx_pad; t.ny_pad = h->ny_pad;
 #ifdef GV_DIAG
   t.dbg = h->d_bin_dbg[1];
+  t.tl = h->tl_slot(1);
 #endif
   launch_bin_tiles(t, (uint32_t)(n / kBinSplitKeys), s, timed ? h->kt[1][0] : nullptr, timed ? h->kt[1][1] : nullptr);
   if (timed) h->kt_used[1] = true;
@@ -786,6 +795,9 @@ int enqueue_grid_pass(gv_context *h, int p, const Rect *rects, int32_t n_rects, 
   t.counts = counts;
   t.y_begin = y0;
   t.y_end = y1;
+#ifdef GV_DIAG
+  t.tl = h->tl_slot(3);
+#endif
   const bool ran = launch_finalize_tiles(t, s, done, t0);
   if (launched) *launched = ran;
   if (!ran && done) GV_HIP(hipEventRecord(done, s));
@@ -1352,6 +1364,15 @@ int gv_create(gv_handle *out, uint8_t grid_x, uint8_t grid_y, double resolution,
           GV_C(hipMemsetAsync(q, 0, 8192 * 16 * sizeof(unsigned long long), h->stream));
         }
     }
+    if (const char *e = std::getenv("GV_TIMELINE")) {
+      if (std::atoi(e) > 0) {
+        const size_t nt = gv_context::kTlFrames * 8;
+        GV_C(hipMalloc(reinterpret_cast<void **>(&h->d_tl), nt * sizeof(unsigned long long)));
+        std::vector<unsigned long long> init(nt);
+        for (size_t i = 0; i < nt; i += 2) { init[i] = ~0ull; init[i + 1] = 0ull; }
+        GV_C(hipMemcpy(h->d_tl, init.data(), nt * sizeof(unsigned long long), hipMemcpyHostToDevice));
+      }
+    }
     if (const char *e = std::getenv("GV_SECTOR_DBG")) {
       if (std::atoi(e) > 0) {
         GV_C(hipMalloc(reinterpret_cast<void **>(&h->d_dbg), kMaxStatSlots * 16 * sizeof(unsigned long long)));
@@ -1448,6 +1469,7 @@ int gv_destroy(gv_handle h)
     if (p) (void)hipFree(p);
 #ifdef GV_DIAG
   if (h->d_dbg) (void)hipFree(h->d_dbg);
+  if (h->d_tl) (void)hipFree(h->d_tl);
   for (auto q : h->d_bin_dbg) if (q) (void)hipFree(q);
 #endif
   for (int k = 0; k < gv_context::kSets; ++k) {
@@ -2140,6 +2162,28 @@ int gv_get_ray_stats(gv_handle h, uint64_t *n_rays, uint64_t *n_visits)
 }
 
 #ifdef GV_DIAG
+// diagnostic build only (tools/native_timeline.py, GV_TIMELINE=1): reset (out == nullptr) or copy out the
+// {begin, end} clock pairs of the four kernels of the last `frames` <= 4096 frames, slot = frame number % 4096
+int gv_debug_timeline(gv_handle h, unsigned long long *out, size_t frames)
+{
+  if (!h || !h->d_tl || frames > gv_context::kTlFrames) return GV_ERR_STATE;
+  GV_TRY
+  int rc = use_device(h);
+  if (rc) return rc;
+  GV_HIP(hipDeviceSynchronize());
+  const size_t n = gv_context::kTlFrames * 8;
+  if (!out) {
+    std::vector<unsigned long long> init(n);
+    for (size_t i = 0; i < n; i += 2) { init[i] = ~0ull; init[i + 1] = 0ull; }
+    GV_HIP(hipMemcpy(h->d_tl, init.data(), n * sizeof(unsigned long long), hipMemcpyHostToDevice));
+    return GV_OK;
+  }
+  GV_HIP(hipMemcpy(out, h->d_tl, frames * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  return GV_OK;
+  GV_CATCH
+}
+uint64_t gv_debug_frame_no(gv_handle h) { return h ? h->frame_no : 0; }
+
 // diagnostic build only (tools/sector_phases.py): copies the phase stamps of the last sector launch
 int gv_debug_sector_stamps(gv_handle h, unsigned long long *out, size_t n_wg)
 {

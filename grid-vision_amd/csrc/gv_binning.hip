@@ -92,6 +92,7 @@ __global__ void __launch_bounds__(kPartThreads, GV_PART_WPE) k_bin_partition(Bin
   const uint32_t base = w * a.chunk;
   const uint32_t npts = min(a.chunk, a.n - base);
   GV_STAMP(a.dbg, 0);
+  GV_TL_BEGIN(a.tl);
   for (int t = tid; t < T; t += kPartThreads) hist[t] = 0;
   if (tid == 0) s_nout = 0;
   // bbox test: thresholds and tile candidate masks staged in LDS -- per point they are a chain of dependent
@@ -314,6 +315,7 @@ __global__ void __launch_bounds__(kPartThreads, GV_PART_WPE) k_bin_partition(Bin
   unsigned *dst = reinterpret_cast<unsigned *>(a.keys + (size_t)w * a.chunk);
   for (unsigned j = tid; j < (total + 1) / 2; j += kPartThreads) dst[j] = src[j];
   GV_STAMP(a.dbg, 5);
+  GV_TL_END(a.tl);
 }
 
 // ------------------------------------------------------------------ tiles -----
@@ -335,6 +337,7 @@ __global__ void __launch_bounds__(kTileThreads) k_bin_tiles(BinTileArgs a)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int T = a.n_tiles;
   GV_STAMP(a.dbg, 0);
+  GV_TL_BEGIN(a.tl);
   // Workgroups are dealt round-robin over the 8 XCDs (blockIdx b and b + 8 share one, each with its own L2).
   // Consecutive tiles read neighbouring bytes of every chunk (one 128-byte line of a chunk's offset row covers
   // 64 tiles, one line of its sorted keys ~9 tiles), so each XCD takes a contiguous run of tiles: its L2 then
@@ -620,6 +623,7 @@ __global__ void __launch_bounds__(kTileThreads) k_bin_tiles(BinTileArgs a)
     }
   }
   GV_STAMP(a.dbg, 5);
+  GV_TL_END(a.tl);
 }
 
 // ---------------------------------------------------------------- launch -----

@@ -10,6 +10,20 @@ namespace gv {
 
 // exact fp32 form of the bbox test + per-16x16-pixel-tile candidate masks (built on the device by
 // launch_bbox_prepare from the uploaded gv_bbox array)
+// Diagnostic build only (-DGV_DIAG, GV_TIMELINE=1): every workgroup of a launch reports the constant-rate clock when
+// it starts and when it ends; min / max over the launch = the kernel's residence on the device, taken without any
+// packet in the queues (tools/native_timeline.py).  Nothing in the shipped kernels.
+#ifdef GV_DIAG
+// (begin: the first workgroup of the launch only; end: every eighth workgroup -- one atomic per workgroup on one
+//  address slowed the 1024-workgroup grid pass by a third)
+#define GV_TL_LINEAR_ID (blockIdx.x + blockIdx.y * gridDim.x)
+#define GV_TL_BEGIN(tl) do { if ((tl) && threadIdx.x == 0 && GV_TL_LINEAR_ID == 0) atomicMin(&(tl)[0], (unsigned long long)__builtin_amdgcn_s_memrealtime()); } while (0)
+#define GV_TL_END(tl) do { if ((tl) && threadIdx.x == 0 && (GV_TL_LINEAR_ID & 7u) == 0) atomicMax(&(tl)[1], (unsigned long long)__builtin_amdgcn_s_memrealtime()); } while (0)
+#else
+#define GV_TL_BEGIN(tl) do { } while (0)
+#define GV_TL_END(tl) do { } while (0)
+#endif
+
 struct BBoxTest {
   const float4 *bbox_f;                  // (x_min, y_min, x_max, y_max) as float thresholds
   const unsigned long long *tile_mask;   // [tiles_y][tiles_x][mask_words]
@@ -107,6 +121,7 @@ struct BinArgs {
   int32_t n_rect_poses;
   Rect *rects_out;
   unsigned long long *dbg; // diagnostic build: 16 clock stamps per workgroup (null in production)
+  unsigned long long *tl;  // diagnostic build: {first workgroup in, last workgroup out} of this launch (GV_TIMELINE)
 };
 constexpr size_t kBinBBoxLdsMax = 24 * 1024;   // LDS the partition kernel may spend on the bbox-test tables
 uint32_t bin_chunk_for(size_t n);
@@ -128,6 +143,7 @@ struct BinTileArgs {
   uint32_t *freeN, *freeT;                 // free-cell bitmaps of the same buffer set: zeroed here (or null)
   int32_t nxw, nyw, nx_pad, ny_pad;
   unsigned long long *dbg;                 // diagnostic build: 16 clock stamps per workgroup (null in production)
+  unsigned long long *tl;                  // diagnostic build: launch begin / end (GV_TIMELINE)
 };
 // n_helpers >= n / split_keys extra workgroups serve the shares 1.. of crowded tiles
 void launch_bin_tiles(const BinTileArgs &a, uint32_t n_helpers, hipStream_t s, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr);
@@ -155,6 +171,7 @@ struct SectorArgs {
   uint32_t flat_direct;   // a tail of at most this many cells is evaluated exactly without looking at the long rays at all
   int32_t ablate;         // timing experiments only: 2 skip gather, 4 skip flush, 8/16/32 early exits
   unsigned long long *dbg; // diagnostic phase stamps, 16 per workgroup (null in production)
+  unsigned long long *tl;  // diagnostic build: launch begin / end (GV_TIMELINE)
 };
 size_t sector_lds_bytes(int cap, int marks_words, int log2m);
 bool launch_ray_sectors(const SectorArgs &a, hipStream_t s, hipEvent_t done = nullptr, hipEvent_t t0 = nullptr);
@@ -170,6 +187,7 @@ struct FinalizeTileArgs {
   int32_t nx_pad, ny_pad;
   bool counts;            // apply the hit/miss rule
   int32_t y_begin, y_end; // rows to finalise ([0, ny) on one GPU)
+  unsigned long long *tl; // diagnostic build: launch begin / end (GV_TIMELINE)
 };
 bool launch_finalize_tiles(const FinalizeTileArgs &a, hipStream_t s, hipEvent_t done = nullptr, hipEvent_t t0 = nullptr);
 void launch_miss_to_i32(const uint32_t *freeN, const uint32_t *freeT, int nx, int ny, int nx_pad, int ny_pad,

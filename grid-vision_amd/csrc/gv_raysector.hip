@@ -161,6 +161,7 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
   extern __shared__ __align__(16) unsigned char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
+  GV_TL_BEGIN(A.tl);
   // position in the dispatch order: a multi-GPU rank runs every wg_stride-th workgroup
   const int bid_all = A.wg_first + (int)blockIdx.x * A.wg_stride;
   // Dispatch order (workgroups start roughly in blockIdx order and the launch is ~2 rounds deep):
@@ -969,6 +970,7 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
   }
   __syncthreads();
   stamp();   // 11: flush done
+  GV_TL_END(A.tl);
   if (tid == 0) {
     // per-workgroup slots, summed by the host on demand: a shared counter would
     // serialise 2 x 8*S atomics on one address (~12 ns each)
@@ -1068,6 +1070,7 @@ __global__ void __launch_bounds__(256) k_finalize_tiles(FinalizeTileArgs a)
   __shared__ int s_nr;
   const int x0 = blockIdx.x * 64, y0 = a.y_begin + blockIdx.y * 64;
   const int tid = threadIdx.x;
+  GV_TL_BEGIN(a.tl);
   if (tid == 0) s_nr = 0;
   __syncthreads();
   // rectangles that touch this tile (object order must be kept only for equal cells:
@@ -1136,6 +1139,7 @@ __global__ void __launch_bounds__(256) k_finalize_tiles(FinalizeTileArgs a)
     const unsigned packed = pack_i8_t(p4.w) | (pack_i8_t(p4.z) << 8) | (pack_i8_t(p4.y) << 16) | (pack_i8_t(p4.x) << 24);
     __builtin_nontemporal_store(packed, reinterpret_cast<unsigned *>(a.occ_i8 + ((size_t)a.g.G - 4 - c)));
   }
+  GV_TL_END(a.tl);
 }
 
 // `done` (optional) completes with the kernel, on its own dispatch packet (see launch_ray_sectors);
