@@ -59,29 +59,35 @@ struct DetSet {
 }  // namespace
 
 struct gv_context {
-  // Frames in flight run on two LANES: frame f does partition, tile pass and sector stage back to back on
-  // the in-order stream of lane f % 2, then its grid pass on the PUBLIC stream behind one event.  No event
-  // sits between the stages on a lane (a barrier packet between two kernels costs ~6 us of queue time, back
-  // to back kernels of one queue follow each other without a gap), the grid passes are one in-order
-  // sequence by construction (the log-odds grid is one sequence of updates), and everything a frame
-  // produced is visible on the public stream right behind it.  Buffer sets 1..4 rotate with the frames
-  // (set 0: serial frames and standalone calls); a set is handed to frame f+4 once the HOST has seen
-  // frame f finish -- back-pressure on the caller, at most four frames in flight, instead of a barrier
-  // on a lane.  With the copy stream that makes the 4 hardware queues a process gets by default (a 5th
-  // stream shares a queue and serialises).  Measured on config 3: one in-order stream 12.0 k frames/s;
-  // one stream per STAGE with three events per frame (round 1) 14.4 k; two lanes with the grid pass on
-  // the lane behind a cross-lane wait 16.5 k; this layout 18.6 k; three / four lanes 15.4 / 14.3 k
-  // (tools/multi_handle.py).
-  static constexpr int kSets = 5;
+  // Frames in flight run on LANES (three; GV_LANES=2: two): frame f does partition, tile pass and sector stage back
+  // to back on the in-order stream of lane f % lanes, then its grid pass on the PUBLIC stream behind one event.
+  // No event sits between the stages on a lane (a barrier packet between two kernels costs ~6 us of queue time,
+  // back to back kernels of one queue follow each other with a gap of a few us that the other lanes fill), the
+  // grid passes are one in-order sequence by construction (the log-odds grid is one sequence of updates), and
+  // everything a frame produced is visible on the public stream right behind it.  Buffer sets 1..2*lanes rotate
+  // with the frames (set 0: serial frames and standalone calls); a set is handed to frame f + 2*lanes once the
+  // HOST has seen frame f finish -- back-pressure on the caller instead of a barrier on a lane.
+  // Measured on config 3: one in-order stream 12.0 k frames/s; one stream per STAGE with three events per frame
+  // (round 1) 14.4 k; two lanes with the grid pass on the lane behind a cross-lane wait 16.5 k; two lanes as above
+  // 18.6 k in round 2, 23.5 k at the end of round 3; three lanes 24.7 k (the in-kernel timeline of the two-lane
+  // form shows the lanes in step, all of them between kernels at the same moments: profiles/r03/native_timeline.txt).
+  // Three lanes + public + copy are five streams on the four hardware queues a process gets by default; with
+  // GPU_MAX_HW_QUEUES=8 the same five streams run slower (57 us per frame against 40).  Independent HANDLES side by
+  // side (three or four grids, round 2: 15.4 / 14.3 k, tools/multi_handle.py) are a different thing: every grid
+  // pays its own grid pass.
+  static constexpr int kLanesMax = 3;              // three lanes by default, GV_LANES=2: two
+  static constexpr int kStreams = 1 + kLanesMax;   // public + lanes
+  static constexpr int kSets = 1 + 2 * kLanesMax;  // set 0: the serial frame; two sets per lane
   static constexpr int kRing = 8;   // event rings: one slot per frame, reused every 8 frames
+  int n_lanes = 3;
   int device = 0;
-  hipStream_t stream = nullptr, stream2 = nullptr, stream3 = nullptr, stream_copy = nullptr;
-  hipStream_t streams[3]{};         // = {stream (public), stream2 (lane 0), stream3 (lane 1)}
+  hipStream_t stream = nullptr, stream2 = nullptr, stream3 = nullptr, stream4 = nullptr, stream_copy = nullptr;
+  hipStream_t streams[kStreams]{};  // = {stream (public), stream2 (lane 0), stream3 (lane 1), stream4 (lane 2, GV_LANES=3)}
   hipEvent_t ev_sec[kRing]{};       // lane: partition, tile pass, sector stage of frame (slot) done
   hipEvent_t ev_fin[kRing]{};       // public stream: grid pass of frame (slot) done => that frame and every earlier one are done
   hipEvent_t ev_join = nullptr;     // copy stream -> public stream (gv_frame_fence)
-  uint64_t lane_frames = 0;         // lane frames enqueued so far: lane = n % 2, buffer set = 1 + n % 4
-  int set_fin_slot[kSets]{-1, -1, -1, -1, -1};   // ev_fin slot of the last frame that used the set
+  uint64_t lane_frames = 0;         // lane frames enqueued so far: lane = n % lanes, buffer set = 1 + n % (2 * lanes)
+  int set_fin_slot[kSets]{-1, -1, -1, -1, -1, -1, -1};   // ev_fin slot of the last frame that used the set
   int last_fin_slot = -1;           // ev_fin slot of the most recently enqueued frame (-1: idle)
   // per-set buffers of the frames in flight: end bitmaps, rectangles, free-cell bitmaps, ray statistics
   uint32_t *x_ends[kSets]{};      // one allocation per set: [hitN | clipN | hitT | clipT], ends_words in all
@@ -123,7 +129,7 @@ struct gv_context {
   float *log_odds = nullptr, *occupancy = nullptr;
   int8_t *occ_i8 = nullptr;
   // per-frame count grids
-  int32_t *hits_s[3]{};                     // per stream (public, lane 0, lane 1); tile path: every cell written by every BIN frame
+  int32_t *hits_s[kStreams]{};                     // per stream (public, lane 0, lane 1); tile path: every cell written by every BIN frame
   int32_t *hits = nullptr;                  // = hits_s[stream of the last frame]
   uint8_t *clip_end = nullptr;              // generic path only
   uint32_t *ray_list = nullptr;
@@ -140,7 +146,7 @@ struct gv_context {
   // sector kernel -- no wait, no upload, no table kernel -- the partition pass is launched without the barrier
   // bit (hipExtAnyOrderLaunch) and starts while the sector kernel's last workgroups still run.  lane_clean[k]:
   // the last packet on lane k is a sector kernel.  GV_ANYORDER=0 switches it off.
-  bool lane_clean[3] = {false, false, false};
+  bool lane_clean[kStreams] = {false, false, false, false};
   bool env_anyorder = true;
   size_t stat_slots = 1;                    // ray statistics slots written by the last frame
   int32_t env_log2s_oct[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // GV_LOG2S_OCT="a,b,..." per octant index (sweeps)
@@ -151,12 +157,12 @@ struct gv_context {
 
   // tile-path binning (gv_binning.hip)
   int32_t tiles_x = 0, tiles_y = 0, n_tiles = 0;
-  uint16_t *bin_keys[3]{}, *bin_tab[3]{};   // per stream: partition(f+1) of one lane runs beside tiles(f) of the other
+  uint16_t *bin_keys[kStreams]{}, *bin_tab[kStreams]{};   // per stream: partition(f+1) of one lane runs beside tiles(f) of the other
   size_t bin_keys_cap = 0, bin_tab_cap = 0;
-  uint32_t *bin_total[3][2]{};
-  uint32_t *bin_done[3]{}, *bin_scratch[3]{};
+  uint32_t *bin_total[kStreams][2]{};
+  uint32_t *bin_done[kStreams]{}, *bin_scratch[kStreams]{};
   size_t bin_slots = 0;
-  int bin_parity[3]{};
+  int bin_parity[kStreams]{};
 
   // resident clouds
   CloudSet cloud[3];
@@ -166,8 +172,8 @@ struct gv_context {
   size_t n = 0;
   float *tx = nullptr, *ty = nullptr, *tz = nullptr;   // transformed copy (A1 read-back)
   size_t tcap = 0;
-  int32_t *cell_idx_s[3]{};                 // per-point outputs, per stream (two frames in flight write them)
-  int16_t *bbox_id_s[3]{};
+  int32_t *cell_idx_s[kStreams]{};                 // per-point outputs, per stream (two frames in flight write them)
+  int16_t *bbox_id_s[kStreams]{};
   int32_t *cell_idx = nullptr;              // = *_s[stream of the last frame]
   int16_t *bbox_id = nullptr;
   size_t idx_cap = 0;
@@ -176,7 +182,7 @@ struct gv_context {
   DetSet det[3];
   int det_cur = 0;
   int32_t bt_tiles_x = 1, bt_tiles_y = 1;   // 16x16-pixel tiles of the image
-  VisionOut *d_vout_s[3]{};
+  VisionOut *d_vout_s[kStreams]{};
   VisionOut *d_vout = nullptr;              // = d_vout_s[0]
   int32_t vout_cap = 0;
   double *d_pts = nullptr;
@@ -261,6 +267,7 @@ int drain(gv_context *h)
   GV_HIP(hipStreamSynchronize(h->stream));
   GV_HIP(hipStreamSynchronize(h->stream2));
   GV_HIP(hipStreamSynchronize(h->stream3));
+  if (h->stream4) GV_HIP(hipStreamSynchronize(h->stream4));
   if (h->stream_x) GV_HIP(hipStreamSynchronize(h->stream_x));
   h->pipe_busy = false;
   h->last_fin_slot = -1;
@@ -303,7 +310,7 @@ void bin_needs(const gv_context *h, size_t n, size_t &keys_need, size_t &tab_nee
 // the sharded frame): a slice may pick a smaller chunk than the whole cloud and then needs MORE table rows
 int ensure_point_buffers(gv_context *h, size_t n, size_t n_slice = 0)
 {
-  const int nsets = sector_path(h) ? 3 : 1;   // per-stream copies
+  const int nsets = sector_path(h) ? 1 + h->n_lanes : 1;   // per-stream copies
   const bool need_idx = n > h->idx_cap || !h->cell_idx;
   size_t keys_need, tab_need;
   bin_needs(h, n, keys_need, tab_need);
@@ -435,7 +442,7 @@ int ensure_det_shared(gv_context *h, int32_t n)
   h->vout_cap = 0;
   for (int k = 0; k < gv_context::kSets; ++k)
     if ((rc = re(h->x_rects[k], (size_t)want * sizeof(Rect)))) return rc;
-  for (int k = 0; k < 3; ++k)
+  for (int k = 0; k < gv_context::kStreams; ++k)
     if ((rc = re(h->d_vout_s[k], (size_t)want * sizeof(VisionOut)))) return rc;
   h->d_vout = h->d_vout_s[0];
   if ((rc = re(h->d_pts, (size_t)want * 3 * sizeof(double)))) return rc;
@@ -836,8 +843,8 @@ int enqueue_frame_tiles(gv_context *h, bool pipelined, bool stage_events)
   const bool keep_cell = fl & GV_FRAME_KEEP_CELL_IDX;
   int rc = check_frame_flags(h, fl);
   if (rc) return rc;
-  const int p = pipelined ? 1 + (int)(h->lane_frames % 4u) : 0;
-  const int k = pipelined ? 1 + (int)(h->lane_frames % 2u) : 0;
+  const int p = pipelined ? 1 + (int)(h->lane_frames % (uint64_t)(2 * h->n_lanes)) : 0;
+  const int k = pipelined ? 1 + (int)(h->lane_frames % (uint64_t)h->n_lanes) : 0;
   hipStream_t s = h->streams[k];
   // back-pressure: the frame that last used this buffer set (four frames ago) has finished
   if (pipelined && h->set_fin_slot[p] >= 0) GV_HIP(hipEventSynchronize(h->ev_fin[h->set_fin_slot[p]]));
@@ -1313,9 +1320,12 @@ int gv_create(gv_handle *out, uint8_t grid_x, uint8_t grid_y, double resolution,
   GV_C(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
   GV_C(hipStreamCreateWithFlags(&h->stream3, hipStreamNonBlocking));
   GV_C(hipStreamCreateWithFlags(&h->stream_copy, hipStreamNonBlocking));
+  if (const char *e = std::getenv("GV_LANES")) h->n_lanes = (std::atoi(e) == 2) ? 2 : 3;
+  if (h->n_lanes == 3) GV_C(hipStreamCreateWithFlags(&h->stream4, hipStreamNonBlocking));
   h->streams[0] = h->stream;
   h->streams[1] = h->stream2;
   h->streams[2] = h->stream3;
+  h->streams[3] = h->stream4;
   // Ordering-only events between queues of this device (and a completion flag the host polls): nobody reads
   // memory on the strength of them -- results are read in stream order on the public stream or after a
   // stream synchronise -- so the kernels that carry them need no system-scope release at their end.
@@ -1383,7 +1393,7 @@ int gv_create(gv_handle *out, uint8_t grid_x, uint8_t grid_y, double resolution,
   }
   const bool sectors = h->tile_path && !h->force_simple;
   const int nsets_alloc = sectors ? gv_context::kSets : 1;
-  for (int k = 0; k < (sectors ? 3 : 1); ++k) {
+  for (int k = 0; k < (sectors ? 1 + h->n_lanes : 1); ++k) {
     GV_C(hipMalloc(reinterpret_cast<void **>(&h->hits_s[k]), G * sizeof(int32_t)));
     GV_C(hipMemsetAsync(h->hits_s[k], 0, G * sizeof(int32_t), h->stream));
   }
@@ -1417,7 +1427,7 @@ int gv_create(gv_handle *out, uint8_t grid_x, uint8_t grid_y, double resolution,
       h->x_freeN[k] = h->x_free[k];
       h->x_freeT[k] = h->x_free[k] + h->bmN_words;
     }
-    for (int q = 0; q < 3; ++q) {
+    for (int q = 0; q < 1 + h->n_lanes; ++q) {
       for (int k = 0; k < 2; ++k) {
         GV_C(hipMalloc(reinterpret_cast<void **>(&h->bin_total[q][k]), (size_t)h->n_tiles * sizeof(uint32_t)));
         GV_C(hipMemsetAsync(h->bin_total[q][k], 0, (size_t)h->n_tiles * sizeof(uint32_t), h->stream));
@@ -1452,7 +1462,7 @@ int gv_destroy(gv_handle h)
 {
   if (!h) return GV_ERR_BAD_ARG;
   (void)hipSetDevice(h->device);
-  for (hipStream_t s : {h->stream_copy, h->stream, h->stream2, h->stream3, h->stream_x})
+  for (hipStream_t s : {h->stream_copy, h->stream, h->stream2, h->stream3, h->stream4, h->stream_x})
     if (s) (void)hipStreamSynchronize(s);
   if (h->comm) { ncclCommDestroy(h->comm); h->comm = nullptr; }
   for (auto &row : h->ev_sh)
@@ -1477,7 +1487,7 @@ int gv_destroy(gv_handle h)
     for (void *p : xs)
       if (p) (void)hipFree(p);
   }
-  for (int k = 0; k < 3; ++k) {
+  for (int k = 0; k < gv_context::kStreams; ++k) {
     void *xs[] = {h->hits_s[k], h->cell_idx_s[k], h->bbox_id_s[k], h->d_vout_s[k], h->bin_keys[k], h->bin_tab[k],
                   h->bin_total[k][0], h->bin_total[k][1], h->bin_done[k], h->bin_scratch[k]};
     for (void *p : xs)
@@ -1504,7 +1514,7 @@ int gv_destroy(gv_handle h)
   for (auto &e : h->ev_sec)
     if (e) (void)hipEventDestroy(e);
   if (h->ev_join) (void)hipEventDestroy(h->ev_join);
-  for (hipStream_t s : {h->stream3, h->stream2, h->stream_copy, h->stream})
+  for (hipStream_t s : {h->stream4, h->stream3, h->stream2, h->stream_copy, h->stream})
     if (s) (void)hipStreamDestroy(s);
   delete h;
   return GV_OK;
@@ -1676,7 +1686,7 @@ int set_detections(gv_context *h, const gv_frame_desc *d)
   // reader, which completes after every earlier frame.
   const int target = h->det_cur ^ 1;
   DetSet &D = h->det[target];
-  const int k = (sector_path(h) && !h->no_pipeline) ? 1 + (int)(h->lane_frames % 2u) : 0;
+  const int k = (sector_path(h) && !h->no_pipeline) ? 1 + (int)(h->lane_frames % (uint64_t)h->n_lanes) : 0;
   hipStream_t s = h->streams[k];
   h->lane_clean[k] = false;   // the upload and the table kernels go on this stream, in front of the frame's partition pass
   if (D.release_slot >= 0 && D.readers != (1u << k)) GV_HIP(hipStreamWaitEvent(s, h->ev_fin[D.release_slot], 0));

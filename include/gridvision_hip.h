@@ -273,11 +273,11 @@ typedef struct {
 int gv_frame_set_detections(gv_handle h, const gv_frame_desc *desc);
 int gv_frame_set_detections_async(gv_handle h, const gv_frame_desc *desc);
 /* Enqueue one frame using the resident cloud and the last detections set (asynchronous).
- * GV_ERR_STATE before the first gv_frame_set_detections.  Two frames run side by side: binning and
- * ray stage of frame f on internal stream f % 2, its grid pass on gv_stream(h) behind them, so the
- * grid passes -- and anything the caller puts on gv_stream(h) between two frames -- execute in
- * enqueue order and see every result of the frames before them.  At most FOUR frames are in flight:
- * the call waits on the host for the frame four back when the caller runs further ahead. */
+ * GV_ERR_STATE before the first gv_frame_set_detections.  Three frames run side by side (GV_LANES=2: two):
+ * binning and ray stage of frame f on internal stream f % 3, its grid pass on gv_stream(h) behind them, so
+ * the grid passes -- and anything the caller puts on gv_stream(h) between two frames -- execute in
+ * enqueue order and see every result of the frames before them.  At most SIX frames are in flight (four
+ * with two lanes): the call waits on the host for the frame six back when the caller runs further ahead. */
 int gv_frame_enqueue(gv_handle h);
 /* Make gv_stream(h) wait (on the device, not the host) for every upload enqueued so far as well
  * (frames are ordered on gv_stream(h) by construction): afterwards an event recorded or a kernel
@@ -336,7 +336,7 @@ int gv_comm_unique_id(uint8_t id_out[128]);
 int gv_comm_init(gv_handle h, const uint8_t id[128], int32_t rank, int32_t world);
 int gv_comm_destroy(gv_handle h);
 /* Sharded frame, asynchronous: the counterpart of gv_frame_enqueue (same detection sets, same back-pressure of
- * four frames in flight, results on the public stream behind it) for a resident cloud that is this rank's
+ * four frames in flight on two lanes, results on the public stream behind it) for a resident cloud that is this rank's
  * slice.  Binning, sector share and band packing run on the frame's lane, the RCCL exchanges on the handle's
  * exchange stream, the band's grid pass on the public stream: frame f's exchanges overlap frame f+1's binning.
  * Collective: every rank of the communicator must enqueue the same sequence of frames. */

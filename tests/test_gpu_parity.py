@@ -1761,7 +1761,8 @@ def test_sector_tail_policies_agree(gvamd, monkeypatch, grid, n):
         assert np.array_equal(got, want), (fd, ml, fk, int(np.count_nonzero(got != want)))
 
 
-def test_partition_overtakes_sector_tail(gvamd, monkeypatch):
+@pytest.mark.parametrize("lanes", ["3", "2"])
+def test_partition_overtakes_sector_tail(gvamd, monkeypatch, lanes):
     """With unchanged inputs the partition pass of frame f + 2 is launched without the barrier bit and starts while
     the sector kernel of frame f (same lane, other buffers) still runs.  Config-3 size so that the kernels really
     overlap: a run of frames on one cloud, new detections in the middle (their upload goes on a lane: those frames
@@ -1774,6 +1775,7 @@ def test_partition_overtakes_sector_tail(gvamd, monkeypatch):
     dets = [(synth.detections(config), synth.lshape_poses(config)), (synth.detections(config, seed_extra=1), synth.lshape_poses(config, seed_extra=1))]
     plan = [(0, 0, 7), (0, 1, 5), (1, 1, 6), (1, 0, 1), (0, 0, 4)]   # (cloud, detection set, frames)
     layers = {}
+    monkeypatch.setenv("GV_LANES", lanes)
     for mode in ("1", "0"):
         monkeypatch.setenv("GV_ANYORDER", mode)
         h, tfs = make_handle(gvamd, config, True)
@@ -1802,13 +1804,14 @@ def test_partition_overtakes_sector_tail(gvamd, monkeypatch):
         assert np.array_equal(a, b)
 
 
-@pytest.mark.parametrize("seed", [11, 29])
-def test_random_call_sequences_with_frames_in_flight(gvamd, seed):
+@pytest.mark.parametrize("seed,lanes", [(11, "3"), (29, "3"), (29, "2")])
+def test_random_call_sequences_with_frames_in_flight(gvamd, monkeypatch, seed, lanes):
     """A caller that does things in no particular order: runs of frames on unchanged inputs (their partition passes
     start inside the previous sector kernel), new clouds through the asynchronous upload, new detections through
     the asynchronous form, both at once, host waits at random points.  300 k points on a 1200 x 1200 grid: long
     enough kernels for real overlap, short enough for ~60 oracle frames.  Whatever the interleaving, the grid
     after every wait equals the oracle's and the last frame's per-point outputs are that frame's."""
+    monkeypatch.setenv("GV_LANES", lanes)
     gx, gy, res = 240, 240, 0.2
     n = 300_000
     rng = np.random.default_rng(seed)
