@@ -13,6 +13,7 @@ from gvamd import synth
 
 config = 3
 frames = next((int(a) for a in sys.argv[1:] if a.isdigit()), 600)
+lanes = 2 if os.environ.get("GV_LANES") == "2" else 3
 g = synth.CONFIGS[config]["grid"]
 tfs = synth.transforms(True)
 x, y, z, _ = (synth.cloud_lidar_like if "lidar" in sys.argv else synth.cloud_uniform)(config)
@@ -37,16 +38,16 @@ t = buf[idx].astype(np.float64) * 0.01   # us (100 MHz)
 t -= t[0, 0, 0]
 names = ["partition", "tiles", "sectors", "grid pass"]
 inner = slice(20, frames - 20)
-print(f"{frames} frames, native; period per frame {((t[frames - 21, 3, 1] - t[20, 3, 1]) / (frames - 41)):.1f} us")
+print(f"{frames} frames, {lanes} lanes, native (diagnostic build: a few % slower than the shipped one); period per frame {((t[frames - 21, 3, 1] - t[20, 3, 1]) / (frames - 41)):.1f} us")
 for k, nme in enumerate(names):
     d = t[inner, k, 1] - t[inner, k, 0]
     print(f"  {nme:10s} on the device: mean {d.mean():5.1f}  p10 {np.percentile(d, 10):5.1f}  p90 {np.percentile(d, 90):5.1f} us")
 gap_pt = t[inner, 1, 0] - t[inner, 0, 1]
 gap_ts = t[inner, 2, 0] - t[inner, 1, 1]
 gap_sf = t[inner, 3, 0] - t[inner, 2, 1]
-ov = t[22:frames - 20, 0, 0] - t[20:frames - 22, 2, 1]    # partition(f+2) start minus sectors(f) end: negative = overlap
+ov = t[20 + lanes:frames - 20, 0, 0] - t[20:frames - 20 - lanes, 2, 1]    # partition(f + lanes) start minus sectors(f) end: negative = overlap
 print(f"  gaps: partition -> tiles {gap_pt.mean():.1f}, tiles -> sectors {gap_ts.mean():.1f}, sectors -> grid pass {gap_sf.mean():.1f} us; "
-      f"partition(f+2) starts {(-ov).mean():.1f} us before sectors(f) ends (same lane)")
+      f"partition(f+{lanes}) starts {(-ov).mean():.1f} us before sectors(f) ends (same lane; end = last of every eighth workgroup)")
 lat = t[inner, 3, 1] - t[inner, 0, 0]
 print(f"  frame latency first partition workgroup -> last grid-pass workgroup: mean {lat.mean():.1f} us")
 # kernels resident over time
@@ -61,11 +62,11 @@ for tt, dlt in ev:
     last, cur = tt, cur + dlt
 tot = sum(res.values())
 print("  kernels resident: " + ", ".join(f"{k}: {100 * v / tot:.0f} %" for k, v in sorted(res.items())))
-print("  excerpt (us; lane = frame % 2):")
+print(f"  excerpt (us; lane = frame % {lanes}):")
 rows = []
 for f in range(100, 108):
     for k in range(4):
         rows.append((t[f, k, 0], t[f, k, 1], f, k))
 for a, b, f, k in sorted(rows):
-    print(f"    {a - t[100, 0, 0]:8.1f} .. {b - t[100, 0, 0]:8.1f}  frame {f} lane {f % 2}  {names[k]}")
+    print(f"    {a - t[100, 0, 0]:8.1f} .. {b - t[100, 0, 0]:8.1f}  frame {f} lane {f % lanes}  {names[k]}")
 h.close()
