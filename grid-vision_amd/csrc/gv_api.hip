@@ -80,6 +80,13 @@ struct gv_context {
   static constexpr int kSets = 1 + 2 * kLanesMax;  // set 0: the serial frame; two sets per lane
   static constexpr int kRing = 8;   // event rings: one slot per frame, reused every 8 frames
   int n_lanes = 3;
+  // The third lane runs on the UPLOAD stream (public + two lanes + uploads are the four hardware queues a process
+  // gets; a fifth stream shares one of them with whatever the runtime picks, and when that is the upload stream the
+  // streamed frame drops to 0.8 of the copy rate).  It is used only while the upload stream is quiet: no cloud
+  // upload for kQuietFrames frames.  With a cloud per frame the library runs on two lanes, as in round 2.
+  static constexpr uint32_t kQuietFrames = 8;
+  uint32_t quiet_frames = 0;        // frames enqueued since the last cloud upload
+  int lanes_now() const { return (n_lanes == 3 && quiet_frames >= kQuietFrames) ? 3 : 2; }
   int device = 0;
   hipStream_t stream = nullptr, stream2 = nullptr, stream3 = nullptr, stream4 = nullptr, stream_copy = nullptr;
   hipStream_t streams[kStreams]{};  // = {stream (public), stream2 (lane 0), stream3 (lane 1), stream4 (lane 2, GV_LANES=3)}
@@ -844,7 +851,7 @@ int enqueue_frame_tiles(gv_context *h, bool pipelined, bool stage_events)
   int rc = check_frame_flags(h, fl);
   if (rc) return rc;
   const int p = pipelined ? 1 + (int)(h->lane_frames % (uint64_t)(2 * h->n_lanes)) : 0;
-  const int k = pipelined ? 1 + (int)(h->lane_frames % (uint64_t)h->n_lanes) : 0;
+  const int k = pipelined ? 1 + (int)(h->lane_frames % (uint64_t)h->lanes_now()) : 0;
   hipStream_t s = h->streams[k];
   // back-pressure: the frame that last used this buffer set (four frames ago) has finished
   if (pipelined && h->set_fin_slot[p] >= 0) GV_HIP(hipEventSynchronize(h->ev_fin[h->set_fin_slot[p]]));
@@ -953,6 +960,7 @@ int enqueue_frame_tiles(gv_context *h, bool pipelined, bool stage_events)
   if (pipelined) {
     h->lane_frames++;
     h->pipe_busy = true;
+    if (h->quiet_frames < 0x7fffffffu) h->quiet_frames++;
   }
   h->have_hits = do_bin;
   h->have_miss = do_bin;   // the free-cell bitmaps of set p stay until the set's next frame
@@ -1321,11 +1329,12 @@ int gv_create(gv_handle *out, uint8_t grid_x, uint8_t grid_y, double resolution,
   GV_C(hipStreamCreateWithFlags(&h->stream3, hipStreamNonBlocking));
   GV_C(hipStreamCreateWithFlags(&h->stream_copy, hipStreamNonBlocking));
   if (const char *e = std::getenv("GV_LANES")) h->n_lanes = (std::atoi(e) == 2) ? 2 : 3;
-  if (h->n_lanes == 3) GV_C(hipStreamCreateWithFlags(&h->stream4, hipStreamNonBlocking));
+  // (GV_LANE3_OWN_STREAM=1, experiment: the third lane on a fifth stream instead of the upload stream)
+  if (h->n_lanes == 3 && std::getenv("GV_LANE3_OWN_STREAM")) GV_C(hipStreamCreateWithFlags(&h->stream4, hipStreamNonBlocking));
   h->streams[0] = h->stream;
   h->streams[1] = h->stream2;
   h->streams[2] = h->stream3;
-  h->streams[3] = h->stream4;
+  h->streams[3] = h->stream4 ? h->stream4 : h->stream_copy;
   // Ordering-only events between queues of this device (and a completion flag the host polls): nobody reads
   // memory on the strength of them -- results are read in stream order on the public stream or after a
   // stream synchronise -- so the kernels that carry them need no system-scope release at their end.
@@ -1586,6 +1595,7 @@ int begin_cloud_upload(gv_context *h, size_t n, int &target)
   if (rc) return rc;
   if ((rc = ensure_point_buffers(h, n))) return rc;
   target = (h->cloud_cur + 1) % 3;
+  h->quiet_frames = 0;   // the upload stream is in use: the frames stay off it for a while
   CloudSet &c = h->cloud[target];
   if (n > c.cap) {
     if (c.release_slot >= 0) GV_HIP(hipEventSynchronize(h->ev_fin[c.release_slot]));
@@ -1686,7 +1696,7 @@ int set_detections(gv_context *h, const gv_frame_desc *d)
   // reader, which completes after every earlier frame.
   const int target = h->det_cur ^ 1;
   DetSet &D = h->det[target];
-  const int k = (sector_path(h) && !h->no_pipeline) ? 1 + (int)(h->lane_frames % (uint64_t)h->n_lanes) : 0;
+  const int k = (sector_path(h) && !h->no_pipeline) ? 1 + (int)(h->lane_frames % (uint64_t)h->lanes_now()) : 0;
   hipStream_t s = h->streams[k];
   h->lane_clean[k] = false;   // the upload and the table kernels go on this stream, in front of the frame's partition pass
   if (D.release_slot >= 0 && D.readers != (1u << k)) GV_HIP(hipStreamWaitEvent(s, h->ev_fin[D.release_slot], 0));

@@ -273,8 +273,9 @@ typedef struct {
 int gv_frame_set_detections(gv_handle h, const gv_frame_desc *desc);
 int gv_frame_set_detections_async(gv_handle h, const gv_frame_desc *desc);
 /* Enqueue one frame using the resident cloud and the last detections set (asynchronous).
- * GV_ERR_STATE before the first gv_frame_set_detections.  Three frames run side by side (GV_LANES=2: two):
- * binning and ray stage of frame f on internal stream f % 3, its grid pass on gv_stream(h) behind them, so
+ * GV_ERR_STATE before the first gv_frame_set_detections.  Two or three frames run side by side (the third lane is
+ * the upload stream while no cloud has been uploaded for a while; GV_LANES=2: never): binning and ray stage of
+ * frame f on an internal stream, its grid pass on gv_stream(h) behind them, so
  * the grid passes -- and anything the caller puts on gv_stream(h) between two frames -- execute in
  * enqueue order and see every result of the frames before them.  At most SIX frames are in flight (four
  * with two lanes): the call waits on the host for the frame six back when the caller runs further ahead. */
