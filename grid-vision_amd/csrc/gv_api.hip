@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -80,6 +81,8 @@ struct gv_context {
   static constexpr int kSets = 1 + 2 * kLanesMax;  // set 0: the serial frame; two sets per lane
   static constexpr int kRing = 8;   // event rings: one slot per frame, reused every 8 frames
   int n_lanes = 3;
+  int upload_stream_retries = 0;    // gv_create: upload streams replaced because they shared a hardware queue
+  double upload_probe_us = 0.0;     // the last probe's wait
   // The third lane runs on the UPLOAD stream (public + two lanes + uploads are the four hardware queues a process
   // gets; a fifth stream shares one of them with whatever the runtime picks, and when that is the upload stream the
   // streamed frame drops to 0.8 of the copy rate).  It is used only while the upload stream is quiet: no cloud
@@ -1331,6 +1334,37 @@ int gv_create(gv_handle *out, uint8_t grid_x, uint8_t grid_y, double resolution,
   if (const char *e = std::getenv("GV_LANES")) h->n_lanes = (std::atoi(e) == 2) ? 2 : 3;
   // (GV_LANE3_OWN_STREAM=1, experiment: the third lane on a fifth stream instead of the upload stream)
   if (h->n_lanes == 3 && std::getenv("GV_LANE3_OWN_STREAM")) GV_C(hipStreamCreateWithFlags(&h->stream4, hipStreamNonBlocking));
+  // The upload stream must not share a hardware queue with the public stream or a lane (a process gets four
+  // queues; a stream created when four exist joins the one with the fewest streams, ties by address -- e.g. a host
+  // application or framework that owns a stream already pushes one of ours onto a shared queue, and when that is
+  // the upload stream every cloud waits behind kernels: the 0.55-0.8-of-copy-rate regime of profiles/r03/h2d_notes.md).
+  // Probe: hold the three compute streams busy for 150 us each, time a 4-byte memset on the upload stream; if it had
+  // to wait, make another upload stream (before letting go of this one, so that it lands elsewhere) and try again.
+  if (!(std::getenv("GV_QUEUE_PROBE") && std::atoi(std::getenv("GV_QUEUE_PROBE")) == 0)) {
+    unsigned *probe = nullptr;
+    GV_C(hipMalloc(reinterpret_cast<void **>(&probe), 256));
+    std::vector<hipStream_t> rejected;
+    for (int attempt = 0; attempt < 6; ++attempt) {
+      GV_C(hipDeviceSynchronize());
+      for (hipStream_t q : {h->stream, h->stream2, h->stream3}) launch_hold(15000ull, q);   // 150 us at 100 MHz
+      const auto t0 = std::chrono::steady_clock::now();
+      GV_C(hipMemsetAsync(probe, 0, 4, h->stream_copy));
+      GV_C(hipStreamSynchronize(h->stream_copy));
+      const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+      GV_C(hipDeviceSynchronize());
+      h->upload_probe_us = us;
+      if (us < 90.0) break;
+      h->upload_stream_retries++;
+      hipStream_t nw = nullptr;
+      GV_C(hipStreamCreateWithFlags(&nw, hipStreamNonBlocking));
+      rejected.push_back(h->stream_copy);
+      h->stream_copy = nw;
+    }
+    for (hipStream_t q : rejected) (void)hipStreamDestroy(q);
+    (void)hipFree(probe);
+    if (std::getenv("GV_VERBOSE"))
+      std::fprintf(stderr, "gridvision_hip: upload stream probe %.0f us, %d replacement(s)\n", h->upload_probe_us, h->upload_stream_retries);
+  }
   h->streams[0] = h->stream;
   h->streams[1] = h->stream2;
   h->streams[2] = h->stream3;

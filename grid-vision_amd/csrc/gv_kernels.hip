@@ -814,6 +814,24 @@ void launch_fill_f32(float *p, float v, size_t n, hipStream_t s)
   hipLaunchKernelGGL(k_fill_f32, dim3(blocks), dim3(256), 0, s, p, v, n);
 }
 
+// one wavefront that stays on the device for `ticks` of the constant-rate clock (100 MHz): the queue probe of
+// gv_create (is the upload stream's hardware queue shared with a busy stream?)
+__global__ void k_hold(unsigned long long ticks, unsigned *sink)
+{
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  unsigned n = 0;
+  while ((unsigned long long)__builtin_amdgcn_s_memrealtime() - t0 < ticks) {
+    __builtin_amdgcn_s_sleep(32);
+    ++n;
+  }
+  if (sink && n == 0xFFFFFFFFu) *sink = n;
+}
+
+void launch_hold(unsigned long long ticks, hipStream_t s)
+{
+  hipLaunchKernelGGL(k_hold, dim3(1), dim3(64), 0, s, ticks, (unsigned *)nullptr);
+}
+
 __global__ void k_i16_to_i32(const int16_t *in, int32_t *out, size_t n)
 {
   const size_t stride = (size_t)gridDim.x * blockDim.x;

@@ -89,6 +89,7 @@ struct FinalizeArgs {
 void launch_finalize(const FinalizeArgs &a, hipStream_t s);
 
 void launch_fill_f32(float *p, float v, size_t n, hipStream_t s);
+void launch_hold(unsigned long long ticks_100mhz, hipStream_t s);   // one idle wavefront for that long (queue probe)
 void launch_u8_to_i32(const uint8_t *in, int32_t *out, size_t n, hipStream_t s);
 void launch_i16_to_i32(const int16_t *in, int32_t *out, size_t n, hipStream_t s);
 
