@@ -1915,3 +1915,47 @@ def test_sector_bucket_rows_overflow_on_shared_slopes(gvamd, extra):
     assert np.array_equal(h.hits(), hits)
     assert np.array_equal(h.miss(), miss.astype(np.int32)), int(np.count_nonzero(h.miss() != miss))
     h.close()
+
+
+@pytest.mark.parametrize("extra", [0, 1, 2])
+def test_upload_stream_gets_a_queue_of_its_own(gvamd, monkeypatch, capfd, extra):
+    """A process gets four hardware queues; with other streams alive (what a host application or a framework owns) one
+    of the handle's four streams has to share, and when that is the upload stream every cloud waits behind kernels
+    (profiles/r03/h2d_notes.md 6).  gv_create probes for it and replaces the upload stream until a 4-byte memset no
+    longer waits for the compute streams; GV_VERBOSE prints the last probe.  The streamed frames stay correct."""
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    others = []
+    for _ in range(extra):
+        s = C.c_void_p()
+        assert hip.hipStreamCreateWithFlags(C.byref(s), 1) == 0
+        others.append(s)
+    monkeypatch.setenv("GV_VERBOSE", "1")
+    config = 2
+    g = synth.CONFIGS[config]["grid"]
+    h, tfs = make_handle(gvamd, config, perturbed=False)
+    err = capfd.readouterr().err
+    line = [l for l in err.splitlines() if "upload stream probe" in l]
+    assert line, err
+    waited_us = float(line[-1].split("probe")[1].split("us")[0])
+    assert waited_us < 90.0, line[-1]          # the idle kernels on the compute streams last 150 us
+    og = ol.OGrid(g.grid_x, g.grid_y, g.resolution)
+    x, y, z, _ = synth.cloud_uniform(config, 50_000)
+    pins = [gvamd.PinnedF32(len(x)) for _ in range(3)]
+    for p, a in zip(pins, (x, y, z)):
+        p.array[:] = a
+    flags = gvamd.FRAME_BIN | gvamd.FRAME_RAYMARCH
+    h.set_detections(flags)
+    for _ in range(5):
+        h.upload_xyz_async(pins[0].array, pins[1].array, pins[2].array)
+        h.enqueue_frame()
+    h.synchronize()
+    for _ in range(5):
+        hits, _, miss, _, _ = oracle_frame(og, tfs, x, y, z)
+    assert np.array_equal(h.hits(), hits) and np.array_equal(h.miss(), miss)
+    assert check_grid(h, og)[0] == 0
+    h.close()
+    for p in pins:
+        p.close()
+    for s in others:
+        hip.hipStreamDestroy(s)
