@@ -1344,6 +1344,7 @@ int gv_create(gv_handle *out, uint8_t grid_x, uint8_t grid_y, double resolution,
     unsigned *probe = nullptr;
     GV_C(hipMalloc(reinterpret_cast<void **>(&probe), 256));
     std::vector<hipStream_t> rejected;
+    launch_hold(1ull, h->stream);   // (the kernel's code object is loaded before anything is timed)
     for (int attempt = 0; attempt < 6; ++attempt) {
       GV_C(hipDeviceSynchronize());
       for (hipStream_t q : {h->stream, h->stream2, h->stream3}) launch_hold(15000ull, q);   // 150 us at 100 MHz
