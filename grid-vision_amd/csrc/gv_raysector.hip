@@ -1063,12 +1063,16 @@ __device__ __forceinline__ float cell_update_t(float l, int k, bool counts, bool
 // hit and free-space flags come from the bitmaps (N: one word per 32 cells of a row; T: bits run
 // along y, a thread's four cells are four consecutive words = one 16-byte load).  Nothing is cleared
 // here: the binning tile pass rewrites / zeroes every bitmap word of the set it is about to use.
+#ifndef GV_FIN_ROWS
+#define GV_FIN_ROWS 64
+#endif
 template <bool COUNTS>
 __global__ void __launch_bounds__(256) k_finalize_tiles(FinalizeTileArgs a)
 {
   __shared__ Rect s_rects[64];
   __shared__ int s_nr;
-  const int x0 = blockIdx.x * 64, y0 = a.y_begin + blockIdx.y * 64;
+  constexpr int kRows = GV_FIN_ROWS;   // rows of the grid per workgroup (64 cells wide): 16 per pass
+  const int x0 = blockIdx.x * 64, y0 = a.y_begin + blockIdx.y * kRows;
   const int tid = threadIdx.x;
   GV_TL_BEGIN(a.tl);
   if (tid == 0) s_nr = 0;
@@ -1077,7 +1081,7 @@ __global__ void __launch_bounds__(256) k_finalize_tiles(FinalizeTileArgs a)
   // all adds are the same constant, so the count is what matters)
   for (int r = tid; r < a.n_rects; r += 256) {
     const Rect R = a.rects[r];
-    if (R.valid && R.y1 >= y0 && R.y0 <= y0 + 63 && R.x1 >= x0 && R.x0 <= x0 + 63) {
+    if (R.valid && R.y1 >= y0 && R.y0 <= y0 + kRows - 1 && R.x1 >= x0 && R.x0 <= x0 + 63) {
       const int k = atomicAdd(&s_nr, 1);
       if (k < 64) s_rects[k] = R;
     }
@@ -1088,7 +1092,7 @@ __global__ void __launch_bounds__(256) k_finalize_tiles(FinalizeTileArgs a)
   const int xq = tid & 15;        // which float4 of the row
   const int x = x0 + xq * 4;
 #pragma unroll
-  for (int pass = 0; pass < 4; ++pass) {
+  for (int pass = 0; pass < kRows / 16; ++pass) {
     const int yl = pass * 16 + (tid >> 4);
     const int y = y0 + yl;
     if (x >= a.g.nx || y >= a.y_end) continue;
@@ -1148,7 +1152,7 @@ bool launch_finalize_tiles(const FinalizeTileArgs &a, hipStream_t s, hipEvent_t 
 {
   const int rows = a.y_end - a.y_begin;
   if (rows <= 0) return false;
-  const dim3 grid((a.g.nx + 63) / 64, (rows + 63) / 64);
+  const dim3 grid((a.g.nx + 63) / 64, (rows + GV_FIN_ROWS - 1) / GV_FIN_ROWS);
   if (a.counts) hipExtLaunchKernelGGL(k_finalize_tiles<true>, grid, dim3(256), 0, s, t0, done, 0, a);
   else hipExtLaunchKernelGGL(k_finalize_tiles<false>, grid, dim3(256), 0, s, t0, done, 0, a);
   return true;
