@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -199,7 +201,6 @@ struct gv_context {
   int32_t pts_cap = 0;
   // kNN depth / PCA pose scratch
   Cand2 *knn_partial = nullptr; size_t knn_partial_cap = 0;
-  float *d_depths = nullptr, *d_knn_d2 = nullptr; size_t knn_out_cap = 0;
   int32_t *d_segstart = nullptr; size_t segstart_cap = 0;
   float *gx = nullptr, *gy = nullptr, *gz = nullptr; size_t gcap = 0;   // kept points by bbox, cloud order
   CellNode *d_nodes = nullptr; uint8_t *d_drop = nullptr; size_t pc_cap = 0;   // per point: cell-list node, filtered-out flag
@@ -210,7 +211,11 @@ struct gv_context {
   double *d_rscratch = nullptr; size_t rscratch_cap = 0;   // tree-sum partials of the plane refinement
   RansacState *d_rstate = nullptr;
   uint32_t *d_blockcnt = nullptr; size_t blockcnt_cap = 0;   // per (1024-point block, bbox) counts of the kept-point split
-  uint8_t *d_pose_out = nullptr; size_t pose_out_cap = 0;   // one read-back block: nb poses | RansacState | nb valid flags
+  // result block of the synchronous kNN / RANSAC / PCA calls: pinned and device-mapped, written by the call's last
+  // kernel; [0] = the sequence number of the last finished call (CallDone, gv_kernels.hpp), payload from byte 64
+  uint8_t *res_host = nullptr; size_t res_cap = 0;
+  unsigned *d_res_ticket = nullptr;
+  unsigned res_seq = 0;
 
   bool counts_dirty = false;   // generic path: hits/miss/clip_end hold a kept frame
   bool have_hits = false, have_miss = false, have_cell_idx = false, have_bbox_id = false;
@@ -1516,11 +1521,12 @@ int gv_destroy(gv_handle h)
     if (e) (void)hipEventDestroy(e);
   if (h->stream_x) (void)hipStreamDestroy(h->stream_x);
   void *bufs[] = {h->log_odds, h->occupancy, h->occ_i8, h->clip_end, h->miss8, h->sh_xchg, h->ray_list, h->ray_count, h->scratch_i32,
-                  h->tx, h->ty, h->tz, h->d_pts, h->knn_partial, h->d_depths,
-                  h->d_knn_d2, h->d_segstart, h->gx, h->gy, h->gz, h->d_nodes, h->d_drop, h->d_cellcnt, h->d_cellpre, h->d_celloff, h->d_planes,
-                  h->d_plane_counts, h->d_ground, h->d_rscratch, h->d_rstate, h->d_blockcnt, h->d_pose_out};
+                  h->tx, h->ty, h->tz, h->d_pts, h->knn_partial,
+                  h->d_segstart, h->gx, h->gy, h->gz, h->d_nodes, h->d_drop, h->d_cellcnt, h->d_cellpre, h->d_celloff, h->d_planes,
+                  h->d_plane_counts, h->d_ground, h->d_rscratch, h->d_rstate, h->d_blockcnt, h->d_res_ticket};
   for (void *p : bufs)
     if (p) (void)hipFree(p);
+  if (h->res_host) (void)hipHostFree(h->res_host);
 #ifdef GV_DIAG
   if (h->d_dbg) (void)hipFree(h->d_dbg);
   if (h->d_tl) (void)hipFree(h->d_tl);
@@ -2353,6 +2359,52 @@ static int ensure_tbuf(gv_context *h, size_t n)
   return GV_OK;
 }
 
+// ---- the result block (see gv_context::res_host) ----
+constexpr size_t kResHeader = 64;
+
+// a block with room for `bytes` of payload; the CallDone of the call about to be enqueued
+static int begin_result(gv_context *h, size_t bytes, CallDone &done)
+{
+  if (bytes + kResHeader > h->res_cap) {
+    GV_HIP(hipStreamSynchronize(h->stream));   // nothing in flight writes the old block
+    if (h->res_host) { GV_HIP(hipHostFree(h->res_host)); h->res_host = nullptr; }
+    h->res_cap = 0;
+    const size_t want = std::max<size_t>(2 * (bytes + kResHeader), 16384);
+    GV_HIP(hipHostMalloc(reinterpret_cast<void **>(&h->res_host), want, hipHostMallocDefault));
+    std::memset(h->res_host, 0, want);
+    h->res_cap = want;
+  }
+  if (!h->d_res_ticket) {
+    GV_HIP(hipMalloc(reinterpret_cast<void **>(&h->d_res_ticket), 64));
+    GV_HIP(hipMemsetAsync(h->d_res_ticket, 0, 64, h->stream));
+  }
+  if (++h->res_seq == 0u) h->res_seq = 1u;   // 0 = "nothing published yet"
+  done.ticket = h->d_res_ticket;
+  done.flag = reinterpret_cast<unsigned *>(h->res_host);
+  done.seq = h->res_seq;
+  return GV_OK;
+}
+
+// Host side of CallDone: spin on the block's first word.  The stream is looked at now and then so that a call
+// whose kernels failed ends in an error instead of a hang.
+static int wait_result(gv_context *h)
+{
+  volatile unsigned *flag = reinterpret_cast<volatile unsigned *>(h->res_host);
+  const unsigned seq = h->res_seq;
+  for (unsigned spins = 1;; ++spins) {
+    if (*flag == seq) break;
+    if ((spins & 0xfffu) == 0u) {
+      const hipError_t q = hipStreamQuery(h->stream);
+      if (q == hipErrorNotReady) continue;
+      if (q == hipSuccess && *flag == seq) break;
+      h->err = q == hipSuccess ? "result block never published" : hipGetErrorString(q);
+      return GV_ERR_HIP;
+    }
+  }
+  std::atomic_thread_fence(std::memory_order_acquire);
+  return GV_OK;
+}
+
 int gv_compute_depth_for_bboxes(gv_handle h, const gv_bbox *bboxes, int32_t nb, int32_t k, float *depths,
                                 float *knn_d2)
 {
@@ -2365,23 +2417,18 @@ int gv_compute_depth_for_bboxes(gv_handle h, const gv_bbox *bboxes, int32_t nb, 
   if ((rc = upload_scratch_bboxes(h, bboxes, nb))) return rc;
   if ((rc = ensure_tbuf(h, std::max<size_t>(h->n, 1)))) return rc;
   if ((rc = grow(h, h->knn_partial, h->knn_partial_cap, knn_partial_entries(nb, k)))) return rc;
-  if ((size_t)nb * k > h->knn_out_cap) {
-    if (h->d_depths) GV_HIP(hipFree(h->d_depths));
-    if (h->d_knn_d2) GV_HIP(hipFree(h->d_knn_d2));
-    h->d_depths = h->d_knn_d2 = nullptr;
-    h->knn_out_cap = 0;
-    GV_HIP(hipMalloc(reinterpret_cast<void **>(&h->d_depths), (size_t)nb * 32 * sizeof(float)));
-    GV_HIP(hipMalloc(reinterpret_cast<void **>(&h->d_knn_d2), (size_t)nb * 32 * sizeof(float)));
-    h->knn_out_cap = (size_t)nb * 32;
-  }
+  // depths | sorted squared distances, stored by the merge kernel straight into the result block
+  CallDone done;
+  if ((rc = begin_result(h, (size_t)nb * (1 + (size_t)k) * sizeof(float), done))) return rc;
+  float *r_depths = reinterpret_cast<float *>(h->res_host + kResHeader), *r_d2 = r_depths + nb;
   // buildKDTree projection (cloud_detections.cpp:8-33) then the exact k nearest (:43-87)
   launch_project_uvd(h->cx, h->cy, h->cz, (uint32_t)h->n, h->m_cam, h->camk, h->tx, h->ty, h->tz, h->stream);
-  launch_knn(h->tx, h->ty, h->tz, (uint32_t)h->n, h->det[2].bboxes, nb, k, h->knn_partial, h->d_depths, h->d_knn_d2, h->stream);
+  launch_knn(h->tx, h->ty, h->tz, (uint32_t)h->n, h->det[2].bboxes, nb, k, h->knn_partial, r_depths, knn_d2 ? r_d2 : nullptr, done,
+             h->stream);
   GV_HIP(hipGetLastError());
-  GV_HIP(hipMemcpyAsync(depths, h->d_depths, (size_t)nb * sizeof(float), hipMemcpyDeviceToHost, h->stream));
-  if (knn_d2)
-    GV_HIP(hipMemcpyAsync(knn_d2, h->d_knn_d2, (size_t)nb * k * sizeof(float), hipMemcpyDeviceToHost, h->stream));
-  GV_HIP(hipStreamSynchronize(h->stream));
+  if ((rc = wait_result(h))) return rc;
+  std::memcpy(depths, r_depths, (size_t)nb * sizeof(float));
+  if (knn_d2) std::memcpy(knn_d2, r_d2, (size_t)nb * k * sizeof(float));
   return GV_OK;
   GV_CATCH
 }
@@ -2421,7 +2468,7 @@ static size_t pose_block_bytes(int32_t nb) { return pose_block_valid_off(nb) + (
 // without a host wait in between; only the nb poses come back.  with_ground: the points of the refined RANSAC
 // plane in *d_rstate are dropped first (computeBBoxPose, cloud_detections.cpp:300-321), and the "empty segmented
 // cloud" outcomes (:307-309) are decided on the device.
-static int enqueue_bbox_pose(gv_context *h, int32_t nb, bool with_ground, float thr_f)
+static int enqueue_bbox_pose(gv_context *h, int32_t nb, bool with_ground, float thr_f, uint8_t *out, const CallDone &done)
 {
   const size_t n = h->n;
   int rc;
@@ -2463,7 +2510,6 @@ static int enqueue_bbox_pose(gv_context *h, int32_t nb, bool with_ground, float 
   const size_t nblocks = (n + 1023) / 1024;
   if ((rc = grow(h, h->d_blockcnt, h->blockcnt_cap, nblocks * (size_t)nb + 16))) return rc;
   if ((rc = grow(h, h->d_segstart, h->segstart_cap, (size_t)nb + 2))) return rc;
-  if ((rc = grow(h, h->d_pose_out, h->pose_out_cap, pose_block_bytes(nb)))) return rc;
   if (!h->d_rstate) {
     GV_HIP(hipMalloc(reinterpret_cast<void **>(&h->d_rstate), sizeof(RansacState)));
     GV_HIP(hipMemsetAsync(h->d_rstate, 0, sizeof(RansacState), h->stream));
@@ -2479,8 +2525,8 @@ static int enqueue_bbox_pose(gv_context *h, int32_t nb, bool with_ground, float 
   // PCA rectangle per bbox in the reference's accumulation order (:156-247)
   launch_split_kept(h->bbox_id, h->d_drop, h->cx, h->cy, h->cz, h->m_cam, (uint32_t)n, nb, h->d_blockcnt, h->d_segstart, h->gx, h->gy, h->gz, s);
   launch_pca_bbox(h->gx, h->gy, h->gz, h->d_segstart, nb, h->d_rstate, with_ground, (uint32_t)n,
-                  reinterpret_cast<gv_lshape_pose *>(h->d_pose_out), h->d_pose_out + pose_block_valid_off(nb),
-                  reinterpret_cast<RansacState *>(h->d_pose_out + (size_t)nb * sizeof(gv_lshape_pose)), s);
+                  reinterpret_cast<gv_lshape_pose *>(out), out + pose_block_valid_off(nb),
+                  reinterpret_cast<RansacState *>(out + (size_t)nb * sizeof(gv_lshape_pose)), done, s);
   GV_HIP(hipGetLastError());
   return GV_OK;
 }
@@ -2507,19 +2553,27 @@ static int compute_bbox_pose_impl(gv_handle h, const gv_bbox *bboxes, int32_t nb
     h->ground_n = 0;   // the mask itself is not materialised on this path
   }
   if (nb) {
-    if ((rc = enqueue_bbox_pose(h, nb, with_ground, thr_f))) return rc;
-    std::vector<uint8_t> blk(pose_block_bytes(nb));   // poses | state | flags: one copy, one wait
-    GV_HIP(hipMemcpyAsync(blk.data(), h->d_pose_out, blk.size(), hipMemcpyDeviceToHost, h->stream));
-    GV_HIP(hipStreamSynchronize(h->stream));
-    std::memcpy(poses_out, blk.data(), (size_t)nb * sizeof(gv_lshape_pose));
-    std::memcpy(valid, blk.data() + pose_block_valid_off(nb), (size_t)nb);
-    if (st_out) std::memcpy(st_out, blk.data() + (size_t)nb * sizeof(gv_lshape_pose), sizeof(RansacState));
+    // poses | state | flags: stored by the PCA kernel straight into the result block, no copy, no runtime wait
+    CallDone done;
+    if ((rc = begin_result(h, pose_block_bytes(nb), done))) return rc;
+    const uint8_t *blk = h->res_host + kResHeader;
+    if ((rc = enqueue_bbox_pose(h, nb, with_ground, thr_f, h->res_host + kResHeader, done))) return rc;
+    if ((rc = wait_result(h))) return rc;
+    std::memcpy(poses_out, blk, (size_t)nb * sizeof(gv_lshape_pose));
+    std::memcpy(valid, blk + pose_block_valid_off(nb), (size_t)nb);
+    if (st_out) std::memcpy(st_out, blk + (size_t)nb * sizeof(gv_lshape_pose), sizeof(RansacState));
     return GV_OK;
   }
   if (with_ground) {   // no boxes: the ground count still decides the return value
     if ((rc = grow(h, h->d_ground, h->ground_cap, n))) return rc;
-    launch_ransac_mask(h->cx, h->cy, h->cz, (uint32_t)n, h->m_cam, thr_f, h->d_rstate, h->d_ground, h->stream);
-    if (st_out) GV_HIP(hipMemcpyAsync(st_out, h->d_rstate, sizeof(RansacState), hipMemcpyDeviceToHost, h->stream));
+    CallDone done;
+    if ((rc = begin_result(h, sizeof(RansacState), done))) return rc;
+    launch_ransac_mask(h->cx, h->cy, h->cz, (uint32_t)n, h->m_cam, thr_f, h->d_rstate, h->d_ground,
+                       reinterpret_cast<RansacState *>(h->res_host + kResHeader), done, h->stream);
+    GV_HIP(hipGetLastError());
+    if ((rc = wait_result(h))) return rc;
+    if (st_out) std::memcpy(st_out, h->res_host + kResHeader, sizeof(RansacState));
+    return GV_OK;
   }
   GV_HIP(hipStreamSynchronize(h->stream));
   return GV_OK;
@@ -2545,10 +2599,13 @@ static int segment_ground_device(gv_context *h, double threshold, int32_t iterat
   // camera-frame cloud (the reference segments transformed_cloud, grid_vision_node.cpp:215-216): transformed on the fly
   launch_ransac_plane(h->cx, h->cy, h->cz, (uint32_t)n, h->m_cam, thr_f, iterations, seed, h->d_planes, h->d_plane_counts,
                       h->d_rscratch, h->d_rstate, h->stream);
-  launch_ransac_mask(h->cx, h->cy, h->cz, (uint32_t)n, h->m_cam, thr_f, h->d_rstate, h->d_ground, h->stream);
+  CallDone done;
+  if ((rc = begin_result(h, sizeof(RansacState), done))) return rc;
+  launch_ransac_mask(h->cx, h->cy, h->cz, (uint32_t)n, h->m_cam, thr_f, h->d_rstate, h->d_ground,
+                     reinterpret_cast<RansacState *>(h->res_host + kResHeader), done, h->stream);
   GV_HIP(hipGetLastError());
-  GV_HIP(hipMemcpyAsync(&st, h->d_rstate, sizeof(RansacState), hipMemcpyDeviceToHost, h->stream));
-  GV_HIP(hipStreamSynchronize(h->stream));
+  if ((rc = wait_result(h))) return rc;
+  std::memcpy(&st, h->res_host + kResHeader, sizeof(RansacState));
   h->ground_n = n;
   return GV_OK;
 }

@@ -216,28 +216,52 @@ __global__ void __launch_bounds__(kCoThreads) k_ransac_moments(const float *__re
   __syncthreads();
   const unsigned bestc = s_bestc;
   const float4 pl = bestc ? planes[s_best] : make_float4(0.f, 0.f, 0.f, 0.f);
+  // A wavefront owns four level-0 groups (256 consecutive points).  Row q of 16 lanes takes group 4 w + q, and
+  // lane r of the row the group's points r, r + 16, r + 32, r + 48: the butterfly's steps 32 and 16 are then adds
+  // between the lane's own four values, and steps 8 .. 1 are DPP shifts inside the row -- for the four groups at
+  // once, nothing through the permute network.  Same pairs, same order of additions as tree_sum64.
+  {
+    const int q = lane >> 4, r = lane & 15;
+    const int g = w * kCoPts + q;   // level-0 group of this workgroup: points [64 g, 64 g + 64) of its 4096
+    const size_t i0 = (size_t)blockIdx.x * kCoBlock + (size_t)g * 64 + r;
+    float px[4], py[4], pz[4];
 #pragma unroll
-  for (int j = 0; j < kCoPts; ++j) {
-    const int g = w * kCoPts + j;   // level-0 group of this workgroup: points [64 g, 64 g + 64) of its 4096
-    const size_t i = (size_t)blockIdx.x * kCoBlock + (size_t)g * 64 + lane;
-    double v[kMom];
+    for (int t = 0; t < 4; ++t) {
+      const size_t i = i0 + 16 * t;
+      const bool in = i < n && bestc;
+      px[t] = in ? x[i] : 0.f;
+      py[t] = in ? y[i] : 0.f;
+      pz[t] = in ? z[i] : 0.f;
+    }
+    auto moments = [&](int t, double *v) {
 #pragma unroll
-    for (int k = 0; k < kMom; ++k) v[k] = 0.0;
-    if (i < n && bestc) {
+      for (int k = 0; k < kMom; ++k) v[k] = 0.0;
       float cx, cy, cz;
-      xform34(m, x[i], y[i], z[i], cx, cy, cz);
-      if (plane_inlier_dev(pl, cx, cy, cz, thr_f)) {
+      xform34(m, px[t], py[t], pz[t], cx, cy, cz);
+      if (i0 + 16 * t < n && bestc && plane_inlier_dev(pl, cx, cy, cz, thr_f)) {
         const double dx = (double)cx, dy = (double)cy, dz = (double)cz;
         v[0] = dx; v[1] = dy; v[2] = dz;
         v[3] = dx * dx; v[4] = dx * dy; v[5] = dx * dz; v[6] = dy * dy; v[7] = dy * dz; v[8] = dz * dz;
         v[9] = 1.0;
       }
-    }
+    };
+    double a[kMom], b[kMom], c[kMom];
+    moments(0, a);
+    moments(2, c);
 #pragma unroll
-    for (int k = 0; k < kMom; ++k) v[k] = wave_butterfly(v[k]);
-    if (lane == 0) {
+    for (int k = 0; k < kMom; ++k) a[k] = a[k] + c[k];   // step 32: v[r] += v[r + 32]
+    moments(1, b);
+    moments(3, c);
 #pragma unroll
-      for (int k = 0; k < kMom; ++k) s_l0[g][k] = v[k];
+    for (int k = 0; k < kMom; ++k) b[k] = b[k] + c[k];   //          v[r + 16] += v[r + 48]
+#pragma unroll
+    for (int k = 0; k < kMom; ++k) {
+      double v = a[k] + b[k];        // step 16
+      v = v + dpp_f64<0x108>(v);     // row_shl:8
+      v = v + dpp_f64<0x104>(v);     // row_shl:4
+      v = v + dpp_f64<0x102>(v);     // row_shl:2
+      v = v + dpp_f64<0x101>(v);     // row_shl:1
+      if (r == 0) s_l0[g][k] = v;
     }
   }
   __syncthreads();
@@ -318,7 +342,8 @@ __global__ void __launch_bounds__(kCoThreads) k_ransac_moments(const float *__re
 // inliers of the refined plane: mask[i] (device resident) and their number
 __global__ void __launch_bounds__(kCoThreads) k_ransac_mask(const float *__restrict__ x, const float *__restrict__ y,
                                                             const float *__restrict__ z, uint32_t n, Mat34f m, float thr_f,
-                                                            RansacState *__restrict__ st, uint8_t *__restrict__ mask)
+                                                            RansacState *__restrict__ st, uint8_t *__restrict__ mask,
+                                                            RansacState *__restrict__ st_copy, CallDone done)
 {
   __shared__ unsigned s_n;
   const float4 pl = st->refined;
@@ -340,7 +365,21 @@ __global__ void __launch_bounds__(kCoThreads) k_ransac_mask(const float *__restr
   }
   if ((threadIdx.x & 63) == 0 && c) atomicAdd(&s_n, c);
   __syncthreads();
-  if (threadIdx.x == 0 && s_n) atomicAdd(&st->n_inliers, (unsigned long long)s_n);
+  if (threadIdx.x == 0) {
+    if (s_n) atomicAdd(&st->n_inliers, (unsigned long long)s_n);
+    if (st_copy) {   // the workgroup that finishes last hands the final state out (its count read past the L1)
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      const unsigned t = __hip_atomic_fetch_add(&st->ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+      if (t == gridDim.x - 1u) {
+        __hip_atomic_store(&st->ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        RansacState o = *st;
+        o.n_inliers = __hip_atomic_load(&st->n_inliers, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        o.ticket = 0u;
+        *st_copy = o;
+        call_done(done, 1u);
+      }
+    }
+  }
 }
 
 size_t ransac_scratch_doubles(size_t n)
@@ -366,10 +405,10 @@ void launch_ransac_plane(const float *x, const float *y, const float *z, uint32_
 }
 
 void launch_ransac_mask(const float *x, const float *y, const float *z, uint32_t n, const Mat34f &m_cam, float thr_f,
-                        RansacState *st, uint8_t *mask, hipStream_t s)
+                        RansacState *st, uint8_t *mask, RansacState *st_copy, const CallDone &done, hipStream_t s)
 {
   const uint32_t nblk = (uint32_t)(((size_t)n + kCoBlock - 1) / kCoBlock);
-  hipLaunchKernelGGL(k_ransac_mask, dim3(nblk), dim3(kCoThreads), 0, s, x, y, z, n, m_cam, thr_f, st, mask);
+  hipLaunchKernelGGL(k_ransac_mask, dim3(nblk), dim3(kCoThreads), 0, s, x, y, z, n, m_cam, thr_f, st, mask, st_copy, done);
 }
 
 // --------------------------------------------- per-bbox clouds: classify + cell hash --
@@ -827,7 +866,7 @@ __global__ void __launch_bounds__(64) k_pca_bbox(const float *__restrict__ gx, c
                                                  const float *__restrict__ gz, const int32_t *__restrict__ seg_start, int nb,
                                                  const RansacState *__restrict__ st, int use_plane, uint32_t n_cloud,
                                                  gv_lshape_pose *__restrict__ poses, uint8_t *__restrict__ valid,
-                                                 RansacState *__restrict__ st_copy)
+                                                 RansacState *__restrict__ st_copy, CallDone done)
 {
   __shared__ __attribute__((aligned(16))) float s_t[2][3][kPcaTile];    // [buffer][y | z | x][point]
   __shared__ __attribute__((aligned(16))) double s_p[2][3][kPcaTile];   // [buffer][aa | ab | bb][point]
@@ -839,7 +878,11 @@ __global__ void __launch_bounds__(64) k_pca_bbox(const float *__restrict__ gx, c
   if (use_plane && (st->best_count == 0 || st->n_inliers == 0ull || st->n_inliers == (unsigned long long)n_cloud)) s1 = s0;
   const int cnt = s1 - s0;
   if (cnt <= 0) {   // :174-175 empty cloud: no pose
-    if (lane == 0) { valid[b] = 0; poses[b] = gv_lshape_pose{}; }
+    if (lane == 0) {
+      valid[b] = 0;
+      poses[b] = gv_lshape_pose{};
+      call_done(done, gridDim.x);
+    }
     return;
   }
   const float *arr[3] = {gy + s0, gz + s0, gx + s0};
@@ -957,6 +1000,7 @@ __global__ void __launch_bounds__(64) k_pca_bbox(const float *__restrict__ gx, c
     p.height = 0.0;           // never set on this path in the reference
     poses[b] = p;
     valid[b] = 1;
+    call_done(done, gridDim.x);
   }
 }
 
@@ -973,11 +1017,12 @@ void launch_split_kept(const int16_t *ids, const uint8_t *drop, const float *x, 
 }
 
 void launch_pca_bbox(const float *gx, const float *gy, const float *gz, const int32_t *seg_start, int nb, const RansacState *st,
-                     bool use_plane, uint32_t n_cloud, gv_lshape_pose *poses, uint8_t *valid, RansacState *st_copy, hipStream_t s)
+                     bool use_plane, uint32_t n_cloud, gv_lshape_pose *poses, uint8_t *valid, RansacState *st_copy,
+                     const CallDone &done, hipStream_t s)
 {
   if (nb <= 0) return;
   hipLaunchKernelGGL(k_pca_bbox, dim3(nb), dim3(64), 0, s, gx, gy, gz, seg_start, nb, st, use_plane ? 1 : 0, n_cloud, poses, valid,
-                     st_copy);
+                     st_copy, done);
 }
 
 }  // namespace gv

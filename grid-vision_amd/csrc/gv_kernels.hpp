@@ -212,8 +212,35 @@ struct Cand2 {
 void launch_project_uvd(const float *x, const float *y, const float *z, uint32_t n, const Mat34f &m,
                         const CamK &cam, float *pu, float *pv, float *pd, hipStream_t s);
 size_t knn_partial_entries(int nb, int k);   // Cand2 entries of the stage-1 lists
+
+// Completion of a synchronous call without a copy command or a runtime wait: the call's last kernel stores its
+// (small) results straight into pinned, device-mapped host memory, every workgroup then takes a ticket, and the
+// one whose ticket comes last publishes the call's sequence number in the block's first word -- the host spins on
+// that word (tools/micro/call_latency.hip: 8 us instead of 31 for copy + hipStreamSynchronize).  flag == nullptr:
+// plain device outputs, nothing published.
+struct CallDone {
+  unsigned *ticket = nullptr;   // device memory, zero between calls
+  unsigned *flag = nullptr;     // host-mapped
+  unsigned seq = 0;
+};
+#if defined(__HIPCC__)
+// by ONE lane of every workgroup of the grid, after that lane's result stores
+__device__ __forceinline__ void call_done(const CallDone &d, unsigned n_wg)
+{
+  if (!d.flag) return;
+  __threadfence_system();
+  const unsigned t = __hip_atomic_fetch_add(d.ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+  if (t == n_wg - 1u) {
+    __hip_atomic_store(d.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __threadfence_system();
+    __hip_atomic_store(d.flag, d.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+#endif
+
+// depths / knn_d2 may be host-mapped (then done.flag is set)
 void launch_knn(const float *pu, const float *pv, const float *pd, uint32_t n, const gv_bbox *bboxes, int nb, int k,
-                Cand2 *partial, float *depths, float *knn_d2, hipStream_t s);
+                Cand2 *partial, float *depths, float *knn_d2, const CallDone &done, hipStream_t s);
 
 // ---- device-resident RANSAC ground plane + per-bbox clouds / radius filter / PCA (gv_cloudops.hip) ----
 struct RansacState {
@@ -231,8 +258,9 @@ void launch_ransac_plane(const float *x, const float *y, const float *z, uint32_
                          unsigned long long seed, float4 *planes, unsigned *counts, double *scratch, RansacState *st,
                          hipStream_t s);
 // mask[n] of the refined plane's inliers + st->n_inliers
+// st_copy (optional, may be host-mapped): the final *st, stored by the workgroup that finishes last
 void launch_ransac_mask(const float *x, const float *y, const float *z, uint32_t n, const Mat34f &m_cam, float thr_f,
-                        RansacState *st, uint8_t *mask, hipStream_t s);
+                        RansacState *st, uint8_t *mask, RansacState *st_copy, const CallDone &done, hipStream_t s);
 // one selected point of the radius filter, in bucket order
 struct CellNode {
   float x, y, z;    // camera frame
@@ -254,6 +282,7 @@ void launch_split_kept(const int16_t *ids, const uint8_t *drop, const float *x, 
                        uint32_t n, int nb, uint32_t *block_counts, int32_t *seg_start, float *gx, float *gy, float *gz, hipStream_t s);
 // st_copy (optional): *st is copied there by the kernel (one read-back block for poses, flags and state)
 void launch_pca_bbox(const float *gx, const float *gy, const float *gz, const int32_t *seg_start, int nb, const RansacState *st,
-                     bool use_plane, uint32_t n_cloud, gv_lshape_pose *poses, uint8_t *valid, RansacState *st_copy, hipStream_t s);
+                     bool use_plane, uint32_t n_cloud, gv_lshape_pose *poses, uint8_t *valid, RansacState *st_copy,
+                     const CallDone &done, hipStream_t s);
 
 }  // namespace gv

@@ -162,7 +162,7 @@ __global__ void __launch_bounds__(kKnnThreads) k_knn_stage1(const float *__restr
 constexpr int kKnnListsPerLane = 4;
 __global__ void __launch_bounds__(64) k_knn_stage2(const KnnKey *__restrict__ partial, int nlists, int k,
                                                    const float *__restrict__ pd, float *__restrict__ depths,
-                                                   float *__restrict__ knn_d2)
+                                                   float *__restrict__ knn_d2, CallDone done)
 {
   __shared__ KnnKey s_best[kKnnMaxK];
   const int lane = threadIdx.x, b = blockIdx.x;
@@ -211,6 +211,7 @@ __global__ void __launch_bounds__(64) k_knn_stage2(const KnnKey *__restrict__ pa
       out = dv[cnt / 2];
     }
     depths[b] = out;
+    call_done(done, gridDim.x);
   }
 }
 
@@ -218,7 +219,7 @@ int knn_chunks() { return 64 * kKnnListsPerLane / kKnnWaves / 2; }   // 32 chunk
 size_t knn_partial_entries(int nb, int k) { return (size_t)nb * knn_chunks() * kKnnWaves * k; }
 
 void launch_knn(const float *pu, const float *pv, const float *pd, uint32_t n, const gv_bbox *bboxes, int nb, int k,
-                Cand2 *partial, float *depths, float *knn_d2, hipStream_t s)
+                Cand2 *partial, float *depths, float *knn_d2, const CallDone &done, hipStream_t s)
 {
   if (nb <= 0) return;
   static_assert(sizeof(Cand2) == sizeof(KnnKey), "candidate layout");
@@ -226,7 +227,7 @@ void launch_knn(const float *pu, const float *pv, const float *pd, uint32_t n, c
   hipLaunchKernelGGL(k_knn_stage1, dim3(nchunks, nb), dim3(kKnnThreads), 0, s, pu, pv, pd, n, bboxes, k,
                      reinterpret_cast<KnnKey *>(partial));
   hipLaunchKernelGGL(k_knn_stage2, dim3(nb), dim3(64), 0, s, reinterpret_cast<const KnnKey *>(partial), nchunks * kKnnWaves, k,
-                     pd, depths, knn_d2);
+                     pd, depths, knn_d2, done);
 }
 
 }  // namespace gv
