@@ -627,6 +627,12 @@ __device__ __forceinline__ int quad_sum(int v)
   return v;
 }
 
+template <int CTRL>
+__device__ __forceinline__ uint32_t quad_bcast(uint32_t v)
+{
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, false);
+}
+
 __global__ void __launch_bounds__(256) k_radius_sorted(const CellNode *__restrict__ sorted, const uint32_t *__restrict__ start,
                                                        uint32_t n_buckets, uint32_t hi_mask, float r2f, int min_pts,
                                                        uint8_t *__restrict__ drop)
@@ -666,24 +672,42 @@ __global__ void __launch_bounds__(256) k_radius_sorted(const CellNode *__restric
     if (x0 >= ix - 1 && x1 <= ix + 1 && y0 >= iy - 1 && y1 <= iy + 1 && z0 >= iz - 1 && z1 <= iz + 1) {
       // row (dy, dz): cells x0..x1 are one run, or two when they straddle a multiple of 8
       const int xs = ((x0 >> 3) != (x1 >> 3)) ? (x1 & ~7) : x1 + 1;   // first cell of the second run (none: x1 + 1)
-      uint32_t ra[18], rb[18];
+      // The nine rows are dealt to the quad's four lanes (lane l: rows l, l + 4, l + 8): each lane hashes and
+      // requests the bounds of at most three rows instead of all nine, and the walk gets a row's bounds from its
+      // owner by a DPP quad broadcast.
+      uint32_t sa[3][2], sb[3][2];
 #pragma unroll
-      for (int q = 0; q < 9; ++q) {
+      for (int sl = 0; sl < 3; ++sl) {
+        const int q = (int)l + 4 * sl;
         const int t9 = (q == 0) ? 4 : (q <= 4 ? q - 1 : q);   // the centre row first: it holds the point's own cell
-        const int cy = iy + t9 % 3 - 1, cz = iz + t9 / 3 - 1;
-        const bool in = cy >= y0 && cy <= y1 && cz >= z0 && cz <= z1;
+        const int t3 = (t9 * 11) >> 5;                         // t9 / 3 for 0 .. 11
+        const int cy = iy + (t9 - 3 * t3) - 1, cz = iz + t3 - 1;
+        const bool in = q < 9 && cy >= y0 && cy <= y1 && cz >= z0 && cz <= z1;
         const uint32_t b_lo = bucket_of(x0, cy, cz, myid, hi_mask);
         const uint32_t b_hi = bucket_of(min(xs - 1, x1), cy, cz, myid, hi_mask);
-        ra[2 * q] = in ? start[b_lo] : 0u;
-        rb[2 * q] = in ? start[b_hi + 1u] : 0u;
+        sa[sl][0] = in ? start[b_lo] : 0u;
+        sb[sl][0] = in ? start[b_hi + 1u] : 0u;
         const bool two = in && xs <= x1;
         const uint32_t c_lo = bucket_of(xs, cy, cz, myid, hi_mask);
         const uint32_t c_hi = bucket_of(x1, cy, cz, myid, hi_mask);
-        ra[2 * q + 1] = two ? start[c_lo] : 0u;
-        rb[2 * q + 1] = two ? start[c_hi + 1u] : 0u;
+        sa[sl][1] = two ? start[c_lo] : 0u;
+        sb[sl][1] = two ? start[c_hi + 1u] : 0u;
       }
 #pragma unroll
-      for (int q = 0; q < 18; ++q) walk(ra[q], rb[q]);
+      for (int q = 0; q < 9; ++q) {
+        constexpr int kBc[4] = {0x00, 0x55, 0xAA, 0xFF};   // quad_perm [k, k, k, k]
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          uint32_t a, b;
+          switch (q & 3) {
+          case 0: a = quad_bcast<kBc[0]>(sa[q >> 2][u]); b = quad_bcast<kBc[0]>(sb[q >> 2][u]); break;
+          case 1: a = quad_bcast<kBc[1]>(sa[q >> 2][u]); b = quad_bcast<kBc[1]>(sb[q >> 2][u]); break;
+          case 2: a = quad_bcast<kBc[2]>(sa[q >> 2][u]); b = quad_bcast<kBc[2]>(sb[q >> 2][u]); break;
+          default: a = quad_bcast<kBc[3]>(sa[q >> 2][u]); b = quad_bcast<kBc[3]>(sb[q >> 2][u]); break;
+          }
+          walk(a, b);
+        }
+      }
     } else {   // coordinates so large that fp32 spacing widens the range (capped at +-3 cells): cell by cell
       for (int cz = z0; cz <= z1 && cnt <= min_pts; ++cz)
         for (int cy = y0; cy <= y1 && cnt <= min_pts; ++cy)

@@ -60,13 +60,24 @@ void launch_project_uvd(const float *x, const float *y, const float *z, uint32_t
 typedef unsigned long long KnnKey;
 constexpr KnnKey kKnnNone = ~0ull;   // the d2 half is a NaN pattern: never a real candidate
 __device__ __forceinline__ KnnKey knn_key(float d2, uint32_t idx) { return ((KnnKey)__float_as_uint(d2) << 32) | (KnnKey)idx; }
+template <int CTRL>
+__device__ __forceinline__ KnnKey dpp_key(KnnKey v)
+{
+  const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(v & 0xffffffffull), CTRL, 0xF, 0xF, false);
+  const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(v >> 32), CTRL, 0xF, 0xF, false);
+  return ((KnnKey)hi << 32) | (KnnKey)lo;
+}
+// minimum over the wavefront, in every lane: rotations by 8, 4, 2, 1 inside the rows of 16 (DPP row_ror: every lane
+// ends with its row's minimum), then the two cross-row steps through the permute network
 __device__ __forceinline__ KnnKey wave_min_key(KnnKey v)
 {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    const KnnKey o = __shfl_xor(v, off);
-    v = o < v ? o : v;
-  }
+  KnnKey o;
+  o = dpp_key<0x128>(v); v = o < v ? o : v;   // row_ror:8
+  o = dpp_key<0x124>(v); v = o < v ? o : v;   // row_ror:4
+  o = dpp_key<0x122>(v); v = o < v ? o : v;   // row_ror:2
+  o = dpp_key<0x121>(v); v = o < v ? o : v;   // row_ror:1
+  o = __shfl_xor(v, 16); v = o < v ? o : v;
+  o = __shfl_xor(v, 32); v = o < v ? o : v;
   return v;
 }
 
@@ -98,6 +109,8 @@ __global__ void __launch_bounds__(kKnnThreads) k_knn_stage1(const float *__restr
   KnnKey *buf = s_buf[w];
   KnnKey mytop = kKnnNone;    // lane r: the r-th best so far (r < k)
   KnnKey thresh = kKnnNone;   // the k-th best so far once k candidates exist
+  float thresh_f = INFINITY;  // its squared distance: the scan compares floats (<=; an equal distance with a higher
+                              // index only adds a buffer entry the merge ranks behind the k-th), NaN never passes
   int nbuf = 0;               // wavefront-uniform
   auto merge = [&]() {
     KnnKey a0 = (lane < k) ? mytop : kKnnNone;
@@ -119,6 +132,7 @@ __global__ void __launch_bounds__(kKnnThreads) k_knn_stage1(const float *__restr
     const unsigned tl = __builtin_amdgcn_readlane((unsigned)(mytop & 0xffffffffull), k - 1);
     const unsigned th = __builtin_amdgcn_readlane((unsigned)(mytop >> 32), k - 1);
     thresh = ((KnnKey)th << 32) | (KnnKey)tl;   // still "none" while fewer than k candidates exist
+    thresh_f = (thresh == kKnnNone) ? INFINITY : __uint_as_float(th);
   };
   const uint32_t per = (n + gridDim.x - 1) / gridDim.x;
   const uint32_t lo = blockIdx.x * per, hi = min(n, lo + per);
@@ -141,11 +155,10 @@ __global__ void __launch_bounds__(kKnnThreads) k_knn_stage1(const float *__restr
       float r = __fmul_rn(d, d);
       d = bv[q] - qy; r = __fadd_rn(r, __fmul_rn(d, d));
       d = bd[q] - qz; r = __fadd_rn(r, __fmul_rn(d, d));
-      const KnnKey c = knn_key(r, i);
-      const bool ok = (r == r) && c < thresh;   // NaN never ranks
+      const bool ok = r <= thresh_f;
       const unsigned long long mk = __ballot(ok);
       if (mk) {
-        if (ok) buf[nbuf + __popcll(mk & ((1ull << lane) - 1ull))] = c;
+        if (ok) buf[nbuf + __popcll(mk & ((1ull << lane) - 1ull))] = knn_key(r, i);
         nbuf += (int)__popcll(mk);
         if (nbuf >= 64) merge();
       }
@@ -156,24 +169,29 @@ __global__ void __launch_bounds__(kKnnThreads) k_knn_stage1(const float *__restr
   if (lane < k) out[lane] = mytop;   // sorted ascending, "none" past the candidates found
 }
 
-// Stage 2: one wavefront per bbox merges the sorted lists of stage 1 (a lane owns every 64th list and keeps
-// their heads in registers), writes the sorted squared distances and the upper-median depth (nth_element at
-// size/2, :78-81).
+// Stage 2: one wavefront per bbox merges the sorted lists of stage 1, writes the sorted squared distances and the
+// upper-median depth (nth_element at size/2, :78-81).  The lists (at most 256 x 32 keys) are staged in LDS first --
+// one coalesced sweep -- so that advancing a list's head inside the k rounds is an LDS read, not a dependent
+// trip to the L2 per round (16 -> 5 us).  A lane owns every 64th list and keeps their heads in registers.
 constexpr int kKnnListsPerLane = 4;
 __global__ void __launch_bounds__(64) k_knn_stage2(const KnnKey *__restrict__ partial, int nlists, int k,
                                                    const float *__restrict__ pd, float *__restrict__ depths,
                                                    float *__restrict__ knn_d2, CallDone done)
 {
-  __shared__ KnnKey s_best[kKnnMaxK];
+  extern __shared__ KnnKey s_lists[];   // nlists * k keys, then kKnnMaxK results
+  KnnKey *s_best = s_lists + (size_t)nlists * k;
   const int lane = threadIdx.x, b = blockIdx.x;
   const KnnKey *p = partial + (size_t)b * nlists * k;
+  const int total = nlists * k;
+  for (int i = lane; i < total; i += 64) s_lists[i] = p[i];
+  __syncthreads();
   int hp[kKnnListsPerLane];
   KnnKey cur[kKnnListsPerLane];
 #pragma unroll
   for (int q = 0; q < kKnnListsPerLane; ++q) {
     const int l = lane + 64 * q;
     hp[q] = 0;
-    cur[q] = (l < nlists) ? p[(size_t)l * k] : kKnnNone;
+    cur[q] = (l < nlists) ? s_lists[l * k] : kKnnNone;
   }
   for (int round = 0; round < k; ++round) {
     KnnKey cand = cur[0];
@@ -186,33 +204,31 @@ __global__ void __launch_bounds__(64) k_knn_stage2(const KnnKey *__restrict__ pa
         if (cur[q] == best) {   // the owner advances that list
           const int l = lane + 64 * q;
           ++hp[q];
-          cur[q] = (hp[q] < k) ? p[(size_t)l * k + hp[q]] : kKnnNone;
+          cur[q] = (hp[q] < k) ? s_lists[l * k + hp[q]] : kKnnNone;
         }
     }
     if (lane == 0) s_best[round] = best;
   }
   __syncthreads();
-  if (lane == 0) {
-    int cnt = 0;
-    float dv[kKnnMaxK];
-    for (int j = 0; j < k; ++j) {
-      const KnnKey c = s_best[j];
-      if (knn_d2) knn_d2[(size_t)b * k + j] = (c == kKnnNone) ? INFINITY : __uint_as_float((unsigned)(c >> 32));
-      if (c != kKnnNone) dv[cnt++] = pd[(uint32_t)(c & 0xffffffffull)];
-    }
-    float out = -1.0f;   // :49
-    if (cnt > 0) {
-      for (int a = 1; a < cnt; ++a) {
-        const float t = dv[a];
-        int j = a - 1;
-        while (j >= 0 && dv[j] > t) { dv[j + 1] = dv[j]; --j; }
-        dv[j + 1] = t;
-      }
-      out = dv[cnt / 2];
-    }
-    depths[b] = out;
-    call_done(done, gridDim.x);
+  // the depths of the neighbours found, requested together (lane j: neighbour j)
+  const KnnKey mine = (lane < k) ? s_best[lane] : kKnnNone;
+  const float dep = (mine != kKnnNone) ? pd[(uint32_t)(mine & 0xffffffffull)] : 0.0f;
+  if (knn_d2 && lane < k) knn_d2[(size_t)b * k + lane] = (mine == kKnnNone) ? INFINITY : __uint_as_float((unsigned)(mine >> 32));
+  const unsigned long long have = __ballot(mine != kKnnNone);   // candidates fill the rounds from the front
+  const int cnt = (int)__popcll(have);
+  // rank of this lane's depth among the cnt found (ties by position): the element of rank cnt / 2 is the
+  // upper median -- what an insertion sort followed by [cnt / 2] yields
+  int rank = 0;
+  for (int j = 0; j < cnt; ++j) {
+    const float o = __shfl(dep, j);
+    rank += (o < dep || (o == dep && j < lane)) ? 1 : 0;
   }
+  float out = -1.0f;   // :49
+  const unsigned long long pick = __ballot(lane < cnt && rank == cnt / 2);
+  if (cnt > 0) out = __shfl(dep, pick ? __ffsll((long long)pick) - 1 : 0);
+  if (lane == 0) depths[b] = out;
+  if (done.flag) __threadfence_system();   // every lane's result stores, then the ticket
+  if (lane == 0) call_done(done, gridDim.x);
 }
 
 int knn_chunks() { return 64 * kKnnListsPerLane / kKnnWaves / 2; }   // 32 chunks x 4 wavefronts = 128 lists: two per lane
@@ -226,7 +242,8 @@ void launch_knn(const float *pu, const float *pv, const float *pd, uint32_t n, c
   const int nchunks = knn_chunks();
   hipLaunchKernelGGL(k_knn_stage1, dim3(nchunks, nb), dim3(kKnnThreads), 0, s, pu, pv, pd, n, bboxes, k,
                      reinterpret_cast<KnnKey *>(partial));
-  hipLaunchKernelGGL(k_knn_stage2, dim3(nb), dim3(64), 0, s, reinterpret_cast<const KnnKey *>(partial), nchunks * kKnnWaves, k,
+  const size_t lds2 = ((size_t)nchunks * kKnnWaves * k + kKnnMaxK) * sizeof(KnnKey);   // 128 lists x k <= 32 keys: 32 KB
+  hipLaunchKernelGGL(k_knn_stage2, dim3(nb), dim3(64), lds2, s, reinterpret_cast<const KnnKey *>(partial), nchunks * kKnnWaves, k,
                      pd, depths, knn_d2, done);
 }
 
