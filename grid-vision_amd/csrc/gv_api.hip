@@ -2449,8 +2449,8 @@ static int ensure_ransac_buffers(gv_context *h, size_t n, int32_t iterations)
     if (h->d_plane_counts) { GV_HIP(hipFree(h->d_plane_counts)); h->d_plane_counts = nullptr; }
     h->planes_cap = 0;
     GV_HIP(hipMalloc(reinterpret_cast<void **>(&h->d_planes), (size_t)iterations * sizeof(float4)));
-    GV_HIP(hipMalloc(reinterpret_cast<void **>(&h->d_plane_counts), (size_t)iterations * sizeof(unsigned)));
-    GV_HIP(hipMemsetAsync(h->d_plane_counts, 0, (size_t)iterations * sizeof(unsigned), h->stream));   // every pass leaves them zero
+    GV_HIP(hipMalloc(reinterpret_cast<void **>(&h->d_plane_counts), (size_t)iterations * kRansacCountSlices * sizeof(unsigned)));
+    GV_HIP(hipMemsetAsync(h->d_plane_counts, 0, (size_t)iterations * kRansacCountSlices * sizeof(unsigned), h->stream));   // every pass leaves them zero
     h->planes_cap = (size_t)iterations;
   }
   if ((rc = grow(h, h->d_rscratch, h->rscratch_cap, ransac_scratch_doubles(n)))) return rc;

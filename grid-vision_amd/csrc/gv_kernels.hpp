@@ -252,8 +252,12 @@ struct RansacState {
   unsigned ticket;              // arrival counter of the moments pass (zero between calls)
 };
 size_t ransac_scratch_doubles(size_t n);
+// The inlier counters of the hypotheses are kept in kRansacCountSlices copies (workgroup w adds to copy w % slices,
+// the selection sums them): every workgroup ends with one atomic per hypothesis, and 245 workgroups on the same
+// 50 words queue up in two L2 channels otherwise.  counts holds kRansacCountSlices * iters words.
+constexpr int kRansacCountSlices = 16;
 // hypotheses, inlier counts of all of them, selection + refinement on stream s; *st stays on the device.
-// counts[iters] must be zero on entry (the pass leaves it zero); thr_f = smallest float >= the fp64 threshold
+// counts[kRansacCountSlices * iters] must be zero on entry (the pass leaves it zero); thr_f = smallest float >= the fp64 threshold
 void launch_ransac_plane(const float *x, const float *y, const float *z, uint32_t n, const Mat34f &m_cam, float thr_f, int iters,
                          unsigned long long seed, float4 *planes, unsigned *counts, double *scratch, RansacState *st,
                          hipStream_t s);

@@ -619,6 +619,28 @@ def test_compute_bbox_pose_pca_path(gvamd):
     h.close()
 
 
+def test_compute_bbox_pose_more_than_64_boxes(gvamd):
+    """The kept-point split keeps its per-bbox cursors in one register up to 64 boxes and in LDS beyond: 90
+    clusters / boxes take the second form.  Same comparison as test_compute_bbox_pose_pca_path."""
+    h, tfs = make_handle(gvamd, 2, perturbed=True)
+    x, y, z, (cx, cy, cz), K, b = _cluster_scene(tfs, n_clusters=90, pts_per=150, seed=23)
+    assert len(b) > 64
+    h.upload_xyz(x, y, z)
+    poses, valid = h.compute_bbox_pose(b)
+    ids = ol.extract_cloud_per_bbox(K, cx, cy, cz, b, synth.IMG_W, synth.IMG_H)
+    n_valid = 0
+    for i in range(len(b)):
+        sel = ids == i
+        keep = ol.radius_outlier(cx[sel], cy[sel], cz[sel], 0.4, 10).astype(bool)
+        ok, e = ol.pca_bbox(cx[sel][keep], cy[sel][keep], cz[sel][keep])
+        assert bool(valid[i]) == ok
+        if ok:
+            n_valid += 1
+            _check_pose(poses[i], e, i)
+    assert n_valid >= 30
+    h.close()
+
+
 def test_sharded_frame_world1_matches_plain(gvamd):
     """RCCL path with a 1-rank communicator (all this box has): send/recv group, slice OR, all-gather,
     band packing, band grid pass and band broadcast must reproduce the plain frame exactly.
