@@ -171,9 +171,13 @@ __global__ void __launch_bounds__(256) k_bbox_prepare(const gv_bbox *__restrict_
     }
     __syncthreads();
     const int lo = max(b0, 64 * wd), hi = min(min(nb, b0 + kPrepBoxes), 64 * wd + 64);
-    for (int q = lo; q < hi; ++q) {
-      const int4 r = s_r[q - b0];
-      if (tx >= r.x && tx <= r.z && ty >= r.y && ty <= r.w) m |= 1ull << (q & 63);
+    for (int q0 = lo; q0 < hi; q0 += 8) {   // eight LDS reads in flight, predicated (no rolled remainder loop)
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int q = q0 + u;
+        const int4 r = s_r[min(q, hi - 1) - b0];
+        if (q < hi && tx >= r.x && tx <= r.z && ty >= r.y && ty <= r.w) m |= 1ull << (q & 63);
+      }
     }
   }
   if (gid < nwords) tile_mask[gid] = m;

@@ -174,6 +174,7 @@ __global__ void __launch_bounds__(kKnnThreads) k_knn_stage1(const float *__restr
 // one coalesced sweep -- so that advancing a list's head inside the k rounds is an LDS read, not a dependent
 // trip to the L2 per round (16 -> 5 us).  A lane owns every 64th list and keeps their heads in registers.
 constexpr int kKnnListsPerLane = 4;
+constexpr int kStageBatch = 20;   // 128 lists x k = 10 keys: one batch
 __global__ void __launch_bounds__(64) k_knn_stage2(const KnnKey *__restrict__ partial, int nlists, int k,
                                                    const float *__restrict__ pd, float *__restrict__ depths,
                                                    float *__restrict__ knn_d2, CallDone done)
@@ -183,7 +184,19 @@ __global__ void __launch_bounds__(64) k_knn_stage2(const KnnKey *__restrict__ pa
   const int lane = threadIdx.x, b = blockIdx.x;
   const KnnKey *p = partial + (size_t)b * nlists * k;
   const int total = nlists * k;
-  for (int i = lane; i < total; i += 64) s_lists[i] = p[i];
+  for (int i0 = 0; i0 < total; i0 += 64 * kStageBatch) {   // batches of predicated loads, all in flight together
+    KnnKey v[kStageBatch];
+#pragma unroll
+    for (int u = 0; u < kStageBatch; ++u) {
+      const int i = i0 + u * 64 + lane;
+      v[u] = (i < total) ? p[i] : kKnnNone;
+    }
+#pragma unroll
+    for (int u = 0; u < kStageBatch; ++u) {
+      const int i = i0 + u * 64 + lane;
+      if (i < total) s_lists[i] = v[u];
+    }
+  }
   __syncthreads();
   int hp[kKnnListsPerLane];
   KnnKey cur[kKnnListsPerLane];

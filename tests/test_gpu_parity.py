@@ -1148,6 +1148,30 @@ def test_pca_path_at_config3_size(gvamd):
     h.close()
 
 
+def test_bbox_pose_beyond_one_million_points(gvamd):
+    """1.3 M points: more than 1024 blocks of the kept-point split, and the kNN / radius-filter grids stride
+    over the cloud.  Poses of
+    computeBBoxPose (no ground removal) against the oracle's arithmetic on the cKDTree-kept points."""
+    h, tfs = make_handle(gvamd, 3, perturbed=True)
+    x, y, z, b = _large_scene(tfs, n_total=1_300_000, seed=29)
+    assert len(x) == 1_300_000 and len(b) >= 30
+    h.upload_xyz(x, y, z)
+    m_cam = ol.tf_to_matrix4f(tfs["cam_lidar"])
+    cx, cy, cz = ol.transform_cloud(m_cam, x, y, z)
+    K = ol.set_intrinsic(synth.FX, synth.FY, synth.CX, synth.CY)
+    poses, valid = h.compute_bbox_pose(b)
+    ids, ref = _pose_reference(cx, cy, cz, K, b, _radius_keep_ckdtree)
+    assert np.array_equal(h.bbox_id(), ids)
+    n_valid = 0
+    for i, (ok, e, nk, ns) in enumerate(ref):
+        assert bool(valid[i]) == ok, (i, nk, ns)
+        if ok:
+            n_valid += 1
+            _check_pose(poses[i], e, (i, nk))
+    assert n_valid >= 15
+    h.close()
+
+
 def test_ransac_tree_levels_and_failure_paths(gvamd):
     """the sum tree of the refinement at sizes that end after 1, 2 and 3 levels (n <= 64, <= 4096, > 4096 with
     more than one workgroup), a cloud that is all ground, and more hypotheses than one LDS batch holds"""
