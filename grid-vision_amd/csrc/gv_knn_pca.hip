@@ -81,6 +81,56 @@ __device__ __forceinline__ KnnKey wave_min_key(KnnKey v)
   return v;
 }
 
+// value of lane ^ J: quad permutes for J = 1, 2, ds_swizzle (bit-mask mode, xor inside 32 lanes) for 4, 8, 16, the
+// permute network for 32
+template <int J>
+__device__ __forceinline__ KnnKey xor_lane_key(KnnKey v)
+{
+  if constexpr (J == 1) return dpp_key<0xB1>(v);        // quad_perm [1,0,3,2]
+  else if constexpr (J == 2) return dpp_key<0x4E>(v);   // quad_perm [2,3,0,1]
+  else if constexpr (J == 32) return __shfl_xor(v, 32);
+  else {
+    constexpr int pat = (J << 10) | 0x1f;
+    const unsigned lo = (unsigned)__builtin_amdgcn_ds_swizzle((int)(unsigned)(v & 0xffffffffull), pat);
+    const unsigned hi = (unsigned)__builtin_amdgcn_ds_swizzle((int)(unsigned)(v >> 32), pat);
+    return ((KnnKey)hi << 32) | (KnnKey)lo;
+  }
+}
+// one compare-exchange step of a bitonic network over the 64 lanes: partner = lane ^ J, blocks of SIZE lanes
+// alternate their direction (SIZE = 64: one block); DESC flips every direction
+template <int SIZE, int J, bool DESC>
+__device__ __forceinline__ KnnKey bitonic_step(KnnKey v, int lane)
+{
+  const KnnKey o = xor_lane_key<J>(v);
+  const bool up = ((lane & SIZE) == 0) != DESC;   // (lane & 64 is always 0)
+  const bool lower = (lane & J) == 0;
+  const bool keep_min = lower == up;
+  return ((o < v) == keep_min) ? o : v;
+}
+template <int SIZE, bool DESC>
+__device__ __forceinline__ KnnKey bitonic_merge_steps(KnnKey v, int lane)   // the steps J = SIZE / 2 .. 1 of one stage
+{
+  if constexpr (SIZE >= 64) v = bitonic_step<SIZE, 32, DESC>(v, lane);
+  if constexpr (SIZE >= 32) v = bitonic_step<SIZE, 16, DESC>(v, lane);
+  if constexpr (SIZE >= 16) v = bitonic_step<SIZE, 8, DESC>(v, lane);
+  if constexpr (SIZE >= 8) v = bitonic_step<SIZE, 4, DESC>(v, lane);
+  if constexpr (SIZE >= 4) v = bitonic_step<SIZE, 2, DESC>(v, lane);
+  v = bitonic_step<SIZE, 1, DESC>(v, lane);
+  return v;
+}
+// the 64 lanes' keys sorted across the lanes (21 steps)
+template <bool DESC>
+__device__ __forceinline__ KnnKey bitonic_sort64(KnnKey v, int lane)
+{
+  v = bitonic_merge_steps<2, DESC>(v, lane);
+  v = bitonic_merge_steps<4, DESC>(v, lane);
+  v = bitonic_merge_steps<8, DESC>(v, lane);
+  v = bitonic_merge_steps<16, DESC>(v, lane);
+  v = bitonic_merge_steps<32, DESC>(v, lane);
+  v = bitonic_merge_steps<64, DESC>(v, lane);
+  return v;
+}
+
 constexpr int kKnnMaxK = 32;
 constexpr int kKnnThreads = 256;
 constexpr int kKnnWaves = kKnnThreads / 64;
@@ -112,23 +162,24 @@ __global__ void __launch_bounds__(kKnnThreads) k_knn_stage1(const float *__restr
   float thresh_f = INFINITY;  // its squared distance: the scan compares floats (<=; an equal distance with a higher
                               // index only adds a buffer entry the merge ranks behind the k-th), NaN never passes
   int nbuf = 0;               // wavefront-uniform
+  // Merge of the buffer's first 64 entries into the top-k: the entries are sorted DESCENDING across the lanes by a
+  // bitonic network (21 compare-exchange steps), lane-wise minimum with the ascending top-k (lanes >= k: "none")
+  // leaves the 64 smallest of both as a bitonic sequence, six more steps sort it.  ~250 vector instructions
+  // whatever k is (the k rounds of wavefront arg-min this replaces: 70 per round).  What the buffer holds beyond
+  // 64 entries moves to its front and waits for the next merge.
   auto merge = [&]() {
-    KnnKey a0 = (lane < k) ? mytop : kKnnNone;
-    KnnKey a1 = (lane < nbuf) ? buf[lane] : kKnnNone;
-    KnnKey a2 = (lane + 64 < nbuf) ? buf[lane + 64] : kKnnNone;
-    KnnKey nt = kKnnNone;
-    for (int r = 0; r < k; ++r) {
-      KnnKey mn = a0 < a1 ? a0 : a1;
-      mn = a2 < mn ? a2 : mn;
-      const KnnKey best = wave_min_key(mn);
-      if (best == kKnnNone) break;
-      if (a0 == best) a0 = kKnnNone;   // keys are unique (the index half): exactly one copy exists
-      if (a1 == best) a1 = kKnnNone;
-      if (a2 == best) a2 = kKnnNone;
-      if (lane == r) nt = best;
+    const int take = min(nbuf, 64);
+    KnnKey a1 = (lane < take) ? buf[lane] : kKnnNone;
+    if (nbuf > 64) {
+      const KnnKey rest = (lane + 64 < nbuf) ? buf[lane + 64] : kKnnNone;
+      buf[lane] = rest;
     }
-    mytop = nt;
-    nbuf = 0;
+    nbuf -= take;
+    a1 = bitonic_sort64<true>(a1, lane);
+    const KnnKey a0 = (lane < k) ? mytop : kKnnNone;
+    KnnKey v = a0 < a1 ? a0 : a1;
+    v = bitonic_merge_steps<64, false>(v, lane);
+    mytop = (lane < k) ? v : kKnnNone;
     const unsigned tl = __builtin_amdgcn_readlane((unsigned)(mytop & 0xffffffffull), k - 1);
     const unsigned th = __builtin_amdgcn_readlane((unsigned)(mytop >> 32), k - 1);
     thresh = ((KnnKey)th << 32) | (KnnKey)tl;   // still "none" while fewer than k candidates exist
@@ -164,7 +215,7 @@ __global__ void __launch_bounds__(kKnnThreads) k_knn_stage1(const float *__restr
       }
     }
   }
-  if (nbuf) merge();
+  while (nbuf) merge();
   KnnKey *out = partial + (((size_t)b * gridDim.x + blockIdx.x) * kKnnWaves + w) * k;
   if (lane < k) out[lane] = mytop;   // sorted ascending, "none" past the candidates found
 }
