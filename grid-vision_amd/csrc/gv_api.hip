@@ -502,8 +502,11 @@ BBoxTest bbox_test_of(const gv_context *h, const DetSet &d)
 // Upload the small per-frame arrays into detection set `d` on stream `s` and derive the bbox-test
 // tables there.  The caller's arrays are copied into the set's pinned staging block first (they are
 // free on return) and the block goes to the device in ONE asynchronous copy.
+// masks = false: the caller's kernels read the raw boxes / poses only (kNN depth, vision orientation, plain pose
+// update) -- the thresholds and tile masks of the bbox test are not rebuilt, and whoever tests points against this
+// set uploads it again first (every such call does).
 int upload_det(gv_context *h, DetSet &d, const gv_bbox *bboxes, int32_t nb, const gv_lshape_pose *poses,
-               int32_t n_poses, const float *orient, const float *conf, const float *dims, hipStream_t s)
+               int32_t n_poses, const float *orient, const float *conf, const float *dims, hipStream_t s, bool masks = true)
 {
   int rc = ensure_det(h, d, std::max(nb, n_poses));
   if (rc) return rc;
@@ -523,7 +526,7 @@ int upload_det(gv_context *h, DetSet &d, const gv_bbox *bboxes, int32_t nb, cons
   if (dims) put(L.dims, dims, (size_t)nb * 3 * sizeof(float));
   if (used) GV_HIP(hipMemcpyAsync(d.block, d.stage, used, hipMemcpyHostToDevice, s));
   d.mask_words = std::max(1, (nb + 63) / 64);
-  launch_bbox_prepare(d.bboxes, nb, h->bt_tiles_x, h->bt_tiles_y, d.mask_words, d.bbox_f, d.tile_mask, s);
+  if (masks) launch_bbox_prepare(d.bboxes, nb, h->bt_tiles_x, h->bt_tiles_y, d.mask_words, d.bbox_f, d.tile_mask, s);
   GV_HIP(hipGetLastError());
   d.nb = nb;
   d.n_poses = n_poses;
@@ -532,10 +535,10 @@ int upload_det(gv_context *h, DetSet &d, const gv_bbox *bboxes, int32_t nb, cons
 }
 
 // bboxes only, synchronously, into the standalone set (extractCloudPerBBox and friends)
-int upload_scratch_bboxes(gv_context *h, const gv_bbox *b, int32_t nb)
+int upload_scratch_bboxes(gv_context *h, const gv_bbox *b, int32_t nb, bool masks = true)
 {
   DetSet &d = h->det[2];
-  int rc = upload_det(h, d, b, nb, nullptr, 0, nullptr, nullptr, nullptr, h->stream);
+  int rc = upload_det(h, d, b, nb, nullptr, 0, nullptr, nullptr, nullptr, h->stream, masks);
   if (rc) return rc;
   GV_HIP(hipEventRecord(d.ready, h->stream));
   return GV_OK;
@@ -1916,7 +1919,7 @@ int gv_vision_post_process(gv_handle h, const float *orient, const float *conf, 
   int rc = use_device(h);
   if (rc) return rc;
   DetSet &d = h->det[2];
-  if ((rc = upload_det(h, d, bboxes, nb, nullptr, 0, orient, conf, dims, h->stream))) return rc;
+  if ((rc = upload_det(h, d, bboxes, nb, nullptr, 0, orient, conf, dims, h->stream, false))) return rc;
   GV_HIP(hipEventRecord(d.ready, h->stream));
   launch_vision(d.orient, d.conf, d.dims, d.bboxes, nb, h->cam, h->d_vout, d.poses, h->stream);
   GV_HIP(hipGetLastError());
@@ -2020,7 +2023,7 @@ int gv_update_map_poses(gv_handle h, const gv_lshape_pose *poses, int32_t n)
   int rc = use_device(h);
   if (rc) return rc;
   DetSet &d = h->det[2];
-  if ((rc = upload_det(h, d, nullptr, 0, poses, n, nullptr, nullptr, nullptr, h->stream))) return rc;
+  if ((rc = upload_det(h, d, nullptr, 0, poses, n, nullptr, nullptr, nullptr, h->stream, false))) return rc;
   GV_HIP(hipEventRecord(d.ready, h->stream));
   if (n) launch_rects_from_poses(d.poses, n, h->g, false, h->x_bc, h->x_rects[0], h->stream);
   if ((rc = enqueue_plain_update(h, n))) return rc;
@@ -2035,7 +2038,7 @@ int gv_update_map_points(gv_handle h, const double *pts, const gv_bbox *bboxes, 
   GV_TRY
   int rc = use_device(h);
   if (rc) return rc;
-  if ((rc = upload_scratch_bboxes(h, bboxes, n))) return rc;
+  if ((rc = upload_scratch_bboxes(h, bboxes, n, false))) return rc;
   if (n) {
     GV_HIP(hipMemcpyAsync(h->d_pts, pts, (size_t)n * 3 * sizeof(double), hipMemcpyHostToDevice, h->stream));
     launch_rects_from_points(h->d_pts, h->det[2].bboxes, n, h->g, h->x_rects[0], h->stream);
@@ -2414,7 +2417,7 @@ int gv_compute_depth_for_bboxes(gv_handle h, const gv_bbox *bboxes, int32_t nb, 
   if (nb == 0) return GV_OK;
   int rc = use_device(h);
   if (rc) return rc;
-  if ((rc = upload_scratch_bboxes(h, bboxes, nb))) return rc;
+  if ((rc = upload_scratch_bboxes(h, bboxes, nb, false))) return rc;   // the kNN reads the boxes' centres only
   if ((rc = ensure_tbuf(h, std::max<size_t>(h->n, 1)))) return rc;
   if ((rc = grow(h, h->knn_partial, h->knn_partial_cap, knn_partial_entries(nb, k)))) return rc;
   // depths | sorted squared distances, stored by the merge kernel straight into the result block
