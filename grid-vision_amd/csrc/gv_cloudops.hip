@@ -295,41 +295,76 @@ __global__ void __launch_bounds__(kCoThreads) k_ransac_moments(const float *__re
   }
   __syncthreads();
   if (!s_last) return;
-  // every workgroup has read the counts: cleared here for the next call (no memset launch)
-  for (int t = tid; t < iters * kRansacCountSlices; t += kCoThreads) counts[t] = 0u;
-  // levels 2..: groups of 64 partial sums per wavefront, ping-pong between the two scratch arrays (agent-scope
-  // accesses: other wavefronts of this workgroup wrote them)
+  // levels 2..: groups of 64 partial sums per wavefront.
   size_t cnt = gridDim.x;
-  const double *src = part_a;
-  double *dst = part_b;
-  while (cnt > 1) {
-    const size_t groups = (cnt + 63) / 64;
-    for (size_t g = (size_t)w; g < groups; g += kCoThreads / 64) {
-      const size_t i = g * 64 + lane;
+  __shared__ double s_tot[kMom];
+  const bool short_tree = cnt > 1 && cnt <= 4096;   // up to 16.7 M points: levels 2 and 3 without a trip through memory
+  if (short_tree) {
+    // ONE round of loads (every wavefront its groups, all ten quantities in flight), level-2 sums into LDS, the
+    // level-3 butterfly out of LDS: the tail used to be store -> wait -> barrier -> load per level (10 us of
+    // dependent round trips for 245 partial sums)
+    const int groups = (int)((cnt + 63) / 64);
+    for (int g = w; g < groups; g += kCoThreads / 64) {
+      const size_t i = (size_t)g * 64 + lane;
       double v[kMom];
 #pragma unroll
       for (int k = 0; k < kMom; ++k)
-        v[k] = (i < cnt) ? __hip_atomic_load(&src[i * kMom + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+        v[k] = (i < cnt) ? __hip_atomic_load(&part_a[i * kMom + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
 #pragma unroll
       for (int k = 0; k < kMom; ++k) v[k] = wave_butterfly(v[k]);
       if (lane == 0) {
 #pragma unroll
-        for (int k = 0; k < kMom; ++k) __hip_atomic_store(&dst[g * kMom + k], v[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int k = 0; k < kMom; ++k) s_l0[g][k] = v[k];
       }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    const double *t = src;
-    src = dst;
-    dst = const_cast<double *>(t);
-    cnt = groups;
-  }
-  if (tid == 0) {
-    double mom[kMom];
+    if (groups > 1) {   // level 3: the group sums and zeros, as the oracle's tree pads them
+      if (w < kMom) {
+        const double t = wave_butterfly(lane < groups ? s_l0[lane][w] : 0.0);
+        if (lane == 0) s_tot[w] = t;
+      }
+    } else if (tid < kMom) {
+      s_tot[tid] = s_l0[0][tid];
+    }
+    __syncthreads();
+  } else {
+    // the general tree: ping-pong between the two scratch arrays (agent-scope accesses: other wavefronts of this
+    // workgroup wrote them)
+    const double *src = part_a;
+    double *dst = part_b;
+    while (cnt > 1) {
+      const size_t groups = (cnt + 63) / 64;
+      for (size_t g = (size_t)w; g < groups; g += kCoThreads / 64) {
+        const size_t i = g * 64 + lane;
+        double v[kMom];
+#pragma unroll
+        for (int k = 0; k < kMom; ++k)
+          v[k] = (i < cnt) ? __hip_atomic_load(&src[i * kMom + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+#pragma unroll
+        for (int k = 0; k < kMom; ++k) v[k] = wave_butterfly(v[k]);
+        if (lane == 0) {
+#pragma unroll
+          for (int k = 0; k < kMom; ++k) __hip_atomic_store(&dst[g * kMom + k], v[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      const double *t = src;
+      src = dst;
+      dst = const_cast<double *>(t);
+      cnt = groups;
+    }
     // one workgroup: its level-1 sums ARE the totals only if the tree had a single level-1 group; the oracle's
     // tree always takes at least one level per 64 values, which the loop above reproduces for cnt > 1 and which
     // is the identity (sum of one value and 63 zeros) for cnt == 1
-    for (int k = 0; k < kMom; ++k) mom[k] = __hip_atomic_load(&src[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid < kMom) s_tot[tid] = __hip_atomic_load(&src[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+  }
+  // every workgroup has read the counts: cleared here for the next call (no memset launch; nobody waits for these)
+  for (int t = tid; t < iters * kRansacCountSlices; t += kCoThreads) counts[t] = 0u;
+  if (tid == 0) {
+    double mom[kMom];
+    for (int k = 0; k < kMom; ++k) mom[k] = s_tot[k];
     const unsigned long long mi = (unsigned long long)mom[9];
     float4 refined = pl;
     if (bestc && mi >= 3) {
