@@ -118,46 +118,61 @@ __global__ void __launch_bounds__(kCoThreads) k_ransac_count_all(const float *__
     if (s_cnt[t]) atomicAdd(&counts[(size_t)(blockIdx.x % kRansacCountSlices) * stride + t], s_cnt[t]);   // sliced: see gv_kernels.hpp
 }
 
-// unit eigenvector of the smallest eigenvalue of a symmetric 3x3 (cyclic Jacobi, fp64): oracle/ransac.c
-__device__ void smallest_eigenvector3_dev(const double cov[6], double v[3])
+// unit eigenvector of the smallest eigenvalue of a symmetric 3x3 (cyclic Jacobi, fp64): oracle/ransac.c, operation
+// for operation.  Every index is a compile-time constant (loops unrolled, the final column picked by selects): with
+// run-time indices the two matrices live in scratch memory and every access of this single-lane tail is a trip to
+// the L2 (14 us of the kernel's 29).
+template <int P, int Q>
+__device__ __forceinline__ void jacobi_rotate(double (&a)[3][3], double (&e)[3][3])
+{
+  if (a[P][Q] == 0.0) return;
+  const double theta = (a[Q][Q] - a[P][P]) / (2.0 * a[P][Q]);
+  const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+  const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const double akp = a[k][P], akq = a[k][Q];
+    a[k][P] = c * akp - s * akq;
+    a[k][Q] = s * akp + c * akq;
+  }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const double apk = a[P][k], aqk = a[Q][k];
+    a[P][k] = c * apk - s * aqk;
+    a[Q][k] = s * apk + c * aqk;
+  }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const double ekp = e[k][P], ekq = e[k][Q];
+    e[k][P] = c * ekp - s * ekq;
+    e[k][Q] = s * ekp + c * ekq;
+  }
+}
+
+__device__ __forceinline__ void smallest_eigenvector3_dev(const double cov[6], double v[3])
 {
   double a[3][3] = {{cov[0], cov[1], cov[2]}, {cov[1], cov[3], cov[4]}, {cov[2], cov[4], cov[5]}};
   double e[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
   for (int sweep = 0; sweep < 32; ++sweep) {
     const double off = a[0][1] * a[0][1] + a[0][2] * a[0][2] + a[1][2] * a[1][2];
     if (off < 1e-300) break;
-    for (int p = 0; p < 2; ++p)
-      for (int q = p + 1; q < 3; ++q) {
-        if (a[p][q] == 0.0) continue;
-        const double theta = (a[q][q] - a[p][p]) / (2.0 * a[p][q]);
-        const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-        const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
-        for (int k = 0; k < 3; ++k) {
-          const double akp = a[k][p], akq = a[k][q];
-          a[k][p] = c * akp - s * akq;
-          a[k][q] = s * akp + c * akq;
-        }
-        for (int k = 0; k < 3; ++k) {
-          const double apk = a[p][k], aqk = a[q][k];
-          a[p][k] = c * apk - s * aqk;
-          a[q][k] = s * apk + c * aqk;
-        }
-        for (int k = 0; k < 3; ++k) {
-          const double ekp = e[k][p], ekq = e[k][q];
-          e[k][p] = c * ekp - s * ekq;
-          e[k][q] = s * ekp + c * ekq;
-        }
-      }
+    jacobi_rotate<0, 1>(a, e);
+    jacobi_rotate<0, 2>(a, e);
+    jacobi_rotate<1, 2>(a, e);
   }
-  int mm = 0;
-  if (a[1][1] < a[mm][mm]) mm = 1;
-  if (a[2][2] < a[mm][mm]) mm = 2;
-  const double nn[3] = {e[0][mm], e[1][mm], e[2][mm]};
+  // column of the smallest diagonal entry (the first of equals), by selects
+  const bool m1 = a[1][1] < a[0][0];
+  const double d01 = m1 ? a[1][1] : a[0][0];
+  const bool m2 = a[2][2] < d01;
+  double nn[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) nn[k] = m2 ? e[k][2] : (m1 ? e[k][1] : e[k][0]);
   const double len = sqrt(nn[0] * nn[0] + nn[1] * nn[1] + nn[2] * nn[2]);
-  int big = 0;
-  if (fabs(nn[1]) > fabs(nn[big])) big = 1;
-  if (fabs(nn[2]) > fabs(nn[big])) big = 2;
-  const double sg = (nn[big] < 0) ? -1.0 / len : 1.0 / len;
+  // sign: the component of largest magnitude (the first of equals) is made positive
+  double big = nn[0];
+  if (fabs(nn[1]) > fabs(big)) big = nn[1];
+  if (fabs(nn[2]) > fabs(big)) big = nn[2];
+  const double sg = (big < 0) ? -1.0 / len : 1.0 / len;
   v[0] = nn[0] * sg; v[1] = nn[1] * sg; v[2] = nn[2] * sg;
 }
 
