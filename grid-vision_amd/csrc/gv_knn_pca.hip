@@ -138,8 +138,8 @@ constexpr int kKnnWaves = kKnnThreads / 64;
 // Stage 1: grid (chunks, nb), four wavefronts per workgroup, each on its own slice of the chunk and with its
 // own running top-k (lane r holds the r-th best).  A lane's candidate is looked at only if it beats the
 // wavefront's k-th best so far; survivors are appended -- ballot-compacted, no divergence -- to the wavefront's
-// LDS buffer, and when 64 or more have gathered the buffer and the old top-k are merged by k rounds of
-// wavefront arg-min.  The threshold tightens with every merge (after 64, ~500, ~4000 points ...), so a slice of
+// LDS buffer, and when 64 or more have gathered the buffer and the old top-k are merged by a bitonic network
+// (below).  The threshold tightens with every merge (after 64, ~500, ~4000 points ...), so a slice of
 // 8000 points sees three or four merges and a few hundred survivors.  (Round 2 kept a sorted list per THREAD:
 // 122 points per thread make a loose threshold, some lane of the wavefront inserted on almost every iteration
 // and the divergent insertion loops were the whole 0.4 ms.)  FLANN L2_Simple distance: ((du*du) + dv*dv) + dz*dz
@@ -158,9 +158,9 @@ __global__ void __launch_bounds__(kKnnThreads) k_knn_stage1(const float *__restr
   const float qz = 0.0f;                                                  // :59
   KnnKey *buf = s_buf[w];
   KnnKey mytop = kKnnNone;    // lane r: the r-th best so far (r < k)
-  KnnKey thresh = kKnnNone;   // the k-th best so far once k candidates exist
-  float thresh_f = INFINITY;  // its squared distance: the scan compares floats (<=; an equal distance with a higher
-                              // index only adds a buffer entry the merge ranks behind the k-th), NaN never passes
+  float thresh_f = INFINITY;  // squared distance of the k-th best so far once k candidates exist: the scan compares
+                              // floats (<=; an equal distance with a higher index only adds a buffer entry the merge
+                              // ranks behind the k-th), NaN never passes
   int nbuf = 0;               // wavefront-uniform
   // Merge of the buffer's first 64 entries into the top-k: the entries are sorted DESCENDING across the lanes by a
   // bitonic network (21 compare-exchange steps), lane-wise minimum with the ascending top-k (lanes >= k: "none")
@@ -182,8 +182,8 @@ __global__ void __launch_bounds__(kKnnThreads) k_knn_stage1(const float *__restr
     mytop = (lane < k) ? v : kKnnNone;
     const unsigned tl = __builtin_amdgcn_readlane((unsigned)(mytop & 0xffffffffull), k - 1);
     const unsigned th = __builtin_amdgcn_readlane((unsigned)(mytop >> 32), k - 1);
-    thresh = ((KnnKey)th << 32) | (KnnKey)tl;   // still "none" while fewer than k candidates exist
-    thresh_f = (thresh == kKnnNone) ? INFINITY : __uint_as_float(th);
+    const KnnKey kth = ((KnnKey)th << 32) | (KnnKey)tl;   // still "none" while fewer than k candidates exist
+    thresh_f = (kth == kKnnNone) ? INFINITY : __uint_as_float(th);
   };
   const uint32_t per = (n + gridDim.x - 1) / gridDim.x;
   const uint32_t lo = blockIdx.x * per, hi = min(n, lo + per);
@@ -223,7 +223,7 @@ __global__ void __launch_bounds__(kKnnThreads) k_knn_stage1(const float *__restr
 // Stage 2: one wavefront per bbox merges the sorted lists of stage 1, writes the sorted squared distances and the
 // upper-median depth (nth_element at size/2, :78-81).  The lists (at most 256 x 32 keys) are staged in LDS first --
 // one coalesced sweep -- so that advancing a list's head inside the k rounds is an LDS read, not a dependent
-// trip to the L2 per round (16 -> 5 us).  A lane owns every 64th list and keeps their heads in registers.
+// trip to the L2 per round (16 -> 11 us).  A lane owns every 64th list and keeps their heads in registers.
 constexpr int kKnnListsPerLane = 4;
 constexpr int kStageBatch = 20;   // 128 lists x k = 10 keys: one batch
 __global__ void __launch_bounds__(64) k_knn_stage2(const KnnKey *__restrict__ partial, int nlists, int k,
