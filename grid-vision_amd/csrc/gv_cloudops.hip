@@ -1096,8 +1096,11 @@ __global__ void __launch_bounds__(64) k_pca_bbox(const float *__restrict__ gx, c
     minW = fminf(minW, __shfl_xor(minW, off)); maxW = fmaxf(maxW, __shfl_xor(maxW, off));
   }
   if (lane == 0) {
-    // :227 degrees, :236 passed to setRPY as if radians (as the reference does); atan2f evaluated in fp64, rounded once
-    const float angle = (float)atan2((double)My, (double)Mx) * 180.0f / (float)3.14159265358979323846;
+    // :227 degrees, :236 passed to setRPY as if radians (as the reference does); atan2f evaluated in fp64, rounded once.
+    // `std::atan2(float, float) * 180.0f / CV_PI`: float product, widened for the division by the DOUBLE CV_PI,
+    // narrowed once on the assignment to `float angle`.
+    const float a32 = (float)atan2((double)My, (double)Mx);
+    const float angle = (float)((double)(a32 * 180.0f) / 3.1415926535897932384626433832795);
     const double hp = (double)(-angle) * 0.5;   // tf2 setRPY(0, pitch, 0): (0, sin(p/2), 0, cos(p/2))
     gv_lshape_pose p{};
     p.px = m1;    // :230 center.y

@@ -169,6 +169,8 @@ void gvo_radius_outlier(const float *x, const float *y, const float *z, size_t n
 /* bboxPoseEstimation :140-185 + computePCABoundingBox :187-247 for ONE bbox
  * cloud (already filtered).  Returns 0 when the cloud is empty (:174-175). */
 int gvo_pca_bbox(const float *x, const float *y, const float *z, size_t n, gvo_lshape *out);
+/* :227 the angle expression alone (float atan2 * 180.0f, divided by the double CV_PI, narrowed once) */
+float gvo_pca_angle_deg(float major_y, float major_x);
 
 /* segmentGroundPlane :105-138, specified BY OUTCOME (oracle/ransac.c): counter-based RANSAC
  * with `iters` hypotheses, fp64 least-squares refinement; inlier[i] = 1 for ground points.

@@ -330,6 +330,13 @@ def pca_bbox(x, y, z):
     return bool(ok), out[0]
 
 
+def pca_angle_deg(major_y, major_x):
+    """cloud_detections.cpp:227 alone"""
+    f = lib().gvo_pca_angle_deg
+    f.restype = C.c_float
+    return float(f(C.c_float(major_y), C.c_float(major_x)))
+
+
 def generate_bins(n):
     o = np.zeros(n, dtype=np.float32)
     lib().gvo_generate_bins(C.c_int32(n), _p(o, C.c_float))

@@ -138,3 +138,16 @@ def test_k_inverse_closed_form():
     exp = np.array([[1 / 320.0, 0, -1.0], [0, 1 / 320.0, -0.75], [0, 0, 1.0]])
     assert np.allclose(Ki, exp, rtol=0, atol=1e-15)
     assert np.allclose(Ki @ K.reshape(3, 3), np.eye(3), atol=1e-12)
+
+
+def test_pca_angle_promotion_canaries():
+    """cloud_detections.cpp:227 `std::atan2(major.y, major.x) * 180.0f / CV_PI`: the float product is divided by the
+    DOUBLE CV_PI and narrowed once.  At (2, 1) and (5, 12) that differs from an all-float division by one ulp
+    (63.43495 vs 63.434948, 22.619865 vs 22.619864): the round-3 restatement used the float form."""
+    f = np.float32
+    for my, mx, want, float_form in ((2.0, 1.0, 63.43495, 63.434948), (5.0, 12.0, 22.619865, 22.619864)):
+        got = f(ol.pca_angle_deg(my, mx))
+        assert got == f(want) and got != f(float_form)
+        prod = f(f(np.arctan2(f(my), f(mx))) * f(180.0))
+        assert got == f(np.float64(prod) / 3.1415926535897932384626433832795)
+    assert ol.pca_angle_deg(0.0, 1.0) == 0.0 and f(ol.pca_angle_deg(1.0, 0.0)) == f(90.0)
