@@ -227,6 +227,7 @@ struct gv_context {
   size_t sh_xchg_cap = 0;
   hipStream_t stream_x = nullptr; // the exchanges of the sharded frame (created by gv_comm_init)
   hipEvent_t ev_sh[kRing][5]{};   // per frame slot: binning, exchange 1, sectors + packing, exchange 2, grid pass done
+  int sh_counts_slot[kStreams]{-1, -1, -1, -1};   // ev_fin slot of the lane's last sharded KEEP_COUNTS frame (its x3 reduces hits_s[lane] in place)
   hipEvent_t sh_t[7]{};           // stage timing of the sharded frame (gv_time_frame_sharded_stages)
 
   hipEvent_t ev[kNumStages + 1]{};
@@ -290,6 +291,7 @@ int drain(gv_context *h)
   h->cloud_wait = false;
   for (auto &c : h->cloud) { c.seen = ~0u; c.release_slot = -1; }   // every upload landed, every reader finished
   for (auto &d : h->det) { d.seen = ~0u; d.release_slot = -1; d.readers = 0; }
+  for (int &q : h->sh_counts_slot) q = -1;
   return GV_OK;
 }
 
@@ -1177,6 +1179,14 @@ int enqueue_frame_sharded(gv_context *h, hipEvent_t *te)
   if ((rc = ensure_shard_scratch(h, h->world))) return rc;
   const int slot = (int)(h->frame_no % (uint64_t)gv_context::kRing);
   hipEvent_t *ev = h->ev_sh[slot];
+  // Step x3 of a KEEP_COUNTS frame reduces hits_s[k] IN PLACE on the exchange stream, and nothing else orders this
+  // lane's next tile pass -- which rewrites every cell of hits_s[k] -- behind it (the buffer-set back-pressure is
+  // four frames deep, the lane comes round every second frame).  The lane waits for that frame's last exchange
+  // (round-3 advisor finding; test_sharded_keep_counts_frames_in_flight).
+  if (h->sh_counts_slot[k] >= 0) {
+    GV_HIP(hipStreamWaitEvent(s, h->ev_fin[h->sh_counts_slot[k]], 0));
+    h->sh_counts_slot[k] = -1;
+  }
   if (te) GV_HIP(hipEventRecord(te[0], s));
   // --- lane: rectangles + binning of this rank's points into private end bitmaps
   Rect *rects = h->x_rects[p];
@@ -1279,6 +1289,7 @@ int enqueue_frame_sharded(gv_context *h, hipEvent_t *te)
   h->cell_idx = h->cell_idx_s[k];
   h->have_cell_idx = keep_cell;
   h->have_bbox_id = do_bbox;
+  if (keep_counts) h->sh_counts_slot[k] = slot;
   h->have_hits = keep_counts;   // band totals at this rank's band rows (gv_comm_band)
   h->have_miss = false;         // free-cell bitmaps are complete for this rank's band only
   return GV_OK;
@@ -1353,14 +1364,25 @@ int gv_create(gv_handle *out, uint8_t grid_x, uint8_t grid_y, double resolution,
     GV_C(hipMalloc(reinterpret_cast<void **>(&probe), 256));
     std::vector<hipStream_t> rejected;
     launch_hold(1ull, h->stream);   // (the kernel's code object is loaded before anything is timed)
+    // Only the handle's own streams are synchronised (a device-wide wait would stall on, and be perturbed by, every
+    // other handle or application stream of the process); a stream's hardware queue is created on its first use, so
+    // one untimed memset goes first.  Costs 0.3-1 ms per gv_create; GV_QUEUE_PROBE=0 skips it.
+    auto sync_own = [&]() -> hipError_t {
+      for (hipStream_t q : {h->stream, h->stream2, h->stream3, h->stream_copy}) {
+        const hipError_t e = hipStreamSynchronize(q);
+        if (e != hipSuccess) return e;
+      }
+      return hipSuccess;
+    };
     for (int attempt = 0; attempt < 6; ++attempt) {
-      GV_C(hipDeviceSynchronize());
+      GV_C(hipMemsetAsync(probe, 0, 4, h->stream_copy));   // untimed: the queue exists afterwards
+      GV_C(sync_own());
       for (hipStream_t q : {h->stream, h->stream2, h->stream3}) launch_hold(15000ull, q);   // 150 us at 100 MHz
       const auto t0 = std::chrono::steady_clock::now();
       GV_C(hipMemsetAsync(probe, 0, 4, h->stream_copy));
       GV_C(hipStreamSynchronize(h->stream_copy));
       const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
-      GV_C(hipDeviceSynchronize());
+      GV_C(sync_own());
       h->upload_probe_us = us;
       if (us < 90.0) break;
       h->upload_stream_retries++;
@@ -1804,7 +1826,9 @@ int gv_cloud_upload_wait(gv_handle h)
   if (!h) return GV_ERR_BAD_ARG;
   int rc = set_device_only(h);
   if (rc) return rc;
-  GV_HIP(hipStreamSynchronize(h->stream_copy));
+  // the clouds' own `ready` events, not the upload stream: the third lane's frames run on that stream too and are
+  // none of this call's business (round-3 advisor finding)
+  for (auto &c : h->cloud) GV_HIP(hipEventSynchronize(c.ready));
   return GV_OK;
 }
 
@@ -2373,7 +2397,9 @@ static int begin_result(gv_context *h, size_t bytes, CallDone &done)
     if (h->res_host) { GV_HIP(hipHostFree(h->res_host)); h->res_host = nullptr; }
     h->res_cap = 0;
     const size_t want = std::max<size_t>(2 * (bytes + kResHeader), 16384);
-    GV_HIP(hipHostMalloc(reinterpret_cast<void **>(&h->res_host), want, hipHostMallocDefault));
+    // coherent (fine-grained) explicitly: the host must see the payload and the flag while the kernel that stores them
+    // is still running, whatever HIP_HOST_COHERENT says
+    GV_HIP(hipHostMalloc(reinterpret_cast<void **>(&h->res_host), want, hipHostMallocCoherent | hipHostMallocMapped));
     std::memset(h->res_host, 0, want);
     h->res_cap = want;
   }
@@ -2388,6 +2414,13 @@ static int begin_result(gv_context *h, size_t bytes, CallDone &done)
   return GV_OK;
 }
 
+static inline void cpu_relax()
+{
+#if !defined(__HIP_DEVICE_COMPILE__) && (defined(__x86_64__) || defined(__i386__))
+  __builtin_ia32_pause();
+#endif
+}
+
 // Host side of CallDone: spin on the block's first word.  The stream is looked at now and then so that a call
 // whose kernels failed ends in an error instead of a hang.
 static int wait_result(gv_context *h)
@@ -2396,6 +2429,7 @@ static int wait_result(gv_context *h)
   const unsigned seq = h->res_seq;
   for (unsigned spins = 1;; ++spins) {
     if (*flag == seq) break;
+    cpu_relax();   // the calls take 80-400 us: leave the core's other thread its issue slots
     if ((spins & 0xfffu) == 0u) {
       const hipError_t q = hipStreamQuery(h->stream);
       if (q == hipErrorNotReady) continue;

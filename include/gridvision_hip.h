@@ -89,7 +89,9 @@ typedef struct {
  * uint8_t grid_y, double resolution)  include/grid_vision/occupancy_grid.hpp:16,
  * src/occupancy_grid.cpp:4-14, plus object_detection::setIntrinsicMatrix /
  * computeKInverse (src/object_detection.cpp:241-249) from cam.  device_id < 0
- * picks the current device. */
+ * picks the current device.  The call also makes sure the handle's upload stream has a hardware queue of its own
+ * (a process gets four; profiles/r03/h2d_notes.md 6): three 150 us idle kernels + a timed 4-byte memset, only the
+ * handle's own streams are waited for; 0.3-1 ms per handle, GV_QUEUE_PROBE=0 in the environment skips it. */
 int gv_create(gv_handle *out, uint8_t grid_x, uint8_t grid_y, double resolution,
               const gv_cam_params *cam, int device_id);
 int gv_destroy(gv_handle h);
@@ -130,7 +132,8 @@ int gv_cloud_upload_pointcloud2(gv_handle h, const uint8_t *data, size_t n, uint
 int gv_cloud_upload_xyz_async(gv_handle h, const float *x, const float *y, const float *z, size_t n);
 int gv_cloud_upload_pointcloud2_async(gv_handle h, const uint8_t *data, size_t n, uint32_t point_step,
                                       uint32_t off_x, uint32_t off_y, uint32_t off_z);
-/* wait until every upload enqueued so far has left the host buffers */
+/* wait until every upload enqueued so far has left the host buffers (the clouds' own completion events: frames
+ * that run on the upload stream -- the third lane -- are not waited for) */
 int gv_cloud_upload_wait(gv_handle h);
 /* page-locked host memory for the *_async uploads (hipHostMalloc / hipHostFree) */
 int gv_host_alloc(void **ptr, size_t bytes);

@@ -689,6 +689,42 @@ def test_sharded_frame_world1_matches_plain(gvamd):
     ha.close(); hb.close()
 
 
+def test_sharded_keep_counts_frames_in_flight(gvamd):
+    """Round-3 advisor finding: step x3 of a sharded KEEP_COUNTS frame reduces the lane's hits[] in place on the
+    exchange stream, and the lane's next tile pass (two frames later) rewrites every cell of it.  Six asynchronous
+    KEEP_COUNTS frames over DIFFERENT clouds, nothing synchronised in between: the counts read afterwards are the
+    last frame's, bit-exact against the oracle, and the grid is the six-frame sequence's."""
+    config = 2
+    g = synth.CONFIGS[config]["grid"]
+    og = ol.OGrid(g.grid_x, g.grid_y, g.resolution)
+    h, tfs = make_handle(gvamd, config, perturbed=True)
+    h.comm_init(gvamd.GridVisionHIP.comm_unique_id(), 0, 1)
+    flags = gvamd.FRAME_BIN | gvamd.FRAME_RAYMARCH | gvamd.FRAME_KEEP_COUNTS
+    h.set_detections(flags)
+    clouds = []
+    for f in range(6):
+        gen = synth.cloud_lidar_like if f % 2 else synth.cloud_uniform
+        x, y, z, _ = gen(config, 200_000 + 10_000 * f, seed_extra=40 + f)
+        pin = [gvamd.PinnedF32(len(x)) for _ in range(3)]
+        for p, a in zip(pin, (x, y, z)):
+            p.array[:] = a
+        clouds.append((x, y, z, pin))
+    hits = None
+    for x, y, z, pin in clouds:
+        h.upload_xyz_async(pin[0].array, pin[1].array, pin[2].array)
+        h.enqueue_frame_sharded()
+        hits, _, _, _, _ = oracle_frame(og, tfs, x, y, z)
+    h.synchronize()
+    assert np.array_equal(h.hits(), hits)
+    nlo, _, _ = check_grid(h, og)
+    assert nlo == 0
+    h.comm_destroy()
+    h.close()
+    for _, _, _, pin in clouds:
+        for p in pin:
+            p.close()
+
+
 @pytest.mark.parametrize("world", [2, 3, 8])
 @pytest.mark.parametrize("grid,n", [((200, 200, 0.2), 90_000), ((120, 200, 0.25), 50_001)])
 def test_sharded_frame_every_rank_emulated(gvamd, world, grid, n):

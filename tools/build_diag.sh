@@ -4,8 +4,11 @@
 set -e
 cd "$(dirname "$0")/.."
 mkdir -p tools/_diag
-cd grid-vision_amd/csrc
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-fast-math -fPIC -shared -Wall \
-  -Wno-unused-function -Wno-bitwise-instead-of-logical -DGV_DIAG -o ../../tools/_diag/libgv_diag.so gv_api.hip gv_kernels.hip gv_binning.hip \
-  gv_raysector.hip gv_shard.hip gv_knn_pca.hip gv_cloudops.hip -L/opt/rocm/lib -lrccl
-echo built tools/_diag/libgv_diag.so
+python3 - <<'PY'
+import os, sys
+sys.path.insert(0, "grid-vision_amd")
+from gvamd import build as b
+root = os.getcwd()
+print("built", b.build(lib=os.path.join(root, "tools/_diag/libgv_diag.so"), extra=["-DGV_DIAG"],
+                       obj_dir=os.path.join(root, "tools/_diag/obj")))
+PY
