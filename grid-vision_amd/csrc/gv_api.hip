@@ -217,6 +217,19 @@ struct gv_context {
   unsigned *d_res_ticket = nullptr;
   unsigned res_seq = 0;
 
+  // the node's tick (gv_tick_enqueue / gv_tick_wait): what the pending tick put where in the result block
+  struct Tick {
+    bool pending = false;
+    uint32_t flags = 0;
+    int32_t n_all = 0, n_static = 0, n_dynamic = 0;
+    bool pca_ran = false, vision_ran = false, knn_ran = false;
+    size_t off_depth = 0, off_pose = 0, off_vout = 0;
+    std::vector<gv_bbox> st_boxes;   // the static boxes (host copy: convertPixelsTo3D after the wait)
+    hipEvent_t done = nullptr;       // public stream: everything the tick enqueued has finished
+    hipEvent_t fork = nullptr, join = nullptr;   // the kNN depth on a lane beside the pose branch
+  } tick;
+  bool env_tick_knn_lane = true;   // GV_TICK_KNN_LANE=0: the static boxes' kNN in line on the public stream
+
   bool counts_dirty = false;   // generic path: hits/miss/clip_end hold a kept frame
   bool have_hits = false, have_miss = false, have_cell_idx = false, have_bbox_id = false;
 
@@ -507,9 +520,15 @@ BBoxTest bbox_test_of(const gv_context *h, const DetSet &d)
 // masks = false: the caller's kernels read the raw boxes / poses only (kNN depth, vision orientation, plain pose
 // update) -- the thresholds and tile masks of the bbox test are not rebuilt, and whoever tests points against this
 // set uploads it again first (every such call does).
+// n_net >= 0: the network outputs cover n_net boxes (default: nb).  nb_test >= 0: the bbox test -- thresholds, tile
+// masks, d.nb -- covers the first nb_test boxes only; what follows them in the block is read by other kernels (the
+// tick keeps [all | static | dynamic] boxes in one block: one copy).
 int upload_det(gv_context *h, DetSet &d, const gv_bbox *bboxes, int32_t nb, const gv_lshape_pose *poses,
-               int32_t n_poses, const float *orient, const float *conf, const float *dims, hipStream_t s, bool masks = true)
+               int32_t n_poses, const float *orient, const float *conf, const float *dims, hipStream_t s, bool masks = true,
+               int32_t n_net = -1, int32_t nb_test = -1)
 {
+  if (n_net < 0) n_net = nb;
+  if (nb_test < 0) nb_test = nb;
   int rc = ensure_det(h, d, std::max(nb, n_poses));
   if (rc) return rc;
   if ((rc = ensure_det_shared(h, std::max(nb, n_poses)))) return rc;
@@ -523,14 +542,14 @@ int upload_det(gv_context *h, DetSet &d, const gv_bbox *bboxes, int32_t nb, cons
   };
   put(L.bboxes, bboxes, (size_t)nb * sizeof(gv_bbox));
   put(L.poses, poses, (size_t)n_poses * sizeof(gv_lshape_pose));
-  if (orient) put(L.orient, orient, (size_t)nb * 4 * sizeof(float));
-  if (conf) put(L.conf, conf, (size_t)nb * 2 * sizeof(float));
-  if (dims) put(L.dims, dims, (size_t)nb * 3 * sizeof(float));
+  if (orient) put(L.orient, orient, (size_t)n_net * 4 * sizeof(float));
+  if (conf) put(L.conf, conf, (size_t)n_net * 2 * sizeof(float));
+  if (dims) put(L.dims, dims, (size_t)n_net * 3 * sizeof(float));
   if (used) GV_HIP(hipMemcpyAsync(d.block, d.stage, used, hipMemcpyHostToDevice, s));
-  d.mask_words = std::max(1, (nb + 63) / 64);
-  if (masks) launch_bbox_prepare(d.bboxes, nb, h->bt_tiles_x, h->bt_tiles_y, d.mask_words, d.bbox_f, d.tile_mask, s);
+  d.mask_words = std::max(1, (nb_test + 63) / 64);
+  if (masks) launch_bbox_prepare(d.bboxes, nb_test, h->bt_tiles_x, h->bt_tiles_y, d.mask_words, d.bbox_f, d.tile_mask, s);
   GV_HIP(hipGetLastError());
-  d.nb = nb;
+  d.nb = nb_test;
   d.n_poses = n_poses;
   d.valid = true;
   return GV_OK;
@@ -1299,7 +1318,7 @@ int enqueue_frame_sharded(gv_context *h, hipEvent_t *te)
 
 extern "C" {
 
-int gv_abi_version(void) { return 3; }
+int gv_abi_version(void) { return 4; }
 
 int gv_create(gv_handle *out, uint8_t grid_x, uint8_t grid_y, double resolution, const gv_cam_params *cam,
               int device_id)
@@ -1406,6 +1425,10 @@ int gv_create(gv_handle *out, uint8_t grid_x, uint8_t grid_y, double resolution,
   for (auto &e : h->ev_fin) GV_C(hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventDisableSystemFence));
   for (auto &e : h->ev_sec) GV_C(hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventDisableSystemFence));
   GV_C(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+  GV_C(hipEventCreateWithFlags(&h->tick.done, hipEventDisableTiming));
+  GV_C(hipEventCreateWithFlags(&h->tick.fork, hipEventDisableTiming));
+  GV_C(hipEventCreateWithFlags(&h->tick.join, hipEventDisableTiming));
+  if (const char *e = std::getenv("GV_TICK_KNN_LANE")) h->env_tick_knn_lane = std::atoi(e) != 0;
   for (auto &c : h->cloud) GV_C(hipEventCreateWithFlags(&c.ready, hipEventDisableTiming));
   for (auto &d : h->det) GV_C(hipEventCreateWithFlags(&d.ready, hipEventDisableTiming));
   const size_t G = (size_t)g.G;
@@ -1589,6 +1612,8 @@ int gv_destroy(gv_handle h)
   for (auto &e : h->ev_sec)
     if (e) (void)hipEventDestroy(e);
   if (h->ev_join) (void)hipEventDestroy(h->ev_join);
+  for (hipEvent_t e : {h->tick.done, h->tick.fork, h->tick.join})
+    if (e) (void)hipEventDestroy(e);
   for (hipStream_t s : {h->stream4, h->stream3, h->stream2, h->stream_copy, h->stream})
     if (s) (void)hipStreamDestroy(s);
   delete h;
@@ -1912,12 +1937,9 @@ int gv_extract_cloud_per_bbox(gv_handle h, const gv_bbox *bboxes, int32_t nb, in
   GV_CATCH
 }
 
-int gv_convert_pixels_to_3d(gv_handle h, const gv_bbox *bboxes, const float *depths, int32_t nb,
-                            double *base_points_xyz)
+// convertPixelsTo3D (grid_vision_node.cpp:309-335): B points, fp64, on the host
+static void convert_pixels_host(const gv_context *h, const gv_bbox *bboxes, const float *depths, int32_t nb, double *base_points_xyz)
 {
-  if (!h || nb < 0 || (nb && (!bboxes || !depths || !base_points_xyz))) return GV_ERR_BAD_ARG;
-  if (!h->has_bc) return GV_ERR_TF;
-  GV_TRY
   for (int32_t i = 0; i < nb; ++i) {
     // grid_vision_node.cpp:320-322 pixel centre (cv::Point2f), :325 pixelTo3D, :328-329 to base
     const float pcx = (float)(bboxes[i].x_min + ((bboxes[i].x_max - bboxes[i].x_min) / 2.0f));
@@ -1929,6 +1951,26 @@ int gv_convert_pixels_to_3d(gv_handle h, const gv_bbox *bboxes, const float *dep
       cam[r] = d * ((h->Kinv[r * 3] * hx + h->Kinv[r * 3 + 1] * hy) + h->Kinv[r * 3 + 2] * hz);   // cloud_detections.cpp:95
     host::apply(h->x_bc, cam, &base_points_xyz[3 * i]);
   }
+}
+
+// camera-frame pose of one VisionOut (vision_orientation.cpp:432-444)
+static gv_lshape_pose pose_of_vision_out(const VisionOut &vo)
+{
+  gv_lshape_pose p;
+  p.px = vo.loc[0]; p.py = vo.loc[1]; p.pz = vo.loc[2];     // :434-436
+  const host::Quat q = host::quat_from_rpy(0, -vo.orient, 0);   // :440
+  p.qx = q.x; p.qy = q.y; p.qz = q.z; p.qw = q.w;
+  p.length = vo.dims[0]; p.width = vo.dims[1]; p.height = vo.dims[2];
+  return p;
+}
+
+int gv_convert_pixels_to_3d(gv_handle h, const gv_bbox *bboxes, const float *depths, int32_t nb,
+                            double *base_points_xyz)
+{
+  if (!h || nb < 0 || (nb && (!bboxes || !depths || !base_points_xyz))) return GV_ERR_BAD_ARG;
+  if (!h->has_bc) return GV_ERR_TF;
+  GV_TRY
+  convert_pixels_host(h, bboxes, depths, nb, base_points_xyz);
   return GV_OK;
   GV_CATCH
 }
@@ -1953,12 +1995,7 @@ int gv_vision_post_process(gv_handle h, const float *orient, const float *conf, 
   int32_t m = 0;
   for (int32_t i = 0; i < nb; ++i) {
     if (!vo[i].valid) continue;   // vision_orientation.cpp:496-499
-    gv_lshape_pose p;
-    p.px = vo[i].loc[0]; p.py = vo[i].loc[1]; p.pz = vo[i].loc[2];     // :434-436
-    const host::Quat q = host::quat_from_rpy(0, -vo[i].orient, 0);       // :440
-    p.qx = q.x; p.qy = q.y; p.qz = q.z; p.qw = q.w;
-    p.length = vo[i].dims[0]; p.width = vo[i].dims[1]; p.height = vo[i].dims[2];
-    poses_out[m++] = p;
+    poses_out[m++] = pose_of_vision_out(vo[i]);
   }
   *n_out = m;
   return GV_OK;
@@ -2505,7 +2542,10 @@ static size_t pose_block_bytes(int32_t nb) { return pose_block_valid_off(nb) + (
 // without a host wait in between; only the nb poses come back.  with_ground: the points of the refined RANSAC
 // plane in *d_rstate are dropped first (computeBBoxPose, cloud_detections.cpp:300-321), and the "empty segmented
 // cloud" outcomes (:307-309) are decided on the device.
-static int enqueue_bbox_pose(gv_context *h, int32_t nb, bool with_ground, float thr_f, uint8_t *out, const CallDone &done)
+// poses_dev (optional): the camera-frame poses also go to device memory (length < 0 marks "no pose": what
+// k_rects_from_poses skips), for a map update enqueued right behind this without a trip to the host.
+static int enqueue_bbox_pose(gv_context *h, int32_t nb, bool with_ground, float thr_f, uint8_t *out, const CallDone &done,
+                             gv_lshape_pose *poses_dev = nullptr)
 {
   const size_t n = h->n;
   int rc;
@@ -2563,7 +2603,7 @@ static int enqueue_bbox_pose(gv_context *h, int32_t nb, bool with_ground, float 
   launch_split_kept(h->bbox_id, h->d_drop, h->cx, h->cy, h->cz, h->m_cam, (uint32_t)n, nb, h->d_blockcnt, h->d_segstart, h->gx, h->gy, h->gz, s);
   launch_pca_bbox(h->gx, h->gy, h->gz, h->d_segstart, nb, h->d_rstate, with_ground, (uint32_t)n,
                   reinterpret_cast<gv_lshape_pose *>(out), out + pose_block_valid_off(nb),
-                  reinterpret_cast<RansacState *>(out + (size_t)nb * sizeof(gv_lshape_pose)), done, s);
+                  reinterpret_cast<RansacState *>(out + (size_t)nb * sizeof(gv_lshape_pose)), done, s, poses_dev);
   GV_HIP(hipGetLastError());
   return GV_OK;
 }
@@ -2879,6 +2919,185 @@ int gv_debug_frame_sharded_emulated(gv_handle h, const gv_frame_desc *desc, int3
   h->have_bbox_id = do_bbox;
   return rc;
   GV_CATCH
+}
+
+/* ------------------------------------------------------------ the node's tick -- */
+// GridVision::timerCallback from filterBBoxes on (grid_vision_node.cpp:153-244) as ONE batch of device work: the
+// static boxes' kNN depth (:168-184), the dynamic boxes' poses -- orientation-network geometry (:190-209) or ground
+// removal + per-box clouds + radius filter + PCA rectangle (:210-231) --, their rectangles in the base frame, the
+// map update with the int8 pack, and the packed grid's way home.  The poses never leave the device on their way
+// into the grid (k_pca_bbox / k_vision -> k_rects_from_poses(from_cam) -> grid pass); what the markers need comes
+// back through the pinned result block.  gv_tick_wait is the tick's only host wait.
+int gv_tick_enqueue(gv_handle h, const gv_tick_desc *d)
+{
+  if (!h || !d || d->n_bboxes < 0 || d->n_bboxes > 16383 || (d->n_bboxes && !d->bboxes)) return GV_ERR_BAD_ARG;
+  if (d->n_net < 0 || (d->n_net && (!d->orient || !d->conf || !d->dims))) return GV_ERR_BAD_ARG;
+  const bool vision = d->flags & GV_TICK_VISION_ORIENT;
+  const bool lidar = d->flags & GV_TICK_LIDAR_BIN, lidar_ray = d->flags & GV_TICK_LIDAR_RAYMARCH;
+  if (lidar_ray && !lidar) return GV_ERR_BAD_ARG;
+  GV_TRY
+  gv_context::Tick &T = h->tick;
+  if (T.pending) return GV_ERR_STATE;   // one tick at a time (the node's timer is single threaded, grid_vision_node.cpp:49-50)
+  const int32_t n_all = d->n_bboxes;
+  // filterBBoxes (:384-403), order preserving
+  std::vector<gv_bbox> cat((size_t)2 * n_all + 1);
+  int32_t ns = 0, nd = 0;
+  if (n_all) {
+    std::memcpy(cat.data(), d->bboxes, (size_t)n_all * sizeof(gv_bbox));
+    std::vector<gv_bbox> dy((size_t)n_all);
+    int rcf = gv_filter_bboxes(d->bboxes, n_all, cat.data() + n_all, &ns, dy.data(), &nd);
+    if (rcf) return rcf;
+    std::memcpy(cat.data() + n_all + ns, dy.data(), (size_t)nd * sizeof(gv_bbox));
+  }
+  const int32_t k = d->k_near;
+  if (ns && (k < 1 || k > 32)) return GV_ERR_BAD_ARG;
+  if (vision && d->n_net && d->n_net != nd) return GV_ERR_BAD_ARG;
+  if (n_all && (!h->has_cl || !h->has_bc)) return GV_ERR_TF;   // transformLidarToCamera / transformPoseToBaseFrame
+  if (lidar && !h->has_bl) return GV_ERR_TF;
+  if (lidar && !sector_path(h)) { h->err = "the lidar extension inside the tick needs the tile path (nx % 4 == 0)"; return GV_ERR_STATE; }
+  int rc = use_device(h);   // frames in flight finish first: the tick's work is one sequence on the public stream
+  if (rc) return rc;
+  hipStream_t s = h->stream;
+  const size_t n = h->n;
+  const bool pca = !vision && nd > 0 && n >= 3;              // computeBBoxPose on ALL boxes (:215-216)
+  const bool net = vision && nd > 0 && d->n_net == nd;       // poses only when the network ran for every dynamic box
+  DetSet &D = h->det[2];
+  if (n_all) {
+    if ((rc = upload_det(h, D, cat.data(), 2 * n_all, nullptr, 0, net ? d->orient : nullptr, net ? d->conf : nullptr,
+                         net ? d->dims : nullptr, s, pca, net ? nd : 0, n_all)))
+      return rc;
+    GV_HIP(hipEventRecord(D.ready, s));
+  }
+  // result block: depths | poses, state, valid (the PCA call's layout) | VisionOut
+  T.off_depth = 0;
+  T.off_pose = ((size_t)ns * sizeof(float) + 15) & ~(size_t)15;
+  T.off_vout = (T.off_pose + pose_block_bytes(n_all) + 15) & ~(size_t)15;
+  CallDone none;   // nothing published: the tick ends with an event on the public stream
+  if ((rc = begin_result(h, T.off_vout + (size_t)nd * sizeof(VisionOut) + 16, none))) return rc;
+  none = CallDone{};
+  uint8_t *blk = h->res_host + kResHeader;
+  // --- static boxes: buildKDTree + computeDepthForBoundingBoxes (:168-184).  Independent of the pose branch: it
+  // runs on a lane beside it and joins the public stream before the tick's last event.
+  T.knn_ran = ns > 0;
+  bool knn_forked = false;
+  if (ns > 0) {
+    if ((rc = ensure_tbuf(h, std::max<size_t>(n, 1)))) return rc;
+    if ((rc = grow(h, h->knn_partial, h->knn_partial_cap, knn_partial_entries(ns, k)))) return rc;
+    hipStream_t sk = s;
+    if (h->env_tick_knn_lane && nd > 0) {
+      sk = h->streams[1];
+      GV_HIP(hipEventRecord(T.fork, s));
+      GV_HIP(hipStreamWaitEvent(sk, T.fork, 0));
+      h->lane_clean[1] = false;
+      knn_forked = true;
+    }
+    launch_project_uvd(h->cx, h->cy, h->cz, (uint32_t)n, h->m_cam, h->camk, h->tx, h->ty, h->tz, sk);
+    launch_knn(h->tx, h->ty, h->tz, (uint32_t)n, D.bboxes + n_all, ns, k, h->knn_partial,
+               reinterpret_cast<float *>(blk + T.off_depth), nullptr, none, sk);
+    GV_HIP(hipGetLastError());
+    if (knn_forked) GV_HIP(hipEventRecord(T.join, sk));
+  }
+  // --- dynamic boxes -> camera-frame poses on the device -> rectangles
+  int32_t n_rects = 0;
+  Rect *rects = h->x_rects[0];
+  T.pca_ran = T.vision_ran = false;
+  if (net) {   // VisionOrientation::postProcessOutputs (:190-209)
+    launch_vision(D.orient, D.conf, D.dims, D.bboxes + n_all + ns, nd, h->cam, reinterpret_cast<VisionOut *>(blk + T.off_vout),
+                  D.poses, s);
+    launch_rects_from_poses(D.poses, nd, h->g, true, h->x_bc, rects, s);
+    n_rects = nd;
+    T.vision_ran = true;
+  } else if (pca) {   // cloud_detections::computeBBoxPose (:210-231)
+    const float thr_f = ceil_to_float(0.04);
+    if ((rc = ensure_ransac_buffers(h, n, 50))) return rc;
+    launch_ransac_plane(h->cx, h->cy, h->cz, (uint32_t)n, h->m_cam, thr_f, 50, 12345ull, h->d_planes, h->d_plane_counts,
+                        h->d_rscratch, h->d_rstate, s);
+    h->ground_n = 0;
+    if ((rc = enqueue_bbox_pose(h, n_all, true, thr_f, blk + T.off_pose, none, D.poses))) return rc;
+    launch_rects_from_poses(D.poses, n_all, h->g, true, h->x_bc, rects, s);
+    n_rects = n_all;
+    T.pca_ran = true;
+  }
+  GV_HIP(hipGetLastError());
+  // --- map update (:145, :206, :230, :235) + int8 pack (:265-278)
+  if (lidar && n > 0) {   // [EXTENSION] the fused frame's kernels, serial on the public stream
+    if ((rc = ensure_point_buffers(h, n))) return rc;
+    if ((rc = enqueue_binning(h, D, 0, 0, 0, n, false, lidar_ray, false, true, nullptr))) return rc;
+    if (lidar_ray && (rc = enqueue_sectors(h, 0, 0, 1, s))) return rc;
+    if ((rc = enqueue_grid_pass(h, 0, rects, n_rects, true, 0, h->g.ny, s))) return rc;
+    h->last_set = 0;
+    h->hits = h->hits_s[0];
+    h->have_hits = true;
+    h->have_miss = true;
+  } else if ((rc = enqueue_plain_update(h, n_rects)))
+    return rc;
+  if (d->grid_out) GV_HIP(hipMemcpyAsync(d->grid_out, h->occ_i8, (size_t)h->g.G, hipMemcpyDeviceToHost, s));
+  if (knn_forked) GV_HIP(hipStreamWaitEvent(s, T.join, 0));
+  GV_HIP(hipEventRecord(T.done, s));
+  T.flags = d->flags;
+  T.n_all = n_all; T.n_static = ns; T.n_dynamic = nd;
+  T.st_boxes.assign(cat.begin() + n_all, cat.begin() + n_all + ns);
+  T.pending = true;
+  return GV_OK;
+  GV_CATCH
+}
+
+int gv_tick_wait(gv_handle h, gv_tick_result *r)
+{
+  if (!h || !r) return GV_ERR_BAD_ARG;
+  GV_TRY
+  gv_context::Tick &T = h->tick;
+  if (!T.pending) return GV_ERR_STATE;
+  int rc = set_device_only(h);
+  if (rc) return rc;
+  GV_HIP(hipEventSynchronize(T.done));   // the tick's one host wait
+  T.pending = false;
+  const uint8_t *blk = h->res_host + kResHeader;
+  r->n_static = T.n_static;
+  r->n_dynamic = T.n_dynamic;
+  r->n_poses = 0;
+  r->pca_empty = 0;
+  if (T.n_static) {
+    const float *dep = reinterpret_cast<const float *>(blk + T.off_depth);
+    if (r->static_bboxes) std::memcpy(r->static_bboxes, T.st_boxes.data(), (size_t)T.n_static * sizeof(gv_bbox));
+    if (r->depths) std::memcpy(r->depths, dep, (size_t)T.n_static * sizeof(float));
+    if (r->base_points_xyz) convert_pixels_host(h, T.st_boxes.data(), dep, T.n_static, r->base_points_xyz);   // :180
+  }
+  if (T.vision_ran) {
+    const VisionOut *vo = reinterpret_cast<const VisionOut *>(blk + T.off_vout);
+    for (int32_t i = 0; i < T.n_dynamic; ++i) {
+      if (!vo[i].valid) continue;   // vision_orientation.cpp:496-499
+      gv_lshape_pose p = pose_of_vision_out(vo[i]);
+      host::transform_pose(h->tf_bc, p);   // transformLShapeObjects (:204)
+      if (r->poses) r->poses[r->n_poses] = p;
+      r->n_poses++;
+    }
+  } else if (T.pca_ran) {
+    const gv_lshape_pose *ps = reinterpret_cast<const gv_lshape_pose *>(blk + T.off_pose);
+    RansacState st;
+    std::memcpy(&st, blk + T.off_pose + (size_t)T.n_all * sizeof(gv_lshape_pose), sizeof(st));
+    const uint8_t *valid = blk + T.off_pose + pose_block_valid_off(T.n_all);
+    const uint64_t m = st.best_count ? st.n_inliers : 0;
+    if (m == 0 || (size_t)m == h->n) r->pca_empty = 1;   // empty segmented cloud: computeBBoxPose returns {} (:307-309)
+    else
+      for (int32_t b = 0; b < T.n_all; ++b) {
+        if (!valid[b]) continue;   // :174-175
+        gv_lshape_pose p = ps[b];
+        host::transform_pose(h->tf_bc, p);   // transformLShapeObjects (:227)
+        if (r->poses) r->poses[r->n_poses] = p;
+        r->n_poses++;
+      }
+  } else if (!(T.flags & GV_TICK_VISION_ORIENT) && T.n_dynamic > 0)
+    r->pca_empty = 1;   // fewer than three points: no plane, no poses
+  return GV_OK;
+  GV_CATCH
+}
+
+int gv_tick(gv_handle h, const gv_tick_desc *d, gv_tick_result *r)
+{
+  int rc = gv_tick_enqueue(h, d);
+  if (rc) return rc;
+  return gv_tick_wait(h, r);
 }
 
 int gv_comm_band(gv_handle h, int64_t *begin, int64_t *end)

@@ -975,7 +975,8 @@ __global__ void __launch_bounds__(64) k_pca_bbox(const float *__restrict__ gx, c
                                                  const float *__restrict__ gz, const int32_t *__restrict__ seg_start, int nb,
                                                  const RansacState *__restrict__ st, int use_plane, uint32_t n_cloud,
                                                  gv_lshape_pose *__restrict__ poses, uint8_t *__restrict__ valid,
-                                                 RansacState *__restrict__ st_copy, CallDone done)
+                                                 RansacState *__restrict__ st_copy, CallDone done,
+                                                 gv_lshape_pose *__restrict__ poses_dev)
 {
   __shared__ __attribute__((aligned(16))) float s_t[2][3][kPcaTile];    // [buffer][y | z | x][point]
   __shared__ __attribute__((aligned(16))) double s_p[2][3][kPcaTile];   // [buffer][aa | ab | bb][point]
@@ -990,6 +991,11 @@ __global__ void __launch_bounds__(64) k_pca_bbox(const float *__restrict__ gx, c
     if (lane == 0) {
       valid[b] = 0;
       poses[b] = gv_lshape_pose{};
+      if (poses_dev) {
+        gv_lshape_pose none{};
+        none.length = -1.0;   // k_rects_from_poses skips it
+        poses_dev[b] = none;
+      }
       call_done(done, gridDim.x);
     }
     return;
@@ -1111,6 +1117,7 @@ __global__ void __launch_bounds__(64) k_pca_bbox(const float *__restrict__ gx, c
     p.width = maxW - minW;    // :219,:244
     p.height = 0.0;           // never set on this path in the reference
     poses[b] = p;
+    if (poses_dev) poses_dev[b] = p;
     valid[b] = 1;
     call_done(done, gridDim.x);
   }
@@ -1130,11 +1137,11 @@ void launch_split_kept(const int16_t *ids, const uint8_t *drop, const float *x, 
 
 void launch_pca_bbox(const float *gx, const float *gy, const float *gz, const int32_t *seg_start, int nb, const RansacState *st,
                      bool use_plane, uint32_t n_cloud, gv_lshape_pose *poses, uint8_t *valid, RansacState *st_copy,
-                     const CallDone &done, hipStream_t s)
+                     const CallDone &done, hipStream_t s, gv_lshape_pose *poses_dev)
 {
   if (nb <= 0) return;
   hipLaunchKernelGGL(k_pca_bbox, dim3(nb), dim3(64), 0, s, gx, gy, gz, seg_start, nb, st, use_plane ? 1 : 0, n_cloud, poses, valid,
-                     st_copy, done);
+                     st_copy, done, poses_dev);
 }
 
 }  // namespace gv

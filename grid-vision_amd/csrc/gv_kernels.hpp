@@ -285,8 +285,9 @@ void launch_radius_filter(const float *x, const float *y, const float *z, uint32
 void launch_split_kept(const int16_t *ids, const uint8_t *drop, const float *x, const float *y, const float *z, const Mat34f &m_cam,
                        uint32_t n, int nb, uint32_t *block_counts, int32_t *seg_start, float *gx, float *gy, float *gz, hipStream_t s);
 // st_copy (optional): *st is copied there by the kernel (one read-back block for poses, flags and state)
+// poses_dev (optional, device memory): a second copy of the camera-frame poses with length = -1 where valid[b] == 0
 void launch_pca_bbox(const float *gx, const float *gy, const float *gz, const int32_t *seg_start, int nb, const RansacState *st,
                      bool use_plane, uint32_t n_cloud, gv_lshape_pose *poses, uint8_t *valid, RansacState *st_copy,
-                     const CallDone &done, hipStream_t s);
+                     const CallDone &done, hipStream_t s, gv_lshape_pose *poses_dev = nullptr);
 
 }  // namespace gv

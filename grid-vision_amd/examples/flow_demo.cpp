@@ -18,9 +18,12 @@ static uint64_t sm64(uint64_t &s)
 }
 static float u01(uint64_t &s) { return (float)(sm64(s) >> 40) * (1.0f / 16777216.0f); }
 
-int main()
+int main(int argc, char **argv)
 {
   using namespace grid_vision;
+  // "0": the reference's call-by-call sequence (one synchronous call per reference function); default: the fused
+  // tick (gv_tick_*: one batch of device work, one host wait).  Both must print the same lines.
+  const bool fused = !(argc > 1 && argv[1][0] == '0');
   try {
     const CAMParams cam{224, 224, 480, 640, 320.f, 320.f, 320.f, 240.f};   // config/grid_vision_cfg.yaml
     GridVisionContext ctx(50, 20, 0.1, cam);
@@ -65,6 +68,7 @@ int main()
     };
 
     FlowParams pv;                        // yaml defaults: vision orientation
+    pv.fused = fused;
     FlowParams pp = pv;
     pp.use_vision_orientation = false;    // PCA branch
     FrameFlow flow_v(ctx, occ_grid, pv), flow_p(ctx, occ_grid, pp);

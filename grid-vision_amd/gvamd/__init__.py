@@ -25,6 +25,10 @@ FRAME_KEEP_CELL_IDX = 1 << 3
 FRAME_KEEP_COUNTS = 1 << 4
 FRAME_VISION_ORIENT = 1 << 5
 
+TICK_VISION_ORIENT = 1 << 0
+TICK_LIDAR_BIN = 1 << 1
+TICK_LIDAR_RAYMARCH = 1 << 2
+
 STAGES = ("detections", "points", "ray_ends", "ray_march", "finalize")
 
 # every symbol include/gridvision_hip.h declares
@@ -44,7 +48,7 @@ ABI_SYMBOLS = [
     "gv_cloud_upload_xyz_async", "gv_cloud_upload_pointcloud2_async", "gv_cloud_upload_wait", "gv_host_alloc",
     "gv_host_free", "gv_frame_set_detections_async", "gv_frame_fence", "gv_debug_frame_sharded_emulated",
     "gv_to_occupancy_grid_async", "gv_frame_enqueue_sharded", "gv_time_frame_sharded_stages", "gv_shard_band_rows",
-    "gv_shard_slice_words", "gv_device_layers",
+    "gv_shard_slice_words", "gv_device_layers", "gv_tick_enqueue", "gv_tick_wait", "gv_tick",
 ]
 
 
@@ -67,6 +71,41 @@ class FrameDesc(C.Structure):
     _fields_ = [("flags", C.c_uint32), ("bboxes", C.c_void_p), ("n_bboxes", C.c_int32),
                 ("poses", C.c_void_p), ("n_poses", C.c_int32), ("orient", C.c_void_p),
                 ("conf", C.c_void_p), ("dims", C.c_void_p)]
+
+
+class TickDesc(C.Structure):
+    _fields_ = [("flags", C.c_uint32), ("bboxes", C.c_void_p), ("n_bboxes", C.c_int32), ("orient", C.c_void_p),
+                ("conf", C.c_void_p), ("dims", C.c_void_p), ("n_net", C.c_int32), ("k_near", C.c_int32),
+                ("grid_out", C.c_void_p)]
+
+
+class TickResult(C.Structure):
+    _fields_ = [("n_static", C.c_int32), ("n_dynamic", C.c_int32), ("static_bboxes", C.c_void_p), ("depths", C.c_void_p),
+                ("base_points_xyz", C.c_void_p), ("poses", C.c_void_p), ("n_poses", C.c_int32), ("pca_empty", C.c_int32)]
+
+
+class PinnedI8:
+    """int8 array in page-locked host memory: the packed grid's landing place (gv_tick grid_out, gv_to_occupancy_grid_async)"""
+
+    def __init__(self, n):
+        self._lib = load()
+        self._p = C.c_void_p()
+        rc = self._lib.gv_host_alloc(C.byref(self._p), C.c_size_t(max(int(n), 1)))
+        if rc:
+            raise GVError(rc, "gv_host_alloc")
+        self.array = np.ctypeslib.as_array(C.cast(self._p, C.POINTER(C.c_int8)), shape=(int(n),))
+
+    def close(self):
+        if self._p:
+            self.array = None
+            self._lib.gv_host_free(self._p)
+            self._p = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class GVError(RuntimeError):
@@ -442,6 +481,42 @@ class GridVisionHIP:
         a, b = C.c_uint64(0), C.c_uint64(0)
         self._ck(self._lib.gv_get_ray_stats(self._h, C.byref(a), C.byref(b)), "ray_stats")
         return a.value, b.value
+
+    # ---- the node's tick (timerCallback from filterBBoxes on, one host wait)
+    def tick_enqueue(self, bboxes, k_near=4, net=None, vision=False, lidar_bin=False, lidar_raymarch=False, grid_out=None):
+        """net: (orient, conf, dims) of the DYNAMIC boxes in filter_bboxes order (vision=True); grid_out: PinnedI8 array"""
+        b = np.ascontiguousarray(bboxes if bboxes is not None else np.zeros(0, BBOX_DTYPE), dtype=BBOX_DTYPE)
+        d = TickDesc()
+        d.flags = (TICK_VISION_ORIENT if vision else 0) | (TICK_LIDAR_BIN if lidar_bin else 0) | (TICK_LIDAR_RAYMARCH if lidar_raymarch else 0)
+        d.bboxes, d.n_bboxes = (b.ctypes.data if len(b) else None), len(b)
+        keep = [b]
+        if net is not None:
+            o, c, dm = (_f32(t) for t in net)
+            keep += [o, c, dm]
+            d.orient, d.conf, d.dims, d.n_net = o.ctypes.data, c.ctypes.data, dm.ctypes.data, len(o.reshape(-1, 4))
+        d.k_near = k_near
+        if grid_out is not None:
+            assert grid_out.dtype == np.int8 and grid_out.size == self.G
+            d.grid_out = grid_out.ctypes.data
+        self._tick_keep = keep
+        self._tick_nb = len(b)
+        self._ck(self._lib.gv_tick_enqueue(self._h, C.byref(d)), "gv_tick_enqueue")
+
+    def tick_wait(self):
+        nb = max(self._tick_nb, 1)
+        st = np.zeros(nb, dtype=BBOX_DTYPE)
+        depths = np.zeros(nb, np.float32)
+        pts = np.zeros((nb, 3), np.float64)
+        poses = np.zeros(nb, dtype=LSHAPE_DTYPE)
+        r = TickResult()
+        r.static_bboxes, r.depths, r.base_points_xyz, r.poses = st.ctypes.data, depths.ctypes.data, pts.ctypes.data, poses.ctypes.data
+        self._ck(self._lib.gv_tick_wait(self._h, C.byref(r)), "gv_tick_wait")
+        return {"n_static": r.n_static, "n_dynamic": r.n_dynamic, "static_bboxes": st[:r.n_static], "depths": depths[:r.n_static],
+                "base_points": pts[:r.n_static], "poses": poses[:r.n_poses], "pca_empty": bool(r.pca_empty)}
+
+    def tick(self, bboxes, **kw):
+        self.tick_enqueue(bboxes, **kw)
+        return self.tick_wait()
 
     # ---- multi-GPU (RCCL inside the library)
     @staticmethod

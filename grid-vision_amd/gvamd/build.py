@@ -14,7 +14,7 @@ CSRC = os.path.join(PKG, "csrc")
 OBJ = os.path.join(PKG, "build")
 LIB = os.path.join(PKG, "libgridvision_hip.so")
 SOURCES = ["gv_api.hip", "gv_kernels.hip", "gv_binning.hip", "gv_raysector.hip", "gv_shard.hip", "gv_knn_pca.hip",
-           "gv_cloudops.hip", "gv_tick.hip"]
+           "gv_cloudops.hip"]
 # -ffp-contract=off: cell indices must be bit-exact with the reference's separate
 # multiply/add roundings; no fast-math anywhere.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math",

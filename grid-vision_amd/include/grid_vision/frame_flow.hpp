@@ -24,6 +24,10 @@ struct FlowParams {
   // [EXTENSION] (ros2/config: lidar_binning, lidar_raymarch) the map update of a tick is one fused frame -- decay,
   // rectangles, per-cell lidar hit counts and optionally the free-space ray stage -- instead of updateMap alone
   bool lidar_binning = false, lidar_raymarch = false;
+  // true (default): everything from filterBBoxes to the packed grid is ONE batch of device work with one host wait
+  // (gv_tick_*): the poses go from the kernel that computes them into the grid pass without leaving the device.
+  // false: the reference's call-by-call sequence over the mirror (one synchronous call per reference function).
+  bool fused = true;
 };
 
 // what one tick of the 50 ms timer (grid_vision_node.cpp:49-50) has to work with
@@ -92,6 +96,7 @@ public:
       r.branch = TickBranch::NoTransform;
       return r;
     }
+    if (p_.fused && fusable()) return tickFused(in, r);
     if (!r.static_bboxes.empty()) {   // :168-184
       r.depth_vec = cloud_detections::computeDepthForBoundingBoxes(ctx_, r.static_bboxes, p_.k_near);
       r.cam_points = cloud_detections::convertPixelsTo3D(ctx_, r.static_bboxes, r.depth_vec);
@@ -120,7 +125,46 @@ public:
     return r;
   }
 
+  // pinned landing place of OccupancyGrid.data (gv_host_alloc, G bytes): the fused tick copies the packed grid there
+  // behind its grid pass; nullptr (default): the caller fetches it with toOccupancyGrid as before
+  void setGridOut(int8_t *pinned) { grid_out_ = pinned; }
+
 private:
+  // the fused form needs the tile path when the lidar extension is on (gv_tick_enqueue says so too)
+  bool fusable() const
+  {
+    if (!p_.lidar_binning) return true;
+    int32_t nx = 0, ny = 0;
+    gv_grid_geometry(ctx_.handle(), &nx, &ny, nullptr, nullptr);
+    return nx % 4 == 0 && nx <= 8000 && ny <= 8000;
+  }
+
+  // :166-236 as one batch: same branches, same outputs, one host wait (GridVisionContext::tickWait)
+  TickResult tickFused(const TickInput &in, TickResult &r)
+  {
+    std::vector<float> orient, conf, dims;
+    uint32_t flags = 0;
+    int32_t n_net = 0;
+    const bool dyn = !r.dynamic_bboxes.empty();
+    if (p_.use_vision_orientation) {
+      flags |= GV_TICK_VISION_ORIENT;
+      if (dyn && in.orientation_net) in.orientation_net(r.dynamic_bboxes, orient, conf, dims);   // :193
+      if (dyn && orient.size() == r.dynamic_bboxes.size() * 4 && conf.size() == r.dynamic_bboxes.size() * 2 &&
+          dims.size() == r.dynamic_bboxes.size() * 3)
+        n_net = (int32_t)r.dynamic_bboxes.size();
+    }
+    if (p_.lidar_binning && ctx_.cloudSize() > 0) flags |= GV_TICK_LIDAR_BIN | (p_.lidar_raymarch ? GV_TICK_LIDAR_RAYMARCH : 0u);
+    ctx_.tickEnqueue(r.bboxes, flags, p_.k_near, n_net ? orient.data() : nullptr, n_net ? conf.data() : nullptr,
+                     n_net ? dims.data() : nullptr, n_net, grid_out_);
+    GridVisionContext::TickOutput t = ctx_.tickWait();
+    r.depth_vec = std::move(t.depths);
+    r.cam_points = std::move(t.base_points);
+    r.bboxes_pose = std::move(t.poses);
+    r.branch = !dyn ? TickBranch::NoDynamicObjects : (p_.use_vision_orientation ? TickBranch::VisionOrientation : TickBranch::CloudPCA);
+    r.publish_detections = true;   // :239-243
+    return r;
+  }
+
   // updateMap(grid) / updateMap(grid, poses) of the reference (the poses overload is called even with an empty
   // vector, :206,:230), or the fused frame when the lidar extension is on and a cloud is resident
   void update(const std::vector<LShapePose> &poses, bool poses_overload = false)
@@ -143,6 +187,7 @@ private:
   VisionOrientation vision_;
   FlowParams p_;
   bool have_tf_ = false;
+  int8_t *grid_out_ = nullptr;
 };
 
 inline const char *branch_name(TickBranch b)

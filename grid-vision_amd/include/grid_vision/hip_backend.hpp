@@ -117,6 +117,47 @@ public:
   void synchronize() { gv::check(gv_synchronize(h_), h_, "gv_synchronize"); }
   size_t cloudSize() const { return n_; }
 
+  // The device half of one timerCallback as a single batch (gv_tick_enqueue / gv_tick_wait): kNN depth of the static
+  // boxes, poses of the dynamic ones (orientation-network geometry or cloud PCA), rectangles, map update, int8 pack.
+  // tickWait is the tick's only host wait.
+  struct TickOutput {
+    std::vector<BoundingBox> static_bboxes;
+    std::vector<float> depths;                   // :176-177
+    std::vector<geometry::Point> base_points;    // :180
+    std::vector<LShapePose> poses;               // base frame (:204, :227)
+    bool pca_empty = false;                      // computeBBoxPose returned {} (:307-309)
+  };
+  void tickEnqueue(const std::vector<BoundingBox> &bboxes, uint32_t flags, uint16_t k_near, const float *orient = nullptr,
+                   const float *conf = nullptr, const float *dims = nullptr, int32_t n_net = 0, int8_t *grid_out = nullptr)
+  {
+    gv_tick_desc d{};
+    d.flags = flags;
+    d.bboxes = bboxes.data();
+    d.n_bboxes = (int32_t)bboxes.size();
+    d.orient = orient; d.conf = conf; d.dims = dims;
+    d.n_net = n_net;
+    d.k_near = k_near;
+    d.grid_out = grid_out;
+    tick_n_ = bboxes.size();
+    gv::check(gv_tick_enqueue(h_, &d), h_, "gv_tick_enqueue");
+  }
+  TickOutput tickWait()
+  {
+    TickOutput o;
+    const size_t cap = tick_n_ ? tick_n_ : 1;
+    o.static_bboxes.resize(cap); o.depths.resize(cap); o.base_points.resize(cap); o.poses.resize(cap);
+    gv_tick_result r{};
+    r.static_bboxes = o.static_bboxes.data();
+    r.depths = o.depths.data();
+    r.base_points_xyz = reinterpret_cast<double *>(o.base_points.data());
+    r.poses = o.poses.data();
+    gv::check(gv_tick_wait(h_, &r), h_, "gv_tick_wait");
+    o.static_bboxes.resize((size_t)r.n_static); o.depths.resize((size_t)r.n_static); o.base_points.resize((size_t)r.n_static);
+    o.poses.resize((size_t)r.n_poses);
+    o.pca_empty = r.pca_empty != 0;
+    return o;
+  }
+
 private:
   struct Staging {
     void *p = nullptr;
@@ -127,6 +168,7 @@ private:
   int flip_ = 0;
   gv_handle h_ = nullptr;
   size_t n_ = 0;
+  size_t tick_n_ = 0;
 };
 
 // OccupancyGridMap  occupancy_grid.hpp:13-40.  grid_map_ is the device-resident grid.

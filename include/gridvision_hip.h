@@ -97,7 +97,7 @@ int gv_create(gv_handle *out, uint8_t grid_x, uint8_t grid_y, double resolution,
 int gv_destroy(gv_handle h);
 /* text of the last HIP/RCCL failure on this handle ("" if none) */
 const char *gv_last_error(gv_handle h);
-/* ABI version of the library (this header: 2) */
+/* ABI version of the library (this header: 4) */
 int gv_abi_version(void);
 /* geometry read-back: nx, ny, pos_x, pos_y (grid_map size / position) */
 int gv_grid_geometry(gv_handle h, int32_t *nx, int32_t *ny, double *pos_x, double *pos_y);
@@ -298,6 +298,49 @@ int gv_get_cell_idx(gv_handle h, int32_t *out);      /* N ints, KEEP_CELL_IDX */
 int gv_get_bbox_id(gv_handle h, int32_t *out);       /* N ints, BBOX_TEST     */
 /* number of grid cells visited by the last ray-march (sum over marched rays) */
 int gv_get_ray_stats(gv_handle h, uint64_t *n_rays, uint64_t *n_visits);
+
+/* ------------------------------------------------------------ the node's tick -- */
+/* Replaces GridVision::timerCallback from filterBBoxes to publishOccupancyGrid (src/grid_vision_node.cpp:153-244) as
+ * ONE batch of device work with ONE host wait:
+ *   filterBBoxes (:384-403, host)                                   -> static / dynamic boxes
+ *   static boxes: buildKDTree + computeDepthForBoundingBoxes (:168-184, cloud_detections.cpp:8-87) + convertPixelsTo3D
+ *   dynamic boxes, GV_TICK_VISION_ORIENT: VisionOrientation::postProcessOutputs on the network outputs (:190-209)
+ *                  otherwise:             cloud_detections::computeBBoxPose on ALL boxes (:210-231, cloud_detections.cpp:300-321)
+ *   transformLShapeObjects (:204, :227), updateMap(grid, poses) / updateMap(grid) (:145, :206, :230, :235),
+ *   GridMapRosConverter::toOccupancyGrid (:265-278).
+ * The poses go from the kernel that computes them through the camera->base transform and the rectangle kernel into the
+ * grid pass without leaving the device; the depths, the poses (for the markers, :243) and optionally the packed grid
+ * come back through pinned memory and are complete when gv_tick_wait returns.  The static boxes' kNN runs on a second
+ * stream beside the pose branch.  The caller runs extract_bboxes and, for GV_TICK_VISION_ORIENT, the orientation
+ * network on the dynamic boxes (gv_filter_bboxes gives their order) first; a tick with no boxes is the :141-147 path.
+ * GV_ERR_TF when a transform the tick needs was never set (the node publishes the stale grid, :160-164).
+ * One tick may be pending per handle; frames in flight (gv_frame_enqueue) are drained first. */
+enum {
+  GV_TICK_VISION_ORIENT  = 1 << 0,  /* use_vision_orientation (config/grid_vision_cfg.yaml:24) */
+  GV_TICK_LIDAR_BIN      = 1 << 1,  /* [EXTENSION] the map update also bins the resident cloud (X1) ...  */
+  GV_TICK_LIDAR_RAYMARCH = 1 << 2   /* [EXTENSION] ... and marks free space (X2); tile-path grids only   */
+};
+typedef struct {
+  uint32_t flags;
+  const gv_bbox *bboxes;             /* what extract_bboxes returned (:138-139): static and dynamic mixed */
+  int32_t n_bboxes;
+  const float *orient, *conf, *dims; /* GV_TICK_VISION_ORIENT: n_net * 4 / 2 / 3 network outputs, dynamic-box order */
+  int32_t n_net;                     /* 0 (no poses this tick, the reference's empty vector) or the number of dynamic boxes */
+  int32_t k_near;                    /* k_near (grid_vision_cfg.yaml:20), 1..32 */
+  int8_t *grid_out;                  /* optional: G bytes (gv_host_alloc for a true DMA) receive OccupancyGrid.data */
+} gv_tick_desc;
+typedef struct {
+  int32_t n_static, n_dynamic;       /* out */
+  gv_bbox *static_bboxes;            /* optional, room for n_bboxes: the static boxes (marker labels, :413-480)      */
+  float *depths;                     /* optional, room for n_bboxes: depth of every static box (:176-177)            */
+  double *base_points_xyz;           /* optional, room for 3 * n_bboxes: their base-frame points (:180)              */
+  gv_lshape_pose *poses;             /* optional, room for n_bboxes: the dynamic objects' base-frame poses           */
+  int32_t n_poses;                   /* out */
+  int32_t pca_empty;                 /* out: 1 = computeBBoxPose returned {} (no plane / empty segmented cloud)      */
+} gv_tick_result;
+int gv_tick_enqueue(gv_handle h, const gv_tick_desc *d);
+int gv_tick_wait(gv_handle h, gv_tick_result *r);
+int gv_tick(gv_handle h, const gv_tick_desc *d, gv_tick_result *r);   /* = enqueue + wait */
 
 /* ------------------------------------------------ raw stream / timing hooks -- */
 /* The public HIP stream of the handle (hipStream_t as void*), for callers that record their own

@@ -878,6 +878,10 @@ def test_cpp_flow_demo(gvamd, tmp_path):
                            "-L" + pkg, "-lgridvision_hip", "-Wl,-rpath," + pkg])
     out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stderr
+    # the fused tick (default: one batch, one host wait) and the call-by-call sequence print the same lines
+    out0 = subprocess.run([exe, "0"], capture_output=True, text=True, timeout=120)
+    assert out0.returncode == 0, out0.stderr
+    assert out0.stdout == out.stdout
     ticks = []
     for ln in out.stdout.splitlines():
         m = re.match(r"tick (\d+) branch (\S+) bboxes (\d+) static (\d+) dynamic (\d+) depths (\d+) poses (\d+) "
@@ -1206,6 +1210,167 @@ def test_bbox_pose_beyond_one_million_points(gvamd):
             _check_pose(poses[i], e, (i, nk))
     assert n_valid >= 15
     h.close()
+
+
+def _oracle_rect(og, p):
+    """index rectangle updateGridCellsFast (occupancy_grid.cpp:140-183) derives from a base-frame pose, or None"""
+    hx, hy = float(p["length"]) / 2.0, float(p["width"]) / 2.0
+    px, py = float(p["px"]), float(p["py"])
+    idx = []
+    for cx, cy in ((px - hx, py - hy), (px + hx, py - hy), (px + hx, py + hy), (px - hx, py + hy)):
+        ok, ix, iy = og.get_index(cx, cy)
+        if not ok:
+            return None
+        idx.append((ix, iy))
+    return (min(i[0] for i in idx), min(i[1] for i in idx), max(i[0] for i in idx), max(i[1] for i in idx))
+
+
+def _base_poses(tfs, cam_poses):
+    out = np.zeros(len(cam_poses), dtype=synth.LSHAPE_DTYPE)
+    for i, e in enumerate(cam_poses):
+        o = ol.tf_pose(tfs["base_cam"], [e[k] for k in ("px", "py", "pz", "qx", "qy", "qz", "qw")])
+        out[i] = tuple(o.tolist()) + (e["length"], e["width"], e["height"])
+    return out
+
+
+@pytest.mark.timeout(1200)
+def test_tick_fused_equals_call_sequence_and_oracle(gvamd):
+    """The reference's timerCallback from filterBBoxes on (grid_vision_node.cpp:153-244) at BASELINE configs[2] size on
+    a scene with objects, three ways:
+      A  gv_tick: ONE batch of device work -- kNN depth on a lane, RANSAC + per-box clouds + radius filter + PCA (or
+         the orientation-network geometry), camera->base, rectangles, map update, int8 pack, grid to pinned memory --
+         and one host wait;
+      B  the call-by-call sequence over the same library (one synchronous call per reference function);
+      C  the oracle.
+    A == B bit for bit (depths, points, poses, both layers, the packed grid).  Against C: depths bit-equal; poses
+    within SURVEY A11 / A14's tolerance; the grid bit-equal to the oracle's updateMap fed with the device's poses, and
+    the index rectangles of the oracle's own poses are the same ones (a differing rectangle would be a pose within
+    tolerance whose corner sits on a cell border: counted, none expected)."""
+    hA, tfs = make_handle(gvamd, 3, perturbed=True)
+    hB, _ = make_handle(gvamd, 3, perturbed=True)
+    g = synth.CONFIGS[3]["grid"]
+    og = ol.OGrid(g.grid_x, g.grid_y, g.resolution)
+    x, y, z, b = _large_scene(tfs)
+    for h in (hA, hB):
+        h.upload_xyz(x, y, z)
+    st, dy = gvamd.filter_bboxes(b)
+    assert len(st) >= 5 and len(dy) >= 20
+    orient, conf, dims = synth.network_outputs(len(dy))
+    K = ol.set_intrinsic(synth.FX, synth.FY, synth.CX, synth.CY)
+    m_cam = ol.tf_to_matrix4f(tfs["cam_lidar"])
+    cx, cy, cz = ol.transform_cloud(m_cam, x, y, z)
+    # --- oracle side, once: kNN depth of the static boxes, poses of both branches
+    u, v, d = ol.project_points(K, cx, cy, cz)
+    edepth, _ = ol.depth_for_bboxes(u, v, d, st, 4)
+    kinv = ol.k_inverse(K)
+    epts = np.array([ol.tf_point(tfs["base_cam"], ol.pixel_to_3d(
+        np.float32(bb["x_min"] + ((bb["x_max"] - bb["x_min"]) / np.float32(2.0))),
+        np.float32(bb["y_min"] + ((bb["y_max"] - bb["y_min"]) / np.float32(2.0))), dep, kinv)) for bb, dep in zip(st, edepth)])
+    _, emask, _ = ol.segment_ground_plane(cx, cy, cz)
+    keep = emask == 0
+    _, ref = _pose_reference(cx[keep], cy[keep], cz[keep], K, b, _radius_keep_ckdtree)
+    e_pca = _base_poses(tfs, [e for ok, e, _, _ in ref if ok])
+    e_vis = _base_poses(tfs, ol.post_process(ol.make_cam(), orient, conf, dims, dy))
+    assert len(e_pca) >= 25 and len(e_vis) == len(dy)
+    pin = gvamd.PinnedI8(hA.G)
+    ties = 0
+    for tick, branch in enumerate(["pca", "vision", "pca", "static_only", "none", "vision_no_net"]):
+        boxes = {"static_only": st, "none": b[:0]}.get(branch, b)
+        vision = branch.startswith("vision")
+        net = (orient, conf, dims) if branch == "vision" else None
+        r = hA.tick(boxes, k_near=4, vision=vision, net=net, grid_out=pin.array)
+        # --- B: the call sequence
+        bst, bdy = gvamd.filter_bboxes(boxes) if len(boxes) else (boxes, boxes)
+        bdepth = hB.compute_depth_for_bboxes(bst, 4)[0] if len(bst) else np.zeros(0, np.float32)
+        bpts = hB.convert_pixels_to_3d(bst, bdepth) if len(bst) else np.zeros((0, 3))
+        if len(bdy) == 0:
+            bposes = np.zeros(0, dtype=synth.LSHAPE_DTYPE)
+            hB.update_map()
+        else:
+            if branch == "vision":
+                bposes = hB.transform_lshape_objects(hB.vision_post_process(orient, conf, dims, bdy))
+            elif branch == "vision_no_net":
+                bposes = np.zeros(0, dtype=synth.LSHAPE_DTYPE)
+            else:
+                pp, valid, npz = hB.compute_bbox_pose_ground_removed(boxes)
+                bposes = hB.transform_lshape_objects(pp[valid.astype(bool)] if npz >= 0 else pp[:0])
+            hB.update_map_poses(bposes)
+        assert r["n_static"] == len(bst) and r["n_dynamic"] == len(bdy), branch
+        assert r["depths"].tobytes() == bdepth.tobytes(), branch
+        assert r["base_points"].tobytes() == np.ascontiguousarray(bpts).tobytes(), branch
+        assert r["poses"].tobytes() == bposes.tobytes(), branch
+        lo = hA.log_odds()
+        assert np.array_equal(lo, hB.log_odds()), branch
+        assert np.array_equal(hA.occupancy(), hB.occupancy()), branch
+        i8 = hA.to_occupancy_grid()[0]
+        assert np.array_equal(i8, hB.to_occupancy_grid()[0]), branch
+        assert np.array_equal(pin.array, i8), branch          # the grid the tick itself delivered
+        # --- C: the oracle
+        if len(bst):
+            assert np.array_equal(r["depths"], edepth), branch
+            assert np.array_equal(r["base_points"], epts), branch
+        want = {"pca": e_pca, "vision": e_vis}.get(branch, e_pca[:0])
+        assert len(r["poses"]) == len(want), branch
+        for i, (p, e) in enumerate(zip(r["poses"], want)):
+            for f in ("px", "py", "pz", "length", "width"):
+                assert p[f] == pytest.approx(e[f], rel=1e-4, abs=1e-4), (branch, i, f)
+            ties += _oracle_rect(og, p) != _oracle_rect(og, e)
+        if len(bdy) == 0:
+            og.update_map()
+        else:
+            og.update_map_poses(r["poses"])
+        nlo, _, _ = check_grid(hA, og)
+        assert nlo == 0, branch
+    assert ties == 0, f"{ties} rectangles differ between the oracle's poses and the device's (poses within tolerance, corner on a cell border)"
+    pin.close()
+    hA.close(); hB.close()
+
+
+def test_tick_lidar_extension_and_error_paths(gvamd):
+    """the tick with the [EXTENSION] map update (hit counts + free space inside the same batch) equals the fused frame
+    fed with the tick's own poses; argument / state errors; a tick while frames are in flight drains them first"""
+    config = 2
+    hA, tfs = make_handle(gvamd, config, perturbed=True)
+    hB, _ = make_handle(gvamd, config, perturbed=True)
+    x, y, z, K, b = _ground_scene(tfs, seed=5)
+    for h in (hA, hB):
+        h.upload_xyz(x, y, z)
+    flags = gvamd.FRAME_BIN | gvamd.FRAME_RAYMARCH
+    hA.set_detections(flags)
+    hB.set_detections(flags)
+    for h in (hA, hB):
+        h.enqueue_frame(); h.enqueue_frame()      # frames in flight when the tick arrives
+    for vision in (False, True):
+        st, dy = gvamd.filter_bboxes(b)
+        net = synth.network_outputs(len(dy)) if vision else None
+        r = hA.tick(b, k_near=4, vision=vision, net=net, lidar_bin=True, lidar_raymarch=True)
+        assert len(r["poses"]) >= (len(dy) if vision else 5)
+        hB.process_frame(flags | gvamd.FRAME_KEEP_COUNTS, poses=r["poses"])
+        assert np.array_equal(hA.log_odds(), hB.log_odds())
+        assert np.array_equal(hA.to_occupancy_grid()[0], hB.to_occupancy_grid()[0])
+        assert np.array_equal(hA.hits(), hB.hits())
+    # errors
+    hA.tick_enqueue(b, k_near=4)
+    with pytest.raises(gvamd.GVError) as e:
+        hA.tick_enqueue(b, k_near=4)           # one tick at a time
+    assert e.value.code == 5
+    hA.tick_wait()
+    with pytest.raises(gvamd.GVError) as e:
+        hA.tick_wait()
+    assert e.value.code == 5
+    with pytest.raises(gvamd.GVError) as e:
+        hA.tick_enqueue(b, k_near=0)
+    assert e.value.code == 1
+    with pytest.raises(gvamd.GVError) as e:
+        hA.tick_enqueue(b, k_near=4, vision=True, net=synth.network_outputs(1))   # outputs for the wrong number of boxes
+    assert e.value.code == 1
+    hC = gvamd.GridVisionHIP(50, 20, 0.1)
+    hC.upload_xyz(x, y, z)
+    with pytest.raises(gvamd.GVError) as e:
+        hC.tick_enqueue(b, k_near=4)           # transforms never set: the node publishes the stale grid (:160-164)
+    assert e.value.code == 6
+    assert hC.tick(b[:0])["n_static"] == 0     # no boxes: plain updateMap, needs no transform
+    hA.close(); hB.close(); hC.close()
 
 
 def test_ransac_tree_levels_and_failure_paths(gvamd):

@@ -229,7 +229,7 @@ def test_library_exports_every_declared_symbol():
     missing = [f for f in declared if not hasattr(lib, f)]
     assert not missing, missing
     assert sorted(gvamd.ABI_SYMBOLS) == declared, "gvamd.ABI_SYMBOLS must list exactly the header's functions"
-    assert lib.gv_abi_version() == 3
+    assert lib.gv_abi_version() == 4
 
 
 @pytest.mark.skipif(os.path.exists("/dev/kfd"), reason="only meaningful without a GPU")
