@@ -201,16 +201,15 @@ struct gv_context {
   int32_t pts_cap = 0;
   // kNN depth / PCA pose scratch
   Cand2 *knn_partial = nullptr; size_t knn_partial_cap = 0;
-  int32_t *d_segstart = nullptr; size_t segstart_cap = 0;
-  float *gx = nullptr, *gy = nullptr, *gz = nullptr; size_t gcap = 0;   // kept points by bbox, cloud order
-  CellNode *d_nodes = nullptr; uint8_t *d_drop = nullptr; size_t pc_cap = 0;   // per point: cell-list node, filtered-out flag
+  CellNode *d_nodes = nullptr; uint8_t *d_keep = nullptr; size_t pc_cap = 0;   // selected points in bucket order; 1 = survives the radius filter
+  long long *d_pca_acc = nullptr; unsigned *d_pca_ext = nullptr; size_t pca_cap = 0;   // per bbox: integer sums / extent keys of the PCA rectangle (zero between calls)
+  unsigned *d_pca_ticket = nullptr;
   uint32_t *d_cellcnt = nullptr, *d_cellpre = nullptr, *d_celloff = nullptr; size_t head_cap = 0;   // cell buckets: counts, prefix, block offsets (+ ticket)
   float4 *d_planes = nullptr; unsigned *d_plane_counts = nullptr; size_t planes_cap = 0;
   uint8_t *d_ground = nullptr; size_t ground_cap = 0;   // last ground mask (device resident)
   size_t ground_n = 0;
   double *d_rscratch = nullptr; size_t rscratch_cap = 0;   // tree-sum partials of the plane refinement
   RansacState *d_rstate = nullptr;
-  uint32_t *d_blockcnt = nullptr; size_t blockcnt_cap = 0;   // per (1024-point block, bbox) counts of the kept-point split
   // result block of the synchronous kNN / RANSAC / PCA calls: pinned and device-mapped, written by the call's last
   // kernel; [0] = the sequence number of the last finished call (CallDone, gv_kernels.hpp), payload from byte 64
   uint8_t *res_host = nullptr; size_t res_cap = 0;
@@ -1570,8 +1569,8 @@ int gv_destroy(gv_handle h)
   if (h->stream_x) (void)hipStreamDestroy(h->stream_x);
   void *bufs[] = {h->log_odds, h->occupancy, h->occ_i8, h->clip_end, h->miss8, h->sh_xchg, h->ray_list, h->ray_count, h->scratch_i32,
                   h->tx, h->ty, h->tz, h->d_pts, h->knn_partial,
-                  h->d_segstart, h->gx, h->gy, h->gz, h->d_nodes, h->d_drop, h->d_cellcnt, h->d_cellpre, h->d_celloff, h->d_planes,
-                  h->d_plane_counts, h->d_ground, h->d_rscratch, h->d_rstate, h->d_blockcnt, h->d_res_ticket};
+                  h->d_nodes, h->d_keep, h->d_pca_acc, h->d_pca_ext, h->d_pca_ticket, h->d_cellcnt, h->d_cellpre, h->d_celloff, h->d_planes,
+                  h->d_plane_counts, h->d_ground, h->d_rscratch, h->d_rstate, h->d_res_ticket};
   for (void *p : bufs)
     if (p) (void)hipFree(p);
   if (h->res_host) (void)hipHostFree(h->res_host);
@@ -2548,25 +2547,29 @@ static int enqueue_bbox_pose(gv_context *h, int32_t nb, bool with_ground, float 
                              gv_lshape_pose *poses_dev = nullptr)
 {
   const size_t n = h->n;
-  int rc;
   if (n > h->pc_cap) {
     if (h->d_nodes) { GV_HIP(hipFree(h->d_nodes)); h->d_nodes = nullptr; }
-    if (h->d_drop) { GV_HIP(hipFree(h->d_drop)); h->d_drop = nullptr; }
+    if (h->d_keep) { GV_HIP(hipFree(h->d_keep)); h->d_keep = nullptr; }
     h->pc_cap = 0;
     const size_t want = n + n / 8 + 1024;
     GV_HIP(hipMalloc(reinterpret_cast<void **>(&h->d_nodes), want * sizeof(CellNode)));
-    GV_HIP(hipMalloc(reinterpret_cast<void **>(&h->d_drop), want));
+    GV_HIP(hipMalloc(reinterpret_cast<void **>(&h->d_keep), want));
     h->pc_cap = want;
   }
-  if (n > h->gcap) {
-    for (float **p : {&h->gx, &h->gy, &h->gz})
-      if (*p) { GV_HIP(hipFree(*p)); *p = nullptr; }
-    h->gcap = 0;
-    const size_t want = n + n / 8 + 1024;
-    GV_HIP(hipMalloc(reinterpret_cast<void **>(&h->gx), want * sizeof(float)));
-    GV_HIP(hipMalloc(reinterpret_cast<void **>(&h->gy), want * sizeof(float)));
-    GV_HIP(hipMalloc(reinterpret_cast<void **>(&h->gz), want * sizeof(float)));
-    h->gcap = want;
+  if ((size_t)nb > h->pca_cap) {
+    if (h->d_pca_acc) { GV_HIP(hipFree(h->d_pca_acc)); h->d_pca_acc = nullptr; }
+    if (h->d_pca_ext) { GV_HIP(hipFree(h->d_pca_ext)); h->d_pca_ext = nullptr; }
+    h->pca_cap = 0;
+    const size_t want = (size_t)nb + (size_t)nb / 4 + 64;
+    GV_HIP(hipMalloc(reinterpret_cast<void **>(&h->d_pca_acc), pca_acc_words((int)want) * sizeof(long long)));
+    GV_HIP(hipMalloc(reinterpret_cast<void **>(&h->d_pca_ext), want * 4 * sizeof(unsigned)));
+    GV_HIP(hipMemsetAsync(h->d_pca_acc, 0, pca_acc_words((int)want) * sizeof(long long), h->stream));   // every call leaves them zero
+    GV_HIP(hipMemsetAsync(h->d_pca_ext, 0, want * 4 * sizeof(unsigned), h->stream));
+    h->pca_cap = want;
+  }
+  if (!h->d_pca_ticket) {
+    GV_HIP(hipMalloc(reinterpret_cast<void **>(&h->d_pca_ticket), 64));
+    GV_HIP(hipMemsetAsync(h->d_pca_ticket, 0, 64, h->stream));
   }
   // cell buckets: a power of two, about one per two points (the three arrays stay L2 resident at config-3 size;
   // cells that share a bucket only add candidates that fail the id or distance test)
@@ -2584,9 +2587,6 @@ static int enqueue_bbox_pose(gv_context *h, int32_t nb, bool with_ground, float 
     h->head_cap = n_buckets;
   }
   n_buckets = h->head_cap;   // the table only grows
-  const size_t nblocks = (n + 1023) / 1024;
-  if ((rc = grow(h, h->d_blockcnt, h->blockcnt_cap, nblocks * (size_t)nb + 16))) return rc;
-  if ((rc = grow(h, h->d_segstart, h->segstart_cap, (size_t)nb + 2))) return rc;
   if (!h->d_rstate) {
     GV_HIP(hipMalloc(reinterpret_cast<void **>(&h->d_rstate), sizeof(RansacState)));
     GV_HIP(hipMemsetAsync(h->d_rstate, 0, sizeof(RansacState), h->stream));
@@ -2595,14 +2595,13 @@ static int enqueue_bbox_pose(gv_context *h, int32_t nb, bool with_ground, float 
   // extractCloudPerBBox + RadiusOutlierRemoval(0.4, 10)  (cloud_detections.cpp:250-298, 150-154)
   const double radius = 0.4;
   launch_radius_filter(h->cx, h->cy, h->cz, (uint32_t)n, h->m_cam, h->camk, bbox_test_of(h, h->det[2]), nb, with_ground, thr_f,
-                       h->d_rstate, h->bbox_id, h->d_drop, h->d_cellcnt, h->d_cellpre, h->d_celloff,
-                       h->d_celloff + n_buckets / 4096 + 2, h->d_nodes, (uint32_t)n_buckets, host::floor_to_float(radius * radius), 10, s);
+                       h->d_rstate, h->bbox_id, h->d_cellcnt, h->d_cellpre, h->d_celloff,
+                       h->d_celloff + n_buckets / 4096 + 2, h->d_nodes, h->d_keep, h->d_pca_acc, (uint32_t)n_buckets,
+                       host::floor_to_float(radius * radius), 10, s);
   h->have_bbox_id = true;
-  // the kept points by bbox in cloud order (the reference appends in cloud order, :286), then centroid +
-  // PCA rectangle per bbox in the reference's accumulation order (:156-247)
-  launch_split_kept(h->bbox_id, h->d_drop, h->cx, h->cy, h->cz, h->m_cam, (uint32_t)n, nb, h->d_blockcnt, h->d_segstart, h->gx, h->gy, h->gz, s);
-  launch_pca_bbox(h->gx, h->gy, h->gz, h->d_segstart, nb, h->d_rstate, with_ground, (uint32_t)n,
-                  reinterpret_cast<gv_lshape_pose *>(out), out + pose_block_valid_off(nb),
+  // centroid + PCA rectangle per bbox from order-independent integer sums over the kept points (:156-247)
+  launch_pca_rect(h->d_nodes, h->d_cellpre + n_buckets, (uint32_t)n, h->d_keep, h->d_pca_acc, h->d_pca_ext, h->d_pca_ticket, nb,
+                  h->d_rstate, with_ground, reinterpret_cast<gv_lshape_pose *>(out), out + pose_block_valid_off(nb),
                   reinterpret_cast<RansacState *>(out + (size_t)nb * sizeof(gv_lshape_pose)), done, s, poses_dev);
   GV_HIP(hipGetLastError());
   return GV_OK;

@@ -118,56 +118,48 @@ __global__ void __launch_bounds__(kCoThreads) k_ransac_count_all(const float *__
     if (s_cnt[t]) atomicAdd(&counts[(size_t)(blockIdx.x % kRansacCountSlices) * stride + t], s_cnt[t]);   // sliced: see gv_kernels.hpp
 }
 
-// unit eigenvector of the smallest eigenvalue of a symmetric 3x3 (cyclic Jacobi, fp64): oracle/ransac.c, operation
-// for operation.  Every index is a compile-time constant (loops unrolled, the final column picked by selects): with
-// run-time indices the two matrices live in scratch memory and every access of this single-lane tail is a trip to
-// the L2 (14 us of the kernel's 29).
-template <int P, int Q>
-__device__ __forceinline__ void jacobi_rotate(double (&a)[3][3], double (&e)[3][3])
-{
-  if (a[P][Q] == 0.0) return;
-  const double theta = (a[Q][Q] - a[P][P]) / (2.0 * a[P][Q]);
-  const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-  const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
-#pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    const double akp = a[k][P], akq = a[k][Q];
-    a[k][P] = c * akp - s * akq;
-    a[k][Q] = s * akp + c * akq;
-  }
-#pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    const double apk = a[P][k], aqk = a[Q][k];
-    a[P][k] = c * apk - s * aqk;
-    a[Q][k] = s * apk + c * aqk;
-  }
-#pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    const double ekp = e[k][P], ekq = e[k][Q];
-    e[k][P] = c * ekp - s * ekq;
-    e[k][Q] = s * ekp + c * ekq;
-  }
-}
-
+// unit eigenvector of the smallest eigenvalue of a symmetric 3x3 (fp64): oracle/ransac.c, operation for operation -- the
+// closed form of pcl::eigen33 (scaled matrix, trigonometric roots, largest cross product of rows of A - lambda I).
+// Rounds 2-3 ran a cyclic Jacobi here: ninety dependent fp64 divisions and square roots on one lane, 14 us of the
+// kernel's 27.  (atan2 / cos / sin may differ from glibc's in the last bit: 1e-16 on lambda, far below the fp32 the
+// plane is stored in; the tests accept a last-bit difference of the coefficients and say so.)
 __device__ __forceinline__ void smallest_eigenvector3_dev(const double cov[6], double v[3])
 {
-  double a[3][3] = {{cov[0], cov[1], cov[2]}, {cov[1], cov[3], cov[4]}, {cov[2], cov[4], cov[5]}};
-  double e[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
-  for (int sweep = 0; sweep < 32; ++sweep) {
-    const double off = a[0][1] * a[0][1] + a[0][2] * a[0][2] + a[1][2] * a[1][2];
-    if (off < 1e-300) break;
-    jacobi_rotate<0, 1>(a, e);
-    jacobi_rotate<0, 2>(a, e);
-    jacobi_rotate<1, 2>(a, e);
-  }
-  // column of the smallest diagonal entry (the first of equals), by selects
-  const bool m1 = a[1][1] < a[0][0];
-  const double d01 = m1 ? a[1][1] : a[0][0];
-  const bool m2 = a[2][2] < d01;
+  double a00 = cov[0], a01 = cov[1], a02 = cov[2], a11 = cov[3], a12 = cov[4], a22 = cov[5];
+  double scale = fmax(fmax(fmax(fabs(a00), fabs(a01)), fmax(fabs(a02), fabs(a11))), fmax(fabs(a12), fabs(a22)));
+  if (!(scale > 2.2250738585072014e-308)) scale = 1.0;
+  a00 = a00 / scale; a01 = a01 / scale; a02 = a02 / scale; a11 = a11 / scale; a12 = a12 / scale; a22 = a22 / scale;
+  const double c0 = (((a00 * a11) * a22 + (2.0 * a01) * a02 * a12) - (a00 * a12) * a12 - (a11 * a02) * a02) - (a22 * a01) * a01;
+  const double c1 = ((((a00 * a11 - a01 * a01) + a00 * a22) - a02 * a02) + a11 * a22) - a12 * a12;
+  const double c2 = (a00 + a11) + a22;
+  const double c2_over_3 = c2 * (1.0 / 3.0);
+  double a_over_3 = (c2 * c2_over_3 - c1) * (1.0 / 3.0);
+  if (a_over_3 < 0.0) a_over_3 = 0.0;
+  const double half_b = 0.5 * (c0 + c2_over_3 * (2.0 * c2_over_3 * c2_over_3 - c1));
+  double q = a_over_3 * a_over_3 * a_over_3 - half_b * half_b;
+  if (q < 0.0) q = 0.0;
+  const double rho = sqrt(a_over_3);
+  const double theta = atan2(sqrt(q), half_b) * (1.0 / 3.0);
+  const double cos_theta = cos(theta), sin_theta = sin(theta);
+  const double r0 = c2_over_3 + 2.0 * rho * cos_theta;
+  const double r1 = c2_over_3 - rho * (cos_theta + 1.7320508075688772 * sin_theta);
+  const double r2 = c2_over_3 - rho * (cos_theta - 1.7320508075688772 * sin_theta);
+  double lam = r0;
+  if (r1 < lam) lam = r1;
+  if (r2 < lam) lam = r2;
+  if (lam <= 0.0) lam = 0.0;
+  a00 -= lam; a11 -= lam; a22 -= lam;
+  const double v1[3] = {a01 * a12 - a02 * a11, a02 * a01 - a00 * a12, a00 * a11 - a01 * a01};
+  const double v2[3] = {a01 * a22 - a02 * a12, a02 * a02 - a00 * a22, a00 * a12 - a01 * a02};
+  const double v3[3] = {a11 * a22 - a12 * a12, a12 * a02 - a01 * a22, a01 * a12 - a11 * a02};
+  const double l1 = (v1[0] * v1[0] + v1[1] * v1[1]) + v1[2] * v1[2];
+  const double l2 = (v2[0] * v2[0] + v2[1] * v2[1]) + v2[2] * v2[2];
+  const double l3 = (v3[0] * v3[0] + v3[1] * v3[1]) + v3[2] * v3[2];
+  const bool p1 = l1 >= l2 && l1 >= l3, p2 = !p1 && l2 >= l1 && l2 >= l3;
   double nn[3];
 #pragma unroll
-  for (int k = 0; k < 3; ++k) nn[k] = m2 ? e[k][2] : (m1 ? e[k][1] : e[k][0]);
-  const double len = sqrt(nn[0] * nn[0] + nn[1] * nn[1] + nn[2] * nn[2]);
+  for (int k = 0; k < 3; ++k) nn[k] = p1 ? v1[k] : (p2 ? v2[k] : v3[k]);
+  const double len = sqrt(p1 ? l1 : (p2 ? l2 : l3));
   // sign: the component of largest magnitude (the first of equals) is made positive
   double big = nn[0];
   if (fabs(nn[1]) > fabs(big)) big = nn[1];
@@ -503,14 +495,12 @@ __device__ __forceinline__ void cell_range(float c, int own, int &lo, int &hi)
 
 // extractCloudPerBBox (:250-298) on the cloud with the ground removed (:306-314): per point the camera
 // transform, the ground test against the refined plane (use_plane) and the first-match bbox.  A selected point
-// is counted into its (cell, id) bucket; unselected points are marked dropped.  Also counts the ground points
-// (st->n_inliers) when the plane is in use.
+// is counted into its (cell, id) bucket.  Also counts the ground points (st->n_inliers) when the plane is in use.
 __global__ void __launch_bounds__(kCoThreads) k_pose_classify(const float *__restrict__ x, const float *__restrict__ y,
                                                               const float *__restrict__ z, uint32_t n, Mat34f m, CamK cam,
                                                               BBoxTest bt, int nb, int use_plane, float thr_f,
                                                               RansacState *__restrict__ st, int16_t *__restrict__ ids,
-                                                              uint8_t *__restrict__ drop, uint32_t *__restrict__ cell_cnt,
-                                                              uint32_t hi_mask)
+                                                              uint32_t *__restrict__ cell_cnt, uint32_t hi_mask)
 {
   __shared__ unsigned s_n;
   float4 pl = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -534,7 +524,6 @@ __global__ void __launch_bounds__(kCoThreads) k_pose_classify(const float *__res
       if (id >= nb) id = -1;
       ids[i] = (int16_t)id;
       if (id >= 0) atomicAdd(&cell_cnt[bucket_of(cell_of(cx), cell_of(cy), cell_of(cz), id, hi_mask)], 1u);
-      else drop[i] = 1;
     }
     c += (unsigned)__popcll(__ballot(ground));
   }
@@ -645,8 +634,8 @@ __global__ void __launch_bounds__(1024) k_cell_starts(uint32_t *__restrict__ pre
 }
 
 // selected points -> bucket order: slot = first slot of the bucket + a ticket out of the bucket's count, which
-// is counted back down to zero (ready for the next call).  The order inside a bucket is arbitrary: the
-// neighbour counts do not depend on it.
+// is counted back down to zero (ready for the next call).  The order inside a bucket is arbitrary: nothing
+// downstream depends on it (neighbour counts, integer sums, min / max).
 __global__ void __launch_bounds__(kCoThreads) k_cell_scatter(const float *__restrict__ x, const float *__restrict__ y,
                                                              const float *__restrict__ z, uint32_t n, Mat34f m,
                                                              const int16_t *__restrict__ ids, uint32_t *__restrict__ cell_cnt,
@@ -666,482 +655,390 @@ __global__ void __launch_bounds__(kCoThreads) k_cell_scatter(const float *__rest
     CellNode nd;
     nd.x = cx; nd.y = cy; nd.z = cz;
     nd.id = id;
-    nd.orig = (int32_t)i;
-    nd.pad[0] = nd.pad[1] = nd.pad[2] = 0;
     sorted[start[b] + k] = nd;
   }
 }
 
-// RadiusOutlierRemoval(0.4, 10) (:150-154) per bbox cloud: drop[i] = 0 iff at least min_pts + 1 points of the
-// same bbox (the point itself included) lie within d2 <= r2f (FLANN L2_Simple in fp32: ((dx*dx) + dy*dy) + dz*dz),
-// r2f = the largest float not above the fp64 radius^2 (PCL >= 1.11 dense path).  Points are taken IN BUCKET
-// ORDER: neighbouring lanes sit in the same cell, probe the same buckets and read the same candidates, so the
-// wavefront's loads collapse to a few lines.  Cells that are neighbours along x and share ix >> 3 are
-// neighbouring BUCKETS (the low bucket bits are ix & 7), so a row of up to three cells is one contiguous run of
-// the sorted array: nine rows, at most eighteen runs, whose bounds are requested together before any candidate
-// is read.  The count stops at min_pts + 1 -- the outcome only asks whether it is reached.
-__device__ __forceinline__ int quad_sum(int v)
+// ---- the PCA rectangle's sums: fixed point, so that they do not depend on the order of the additions ----
+// The reference adds in cloud order (pcl::compute3DCentroid and cv::PCA's mean in fp32, the covariance in fp64);
+// round 3 kept that order with one dependent add per kept point on a single wavefront (153-250 us).  SURVEY A11 asks
+// for 1e-4, not for that rounding, so the sums are taken EXACTLY instead: every term is rounded once to a fixed-point
+// grid (2^-28 m for coordinates, 2^-26 m^2 for products of centred samples) and added as a 64-bit integer --
+// associative, hence bit-reproducible whatever order the chip's workgroups arrive in, and closer to the real-number
+// sums than the reference's fp32 running sum.  Everything downstream (mean to fp32, fp32-centred samples, covariance
+// scaled and stored fp32, 2x2 eigenvectors, fp32 projections) follows the reference line by line.
+constexpr double kFixCoord = 268435456.0;    // 2^28: |coordinate| < 2^11 m and < 2^23 points keep the sum below 2^62
+constexpr double kFixProd = 67108864.0;      // 2^26: |centred sample| < 2^7 m
+constexpr float kCoordClamp = 2047.0f, kCentredClamp = 127.0f;
+constexpr int kAccStride = 8;                // per bbox: sum y, z, x, count, sum aa, ab, bb, (unused)
+constexpr int kPcaTab = 128;                 // bboxes whose accumulators a workgroup keeps in LDS (more: global atomics)
+
+__device__ __forceinline__ long long fix_coord(float v) { return __double2ll_rn((double)fminf(fmaxf(v, -kCoordClamp), kCoordClamp) * kFixCoord); }
+__device__ __forceinline__ long long fix_prod(float a, float b)
 {
-  v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, false);   // quad_perm [1,0,3,2]
-  v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, false);   // quad_perm [2,3,0,1]
-  return v;
+  a = fminf(fmaxf(a, -kCentredClamp), kCentredClamp);
+  b = fminf(fmaxf(b, -kCentredClamp), kCentredClamp);
+  return __double2ll_rn(((double)a * (double)b) * kFixProd);   // the product of two floats is exact in fp64
+}
+// order-preserving unsigned key of a float (min / max by integer atomics)
+__device__ __forceinline__ unsigned fkey(float f)
+{
+  const unsigned b = __float_as_uint(f);
+  return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float fkey_inv(unsigned k)
+{
+  return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
 }
 
-template <int CTRL>
-__device__ __forceinline__ uint32_t quad_bcast(uint32_t v)
+// mean of bbox b's kept points from the integer sums (the reference: :157-158 centroid[1], cv::PCA's mean of the rows
+// (z, x), each narrowed to fp32)
+__device__ __forceinline__ void pca_means(const long long *__restrict__ a, float &cy, float &m0, float &m1, unsigned long long &cnt)
 {
-  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, false);
+  cnt = (unsigned long long)a[3];
+  const double inv = 1.0 / ((double)cnt * kFixCoord);
+  cy = (float)((double)a[0] * inv);
+  m0 = (float)((double)a[1] * inv);
+  m1 = (float)((double)a[2] * inv);
+}
+
+// RadiusOutlierRemoval(0.4, 10) (:150-154) per bbox cloud: keep[t] = 1 iff at least min_pts + 1 points of the same
+// bbox (the point itself included) lie within d2 <= r2f (FLANN L2_Simple in fp32: ((dx*dx) + dy*dy) + dz*dz),
+// r2f = the largest float not above the fp64 radius^2 (PCL >= 1.11 dense path).  Points are taken IN BUCKET ORDER.
+// Cells that are neighbours along x and share ix >> 3 are neighbouring BUCKETS (the low bucket bits are ix & 7), so a
+// row of up to three cells is one contiguous run of the sorted array (two when it straddles a multiple of 8).
+//
+// SIXTEEN lanes per point (one DPP row).  Round 3 used four, which walked the nine rows one after the other -- every
+// step a dependent trip to the L2 behind the running count: 9 to 18 trips per point, 65-116 us.  Now the eight rows
+// around the centre row have a lane each and the centre row (the point's own cell: where the hits are) eight lanes
+// that stride it; every step looks at up to sixteen candidates, the row-wide sum of hits and of lanes that still have
+// candidates is one DPP reduction, and the walk ends as soon as min_pts + 1 hits are in -- one or two trips for a
+// point inside an object, as many as its longest row for an outlier.  The kept points' coordinates are added to their
+// bbox's integer sums on the way out (LDS table per workgroup, flushed once).
+template <int CTRL>
+__device__ __forceinline__ int dpp_i32(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, false); }
+__device__ __forceinline__ int row16_sum(int v)   // every lane of the row of 16 ends with the row's sum
+{
+  v += dpp_i32<0x128>(v);   // row_ror:8
+  v += dpp_i32<0x124>(v);   // row_ror:4
+  v += dpp_i32<0x122>(v);   // row_ror:2
+  v += dpp_i32<0x121>(v);   // row_ror:1
+  return v;
 }
 
 __global__ void __launch_bounds__(256) k_radius_sorted(const CellNode *__restrict__ sorted, const uint32_t *__restrict__ start,
                                                        uint32_t n_buckets, uint32_t hi_mask, float r2f, int min_pts,
-                                                       uint8_t *__restrict__ drop)
+                                                       uint8_t *__restrict__ keep, long long *__restrict__ acc, int nb)
 {
-  // FOUR lanes per point: the selected points are few (1e5) and every query is a chain of dependent loads, so
-  // one lane per point leaves the chip two wavefronts per SIMD and all of them waiting; the four lanes of a quad
-  // take every fourth candidate of a run (one 128-byte read per quad and step) and share one count (DPP).
+  __shared__ long long s_acc[kPcaTab][4];
+  const bool tab = nb <= kPcaTab;
+  if (tab)
+    for (int i = threadIdx.x; i < nb * 4; i += 256) (&s_acc[0][0])[i] = 0;
+  __syncthreads();
   const uint32_t n_sel = start[n_buckets];
-  const uint32_t l = threadIdx.x & 3u;
-  for (uint32_t t = (blockIdx.x * 256u + threadIdx.x) >> 2; t < n_sel; t += gridDim.x * 64u) {
-    const CellNode p = sorted[t];
-    const int ix = cell_of(p.x), iy = cell_of(p.y), iz = cell_of(p.z);
-    const int myid = p.id;
+  const uint32_t g = threadIdx.x & 15u;
+  const float4 *nodes = reinterpret_cast<const float4 *>(sorted);
+  for (uint32_t t = (blockIdx.x * 256u + threadIdx.x) >> 4; t < n_sel; t += gridDim.x * 16u) {
+    const float4 pv = nodes[t];
+    const float px = pv.x, py = pv.y, pz = pv.z;
+    const int myid = __float_as_int(pv.w);
+    const int ix = cell_of(px), iy = cell_of(py), iz = cell_of(pz);
     int x0, x1, y0, y1, z0, z1;
-    cell_range(p.x, ix, x0, x1);
-    cell_range(p.y, iy, y0, y1);
-    cell_range(p.z, iz, z0, z1);
-    int cnt = 0;   // the same in the four lanes
-    auto walk = [&](uint32_t j, uint32_t e) {
-      while (j < e && cnt <= min_pts) {
-        CellNode c[2];
-#pragma unroll
-        for (int q = 0; q < 2; ++q) c[q] = sorted[min(j + (uint32_t)q * 4u + l, e - 1u)];
-        int hits = 0;
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-          float d = c[q].x - p.x;
-          float r = __fmul_rn(d, d);
-          d = c[q].y - p.y; r = __fadd_rn(r, __fmul_rn(d, d));
-          d = c[q].z - p.z; r = __fadd_rn(r, __fmul_rn(d, d));
-          hits += (j + (uint32_t)q * 4u + l < e && c[q].id == myid && r <= r2f) ? 1 : 0;
-        }
-        cnt += quad_sum(hits);
-        j += 8u;
-      }
+    cell_range(px, ix, x0, x1);
+    cell_range(py, iy, y0, y1);
+    cell_range(pz, iz, z0, z1);
+    int cnt = 0;   // the same in the sixteen lanes
+    auto test = [&](uint32_t j, bool on) -> int {
+      const float4 c = nodes[on ? j : t];
+      float d = c.x - px;
+      float r = __fmul_rn(d, d);
+      d = c.y - py; r = __fadd_rn(r, __fmul_rn(d, d));
+      d = c.z - pz; r = __fadd_rn(r, __fmul_rn(d, d));
+      return (on && __float_as_int(c.w) == myid && r <= r2f) ? 1 : 0;
     };
     if (x0 >= ix - 1 && x1 <= ix + 1 && y0 >= iy - 1 && y1 <= iy + 1 && z0 >= iz - 1 && z1 <= iz + 1) {
-      // row (dy, dz): cells x0..x1 are one run, or two when they straddle a multiple of 8
+      // lanes 0..7: the eight rows around the centre, one each; lanes 8..15: the centre row, strided by 8
+      const int q = (g < 8u) ? (int)g + ((int)g >= 4 ? 1 : 0) : 4;   // row number 0..8, 4 = centre
+      const int t3 = (q * 11) >> 5;                                   // q / 3
+      const int cy = iy + (q - 3 * t3) - 1, cz = iz + t3 - 1;
+      const bool in = cy >= y0 && cy <= y1 && cz >= z0 && cz <= z1;
+      // cells x0..x1 are one run, or two when they straddle a multiple of 8
       const int xs = ((x0 >> 3) != (x1 >> 3)) ? (x1 & ~7) : x1 + 1;   // first cell of the second run (none: x1 + 1)
-      // The nine rows are dealt to the quad's four lanes (lane l: rows l, l + 4, l + 8): each lane hashes and
-      // requests the bounds of at most three rows instead of all nine, and the walk gets a row's bounds from its
-      // owner by a DPP quad broadcast.
-      uint32_t sa[3][2], sb[3][2];
-#pragma unroll
-      for (int sl = 0; sl < 3; ++sl) {
-        const int q = (int)l + 4 * sl;
-        const int t9 = (q == 0) ? 4 : (q <= 4 ? q - 1 : q);   // the centre row first: it holds the point's own cell
-        const int t3 = (t9 * 11) >> 5;                         // t9 / 3 for 0 .. 11
-        const int cy = iy + (t9 - 3 * t3) - 1, cz = iz + t3 - 1;
-        const bool in = q < 9 && cy >= y0 && cy <= y1 && cz >= z0 && cz <= z1;
-        const uint32_t b_lo = bucket_of(x0, cy, cz, myid, hi_mask);
-        const uint32_t b_hi = bucket_of(min(xs - 1, x1), cy, cz, myid, hi_mask);
-        sa[sl][0] = in ? start[b_lo] : 0u;
-        sb[sl][0] = in ? start[b_hi + 1u] : 0u;
-        const bool two = in && xs <= x1;
-        const uint32_t c_lo = bucket_of(xs, cy, cz, myid, hi_mask);
-        const uint32_t c_hi = bucket_of(x1, cy, cz, myid, hi_mask);
-        sa[sl][1] = two ? start[c_lo] : 0u;
-        sb[sl][1] = two ? start[c_hi + 1u] : 0u;
-      }
-#pragma unroll
-      for (int q = 0; q < 9; ++q) {
-        constexpr int kBc[4] = {0x00, 0x55, 0xAA, 0xFF};   // quad_perm [k, k, k, k]
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          uint32_t a, b;
-          switch (q & 3) {
-          case 0: a = quad_bcast<kBc[0]>(sa[q >> 2][u]); b = quad_bcast<kBc[0]>(sb[q >> 2][u]); break;
-          case 1: a = quad_bcast<kBc[1]>(sa[q >> 2][u]); b = quad_bcast<kBc[1]>(sb[q >> 2][u]); break;
-          case 2: a = quad_bcast<kBc[2]>(sa[q >> 2][u]); b = quad_bcast<kBc[2]>(sb[q >> 2][u]); break;
-          default: a = quad_bcast<kBc[3]>(sa[q >> 2][u]); b = quad_bcast<kBc[3]>(sb[q >> 2][u]); break;
-          }
-          walk(a, b);
+      uint32_t a0 = 0, e0 = 0, a1 = 0, e1 = 0;
+      if (in) {
+        a0 = start[bucket_of(x0, cy, cz, myid, hi_mask)];
+        e0 = start[bucket_of(min(xs - 1, x1), cy, cz, myid, hi_mask) + 1u];
+        if (xs <= x1) {
+          a1 = start[bucket_of(xs, cy, cz, myid, hi_mask)];
+          e1 = start[bucket_of(x1, cy, cz, myid, hi_mask) + 1u];
         }
       }
-    } else {   // coordinates so large that fp32 spacing widens the range (capped at +-3 cells): cell by cell
+      const uint32_t step = (g < 8u) ? 1u : 8u;
+      uint32_t j = a0 + ((g < 8u) ? 0u : g - 8u), e = e0;
+      bool second = false;
+      for (;;) {
+        if (j >= e && !second) {   // on to the row's second run (same stride phase)
+          second = true;
+          j = a1 + (j - e);
+          e = e1;
+        }
+        const bool on = j < e;
+        const int v = row16_sum(test(j, on) | (on ? 0x10000 : 0));
+        cnt += v & 0xffff;
+        if (cnt > min_pts || (v >> 16) == 0) break;
+        j += step;
+      }
+    } else {   // coordinates so large that fp32 spacing widens the range (capped at +-3 cells): cell by cell, 16 lanes per run
       for (int cz = z0; cz <= z1 && cnt <= min_pts; ++cz)
         for (int cy = y0; cy <= y1 && cnt <= min_pts; ++cy)
           for (int cx = x0; cx <= x1 && cnt <= min_pts; ++cx) {
             const uint32_t b = bucket_of(cx, cy, cz, myid, hi_mask);
-            walk(start[b], start[b + 1u]);
+            const uint32_t e = start[b + 1u];
+            for (uint32_t j = start[b]; j < e && cnt <= min_pts; j += 16u) cnt += row16_sum(test(j + g, j + g < e));
           }
     }
-    if (l == 0) drop[p.orig] = (cnt >= min_pts + 1) ? 0 : 1;
+    if (g == 0u) {
+      const bool kept = cnt >= min_pts + 1;
+      keep[t] = kept ? 1 : 0;
+      if (kept && myid < nb) {
+        const long long fy = fix_coord(py), fz = fix_coord(pz), fx = fix_coord(px);
+        if (tab) {
+          atomicAdd(reinterpret_cast<unsigned long long *>(&s_acc[myid][0]), (unsigned long long)fy);
+          atomicAdd(reinterpret_cast<unsigned long long *>(&s_acc[myid][1]), (unsigned long long)fz);
+          atomicAdd(reinterpret_cast<unsigned long long *>(&s_acc[myid][2]), (unsigned long long)fx);
+          atomicAdd(reinterpret_cast<unsigned long long *>(&s_acc[myid][3]), 1ull);
+        } else {
+          unsigned long long *a = reinterpret_cast<unsigned long long *>(acc + (size_t)myid * kAccStride);
+          atomicAdd(a + 0, (unsigned long long)fy);
+          atomicAdd(a + 1, (unsigned long long)fz);
+          atomicAdd(a + 2, (unsigned long long)fx);
+          atomicAdd(a + 3, 1ull);
+        }
+      }
+    }
+  }
+  if (!tab) return;
+  __syncthreads();
+  for (int i = threadIdx.x; i < nb * 4; i += 256) {
+    const long long v = (&s_acc[0][0])[i];
+    if (v != 0) atomicAdd(reinterpret_cast<unsigned long long *>(acc + (size_t)(i >> 2) * kAccStride + (i & 3)), (unsigned long long)v);
+  }
+}
+
+// covariance sums of the fp32-centred samples (cv::PCA: rows (z, x) minus the fp32 mean, products accumulated in
+// fp64 -- here: each product, exact in fp64, rounded once to 2^-26 m^2 and added as an integer)
+__global__ void __launch_bounds__(256) k_pca_cov(const CellNode *__restrict__ sorted, const uint32_t *__restrict__ n_sel_p,
+                                                 const uint8_t *__restrict__ keep, long long *__restrict__ acc, int nb)
+{
+  __shared__ long long s_acc[kPcaTab][3];
+  __shared__ float s_m[kPcaTab][2];
+  const bool tab = nb <= kPcaTab;
+  if (tab) {
+    for (int i = threadIdx.x; i < nb * 3; i += 256) (&s_acc[0][0])[i] = 0;
+    for (int b = threadIdx.x; b < nb; b += 256) {
+      float cy, m0 = 0.f, m1 = 0.f;
+      unsigned long long cnt;
+      if (acc[(size_t)b * kAccStride + 3] != 0) pca_means(acc + (size_t)b * kAccStride, cy, m0, m1, cnt);
+      s_m[b][0] = m0;
+      s_m[b][1] = m1;
+    }
+  }
+  __syncthreads();
+  const uint32_t n_sel = *n_sel_p;
+  const float4 *nodes = reinterpret_cast<const float4 *>(sorted);
+  for (uint32_t t = blockIdx.x * 256u + threadIdx.x; t < n_sel; t += gridDim.x * 256u) {
+    if (!keep[t]) continue;
+    const float4 p = nodes[t];
+    const int id = __float_as_int(p.w);
+    if (id >= nb) continue;
+    float m0, m1;
+    if (tab) { m0 = s_m[id][0]; m1 = s_m[id][1]; }
+    else {
+      float cy;
+      unsigned long long cnt;
+      pca_means(acc + (size_t)id * kAccStride, cy, m0, m1, cnt);
+    }
+    const float a = p.z - m0, b = p.x - m1;
+    const long long aa = fix_prod(a, a), ab = fix_prod(a, b), bb = fix_prod(b, b);
+    unsigned long long *d = tab ? reinterpret_cast<unsigned long long *>(&s_acc[id][0])
+                                : reinterpret_cast<unsigned long long *>(acc + (size_t)id * kAccStride + 4);
+    atomicAdd(d + 0, (unsigned long long)aa);
+    atomicAdd(d + 1, (unsigned long long)ab);
+    atomicAdd(d + 2, (unsigned long long)bb);
+  }
+  if (!tab) return;
+  __syncthreads();
+  for (int i = threadIdx.x; i < nb * 3; i += 256) {
+    const long long v = (&s_acc[0][0])[i];
+    if (v != 0) atomicAdd(reinterpret_cast<unsigned long long *>(acc + (size_t)(i / 3) * kAccStride + 4 + (i % 3)), (unsigned long long)v);
+  }
+}
+
+// mean, principal axes of one bbox from its integer sums: cv::PCA (:191-200) -- covariance scaled by 1 / n and stored
+// fp32, eigenvectors of the symmetric 2x2 as rows, eigenvalues descending; major.x >= 0 (the sign is arbitrary
+// upstream; length, width and centre do not depend on it)
+struct PcaAxes {
+  float cy, m0, m1, Mx, My, Nx, Ny;
+  unsigned long long cnt;
+};
+__device__ __forceinline__ PcaAxes pca_axes(const long long *__restrict__ a)
+{
+  PcaAxes r{};
+  pca_means(a, r.cy, r.m0, r.m1, r.cnt);
+  const double sc = 1.0 / ((double)r.cnt * kFixProd);
+  const double c00 = (double)(float)((double)a[4] * sc), c01 = (double)(float)((double)a[5] * sc), c11 = (double)(float)((double)a[6] * sc);
+  double mjx, mjy;
+  if (c01 == 0.0) {
+    if (c00 >= c11) { mjx = 1; mjy = 0; } else { mjx = 0; mjy = 1; }
+  } else {
+    const double tr = c00 + c11, df = c00 - c11;
+    const double root = sqrt(df * df + 4.0 * c01 * c01);
+    const double l1 = 0.5 * (tr + root);
+    mjx = c01; mjy = l1 - c00;
+    if (fabs(l1 - c11) > fabs(mjy)) { mjx = l1 - c11; mjy = c01; }
+    const double nn = sqrt(mjx * mjx + mjy * mjy);
+    mjx /= nn; mjy /= nn;
+  }
+  if (mjx < 0 || (mjx == 0 && mjy < 0)) { mjx = -mjx; mjy = -mjy; }
+  r.Mx = (float)mjx; r.My = (float)mjy; r.Nx = (float)(-mjy); r.Ny = (float)mjx;
+  return r;
+}
+
+// extents of the projections on the principal axes (:203-216; min / max: order free), and -- by the workgroup whose
+// ticket comes last -- the poses of all bboxes (:218-247), stored straight into the caller's block; the accumulators
+// are left zero for the next call.  ext[b] = {~key(minL), key(maxL), ~key(minW), key(maxW)}: zero = "nothing yet".
+__global__ void __launch_bounds__(256) k_pca_extent(const CellNode *__restrict__ sorted, const uint32_t *__restrict__ n_sel_p,
+                                                    const uint8_t *__restrict__ keep, long long *__restrict__ acc,
+                                                    unsigned *__restrict__ ext, unsigned *__restrict__ ticket, int nb,
+                                                    const RansacState *__restrict__ st, int use_plane, uint32_t n_cloud,
+                                                    gv_lshape_pose *__restrict__ poses, uint8_t *__restrict__ valid,
+                                                    RansacState *__restrict__ st_copy, CallDone done,
+                                                    gv_lshape_pose *__restrict__ poses_dev)
+{
+  __shared__ PcaAxes s_ax[kPcaTab];
+  __shared__ unsigned s_ext[kPcaTab][4];
+  __shared__ unsigned s_last;
+  const bool tab = nb <= kPcaTab;
+  if (tab)
+    for (int b = threadIdx.x; b < nb; b += 256) {
+      PcaAxes ax{};
+      if (acc[(size_t)b * kAccStride + 3] != 0) ax = pca_axes(acc + (size_t)b * kAccStride);
+      s_ax[b] = ax;
+      s_ext[b][0] = s_ext[b][1] = s_ext[b][2] = s_ext[b][3] = 0u;
+    }
+  __syncthreads();
+  const uint32_t n_sel = *n_sel_p;
+  const float4 *nodes = reinterpret_cast<const float4 *>(sorted);
+  for (uint32_t t = blockIdx.x * 256u + threadIdx.x; t < n_sel; t += gridDim.x * 256u) {
+    if (!keep[t]) continue;
+    const float4 p = nodes[t];
+    const int id = __float_as_int(p.w);
+    if (id >= nb) continue;
+    const PcaAxes ax = tab ? s_ax[id] : pca_axes(acc + (size_t)id * kAccStride);
+    const float dx = p.z - ax.m0, dy = p.x - ax.m1;
+    const float pl = dx * ax.Mx + dy * ax.My, pw = dx * ax.Nx + dy * ax.Ny;
+    unsigned *e = tab ? &s_ext[id][0] : ext + (size_t)id * 4;
+    const unsigned kl = fkey(pl), kw = fkey(pw);
+    atomicMax(e + 0, ~kl); atomicMax(e + 1, kl);
+    atomicMax(e + 2, ~kw); atomicMax(e + 3, kw);
+  }
+  __syncthreads();
+  if (tab)
+    for (int i = threadIdx.x; i < nb * 4; i += 256) {
+      const unsigned v = (&s_ext[0][0])[i];
+      if (v != 0u) atomicMax(ext + i, v);
+    }
+  // ---- the last workgroup to arrive writes the poses
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned tk = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    const bool last = tk == gridDim.x - 1u;
+    if (last) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = last ? 1u : 0u;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  __threadfence();
+  if (threadIdx.x == 0 && st_copy) *st_copy = *st;   // the state rides home in the same block as the poses
+  // computeBBoxPose :307-309: an empty segmented cloud (no plane found, or everything is ground) -> no poses
+  const bool none = use_plane && (st->best_count == 0 || st->n_inliers == 0ull || st->n_inliers == (unsigned long long)n_cloud);
+  for (int b = threadIdx.x; b < nb; b += 256) {
+    long long a[kAccStride];
+#pragma unroll
+    for (int k = 0; k < kAccStride; ++k) {
+      a[k] = __hip_atomic_load(acc + (size_t)b * kAccStride + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      acc[(size_t)b * kAccStride + k] = 0;
+    }
+    unsigned e[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      e[k] = __hip_atomic_load(ext + (size_t)b * 4 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      ext[(size_t)b * 4 + k] = 0u;
+    }
+    gv_lshape_pose p{};
+    bool ok = false;
+    if (!none && a[3] != 0) {   // :174-175 an empty cloud has no pose
+      const PcaAxes ax = pca_axes(a);
+      const float minL = fkey_inv(~e[0]), maxL = fkey_inv(e[1]), minW = fkey_inv(~e[2]), maxW = fkey_inv(e[3]);
+      // :227 degrees, :236 passed to setRPY as if radians (as the reference does); atan2f evaluated in fp64, rounded once.
+      // `std::atan2(float, float) * 180.0f / CV_PI`: float product, widened for the division by the DOUBLE CV_PI,
+      // narrowed once on the assignment to `float angle`.
+      const float a32 = (float)atan2((double)ax.My, (double)ax.Mx);
+      const float angle = (float)((double)(a32 * 180.0f) / 3.1415926535897932384626433832795);
+      const double hp = (double)(-angle) * 0.5;   // tf2 setRPY(0, pitch, 0): (0, sin(p/2), 0, cos(p/2))
+      p.px = ax.m1;    // :230 center.y
+      p.py = ax.cy;    // :231 then :181
+      p.pz = ax.m0;    // :232 center.x
+      p.qx = 0.0; p.qy = sin(hp); p.qz = 0.0; p.qw = cos(hp);
+      p.length = maxL - minL;   // :218,:243
+      p.width = maxW - minW;    // :219,:244
+      p.height = 0.0;           // never set on this path in the reference
+      ok = true;
+    }
+    poses[b] = p;
+    valid[b] = ok ? 1 : 0;
+    if (poses_dev) {
+      if (!ok) p.length = -1.0;   // k_rects_from_poses skips it
+      poses_dev[b] = p;
+    }
+  }
+  if (done.flag) {
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) call_done(done, 1u);
   }
 }
 
 void launch_radius_filter(const float *x, const float *y, const float *z, uint32_t n, const Mat34f &m_cam, const CamK &cam,
-                          const BBoxTest &bt, int nb, bool use_plane, float thr_f, RansacState *st, int16_t *ids, uint8_t *drop,
-                          uint32_t *cell_cnt, uint32_t *pre, uint32_t *blk_off, unsigned *ticket, CellNode *sorted,
-                          uint32_t n_buckets, float r2f, int min_pts, hipStream_t s)
+                          const BBoxTest &bt, int nb, bool use_plane, float thr_f, RansacState *st, int16_t *ids,
+                          uint32_t *cell_cnt, uint32_t *pre, uint32_t *blk_off, unsigned *ticket, CellNode *sorted, uint8_t *keep,
+                          long long *acc, uint32_t n_buckets, float r2f, int min_pts, hipStream_t s)
 {
   if (!n) return;
   const uint32_t nblk = (uint32_t)(((size_t)n + kCoBlock - 1) / kCoBlock);
   const uint32_t hi_mask = n_buckets / 512u - 1u;
   hipLaunchKernelGGL(k_pose_classify, dim3(nblk), dim3(kCoThreads), 0, s, x, y, z, n, m_cam, cam, bt, nb, use_plane ? 1 : 0, thr_f, st,
-                     ids, drop, cell_cnt, hi_mask);
+                     ids, cell_cnt, hi_mask);
   hipLaunchKernelGGL(k_cell_scan, dim3(n_buckets / kScanBlock), dim3(1024), 0, s, cell_cnt, n_buckets, pre, blk_off, ticket);
   hipLaunchKernelGGL(k_cell_starts, dim3(n_buckets / kScanBlock + 1), dim3(1024), 0, s, pre, blk_off, n_buckets);
   hipLaunchKernelGGL(k_cell_scatter, dim3(nblk), dim3(kCoThreads), 0, s, x, y, z, n, m_cam, ids, cell_cnt, pre, hi_mask, sorted);
-  // four lanes per selected point; their number is only known on the device: a fixed grid strides over them
-  const uint32_t rblk = (uint32_t)std::min<size_t>(((size_t)n * 4 + 255) / 256, 8192);
-  hipLaunchKernelGGL(k_radius_sorted, dim3(rblk), dim3(256), 0, s, sorted, pre, n_buckets, hi_mask, r2f, min_pts, drop);
+  // sixteen lanes per selected point; their number is only known on the device: a fixed grid strides over them
+  const uint32_t rblk = (uint32_t)std::min<size_t>(((size_t)n * 16 + 255) / 256, 4096);
+  hipLaunchKernelGGL(k_radius_sorted, dim3(rblk), dim3(256), 0, s, sorted, pre, n_buckets, hi_mask, r2f, min_pts, keep, acc, nb);
 }
 
-// --------------------------------------------------- kept points by bbox + PCA --
-// Stable split of the KEPT points by bbox id (the reference appends in cloud order, :286, and the filter keeps
-// that order): blocks of 1024 points are counted, a column scan gives every (block, bbox) its first slot, and
-// one wavefront per block places its points in order, writing their (recomputed) camera coordinates into the
-// per-bbox arrays.  drop[i] != 0 removes the point.
-constexpr int kSegBlock = 1024;
-
-__global__ void __launch_bounds__(256) k_seg_count(const int16_t *__restrict__ ids, const uint8_t *__restrict__ drop,
-                                                   uint32_t n, int nb, uint32_t *__restrict__ block_counts)
-{
-  extern __shared__ unsigned s_h[];
-  for (int b = threadIdx.x; b < nb; b += 256) s_h[b] = 0;
-  __syncthreads();
-  const size_t base = (size_t)blockIdx.x * kSegBlock;
-  for (int k = threadIdx.x; k < kSegBlock; k += 256) {
-    const size_t i = base + k;
-    if (i < n) {
-      const int id = drop[i] ? -1 : (int)ids[i];
-      if (id >= 0 && id < nb) atomicAdd(&s_h[id], 1u);
-    }
-  }
-  __syncthreads();
-  for (int b = threadIdx.x; b < nb; b += 256) block_counts[(size_t)blockIdx.x * nb + b] = s_h[b];
-}
-
-// Exclusive prefix of every bbox's counts over the blocks (in place) and seg_start[0..nb].  One workgroup:
-// 64 columns at a time (lane = bbox), the rows dealt to the 16 wavefronts in contiguous runs -- two short
-// walks with independent loads instead of one dependent walk over all the blocks.
-__global__ void __launch_bounds__(1024) k_seg_scan(uint32_t *__restrict__ block_counts, int nblocks, int nb,
-                                                   int32_t *__restrict__ seg_start)
-{
-  __shared__ unsigned s_part[16][64];
-  __shared__ unsigned s_tot[64];
-  __shared__ unsigned s_base;
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int per = (nblocks + 15) / 16;
-  const int r0 = min(nblocks, w * per), r1 = min(nblocks, r0 + per);
-  if (threadIdx.x == 0) s_base = 0u;
-  __syncthreads();
-  for (int b0 = 0; b0 < nb; b0 += 64) {
-    const int b = b0 + lane;
-    unsigned run = 0;
-    if (b < nb) {
-#pragma unroll 8
-      for (int k = r0; k < r1; ++k) run += block_counts[(size_t)k * nb + b];
-    }
-    s_part[w][lane] = run;
-    __syncthreads();
-    unsigned before = 0, total = 0;
-    for (int q = 0; q < 16; ++q) {
-      const unsigned v = s_part[q][lane];
-      if (q < w) before += v;
-      total += v;
-    }
-    if (b < nb) {
-      unsigned acc = before;
-#pragma unroll 8
-      for (int k = r0; k < r1; ++k) {
-        const unsigned c = block_counts[(size_t)k * nb + b];
-        block_counts[(size_t)k * nb + b] = acc;
-        acc += c;
-      }
-    }
-    if (w == 0) {   // segment starts of these 64 bboxes: exclusive scan of their totals across the lanes
-      unsigned t = (b < nb) ? total : 0u, inc = t;
-#pragma unroll
-      for (int off = 1; off < 64; off <<= 1) {
-        const unsigned o = __shfl_up(inc, off);
-        if (lane >= off) inc += o;
-      }
-      const unsigned base = s_base;
-      if (b < nb) seg_start[b] = (int32_t)(base + inc - t);
-      if (lane == 63) s_tot[0] = base + inc;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) s_base = s_tot[0];
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) seg_start[nb] = (int32_t)s_base;
-}
-
-__global__ void __launch_bounds__(64) k_seg_scatter(const int16_t *__restrict__ ids, const uint8_t *__restrict__ drop,
-                                                    const float *__restrict__ x, const float *__restrict__ y,
-                                                    const float *__restrict__ z, Mat34f m, uint32_t n, int nb,
-                                                    const uint32_t *__restrict__ block_off, const int32_t *__restrict__ seg_start,
-                                                    float *__restrict__ gx, float *__restrict__ gy, float *__restrict__ gz)
-{
-  extern __shared__ unsigned s_cur[];   // next slot of every bbox for this block (absolute position in the output)
-  const int lane = threadIdx.x;
-  for (int b = lane; b < nb; b += 64) s_cur[b] = (unsigned)seg_start[b] + block_off[(size_t)blockIdx.x * nb + b];
-  __syncthreads();
-  const size_t base = (size_t)blockIdx.x * kSegBlock;
-  int idb[kSegBlock / 64];   // this lane's ids of all 16 batches, requested together
-#pragma unroll
-  for (int q = 0; q < kSegBlock / 64; ++q) {
-    const size_t i = base + (size_t)q * 64 + lane;
-    int id = -1;
-    if (i < n) {
-      id = drop[i] ? -1 : (int)ids[i];
-      if (id >= nb) id = -1;
-    }
-    idb[q] = id;
-  }
-  // One wavefront walks the block's 16 batches in order; per batch one round per distinct bbox id.  With at most
-  // 64 boxes the cursors live in a REGISTER (lane b holds the next slot of bbox b): a round reads the leader's
-  // cursor with a lane read and advances it in place -- no LDS round trip per round (measured the same as the LDS
-  // form, 20 us on the lidar-like cloud, where a batch of 64 ring neighbours holds many ids).  More boxes: the cursors stay in LDS and are
-  // advanced by the round's leader lane with a returning LDS add (LDS operations of one wavefront complete in
-  // order).  Either way no barrier, so the stores of one round are still in flight while the next one runs.
-  if (nb <= 64) {
-    unsigned cur_reg = (lane < nb) ? s_cur[lane] : 0u;
-#pragma unroll
-    for (int q = 0; q < kSegBlock / 64; ++q) {
-      const size_t i = base + (size_t)q * 64 + lane;
-      const int id = idb[q];
-      float cx = 0.f, cy = 0.f, cz = 0.f;
-      if (id >= 0) xform34(m, x[i], y[i], z[i], cx, cy, cz);
-      unsigned long long todo = __ballot(id >= 0);
-      while (todo) {
-        const int leader = __ffsll((long long)todo) - 1;
-        const int idl = __builtin_amdgcn_readlane(id, leader);
-        const unsigned long long same = __ballot(id == idl);
-        const unsigned cur = (unsigned)__builtin_amdgcn_readlane((int)cur_reg, idl);
-        if (lane == idl) cur_reg += (unsigned)__popcll(same);
-        if (id == idl) {
-          const unsigned pos = cur + (unsigned)__popcll(same & ((1ull << lane) - 1ull));
-          gx[pos] = cx; gy[pos] = cy; gz[pos] = cz;
-        }
-        todo &= ~same;
-      }
-    }
-    return;
-  }
-#pragma unroll
-  for (int q = 0; q < kSegBlock / 64; ++q) {
-    const size_t i = base + (size_t)q * 64 + lane;
-    const int id = idb[q];
-    float cx = 0.f, cy = 0.f, cz = 0.f;
-    if (id >= 0) xform34(m, x[i], y[i], z[i], cx, cy, cz);
-    unsigned long long todo = __ballot(id >= 0);
-    while (todo) {
-      const int leader = __ffsll((long long)todo) - 1;
-      const int idl = __builtin_amdgcn_readlane(id, leader);
-      const unsigned long long same = __ballot(id == idl);
-      unsigned cur = 0;
-      if (lane == leader) cur = atomicAdd(&s_cur[idl], (unsigned)__popcll(same));
-      cur = (unsigned)__builtin_amdgcn_readlane((int)cur, leader);
-      if (id == idl) {
-        const unsigned pos = cur + (unsigned)__popcll(same & ((1ull << lane) - 1ull));
-        gx[pos] = cx; gy[pos] = cy; gz[pos] = cz;
-      }
-      todo &= ~same;
-    }
-  }
-}
-
-// bboxPoseEstimation :156-181 + computePCABoundingBox :187-247 for one bbox cloud (the kept points, contiguous
-// and in cloud order), one wavefront each.  The reference accumulates in cloud order -- pcl::compute3DCentroid
-// and cv::PCA's mean in fp32, the covariance in fp64 -- so those sums are order dependent and are taken as
-// sequential chains: lane 0 sums y (the centroid's y), lane 1 z and lane 2 x (the PCA rows (z, x), :167-172),
-// each walking ITS array; in the covariance pass the three lanes hold c00, c01, c11.  The arrays are staged
-// through LDS a tile ahead by the whole wavefront (coalesced loads; the chains read 16 bytes per LDS access),
-// so a chain step costs one dependent add.  The projections' min / max are order free and run 64 wide.
-constexpr int kPcaTile = 1024;   // points per LDS tile and array
-
-__device__ __forceinline__ float lane_f32(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
-__device__ __forceinline__ double lane_f64(double v, int l)
-{
-  const long long b = __double_as_longlong(v);
-  const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), l), hi = __builtin_amdgcn_readlane((int)(b >> 32), l);
-  return __longlong_as_double(((long long)hi << 32) | (unsigned long long)(unsigned)lo);
-}
-
-__global__ void __launch_bounds__(64) k_pca_bbox(const float *__restrict__ gx, const float *__restrict__ gy,
-                                                 const float *__restrict__ gz, const int32_t *__restrict__ seg_start, int nb,
-                                                 const RansacState *__restrict__ st, int use_plane, uint32_t n_cloud,
-                                                 gv_lshape_pose *__restrict__ poses, uint8_t *__restrict__ valid,
-                                                 RansacState *__restrict__ st_copy, CallDone done,
-                                                 gv_lshape_pose *__restrict__ poses_dev)
-{
-  __shared__ __attribute__((aligned(16))) float s_t[2][3][kPcaTile];    // [buffer][y | z | x][point]
-  __shared__ __attribute__((aligned(16))) double s_p[2][3][kPcaTile];   // [buffer][aa | ab | bb][point]
-  const int b = blockIdx.x, lane = threadIdx.x;
-  if (b >= nb) return;
-  if (b == 0 && lane == 0 && st_copy) *st_copy = *st;   // the state rides home in the same block as the poses
-  int s0 = seg_start[b], s1 = seg_start[b + 1];
-  // computeBBoxPose :307-309: an empty segmented cloud (no plane found, or everything is ground) -> no poses
-  if (use_plane && (st->best_count == 0 || st->n_inliers == 0ull || st->n_inliers == (unsigned long long)n_cloud)) s1 = s0;
-  const int cnt = s1 - s0;
-  if (cnt <= 0) {   // :174-175 empty cloud: no pose
-    if (lane == 0) {
-      valid[b] = 0;
-      poses[b] = gv_lshape_pose{};
-      if (poses_dev) {
-        gv_lshape_pose none{};
-        none.length = -1.0;   // k_rects_from_poses skips it
-        poses_dev[b] = none;
-      }
-      call_done(done, gridDim.x);
-    }
-    return;
-  }
-  const float *arr[3] = {gy + s0, gz + s0, gx + s0};
-  const int ntiles = (cnt + kPcaTile - 1) / kPcaTile;
-  constexpr int kPer = kPcaTile / 64;   // tile elements per lane and array
-  float r[3][kPer];
-  auto fetch = [&](int t) {   // tile t of the three arrays -> registers (zero padded), coalesced
-    const int o = t * kPcaTile;
-#pragma unroll
-    for (int a = 0; a < 3; ++a)
-#pragma unroll
-      for (int q = 0; q < kPer; ++q) r[a][q] = (o + q * 64 + lane < cnt) ? arr[a][o + q * 64 + lane] : 0.0f;
-  };
-  auto put = [&](int buf) {
-#pragma unroll
-    for (int a = 0; a < 3; ++a)
-#pragma unroll
-      for (int q = 0; q < kPer; ++q) s_t[buf][a][q * 64 + lane] = r[a][q];
-  };
-  const int ch = lane < 3 ? lane : 0;   // the chain this lane runs (lanes >= 3 shadow lane 0)
-  // pass 1: fp32 running sums in order.  The next tile's loads are in flight while this one is summed.
-  float sum = 0.0f;
-  fetch(0);
-  put(0);
-  __syncthreads();
-  for (int t = 0; t < ntiles; ++t) {
-    if (t + 1 < ntiles) fetch(t + 1);
-    const float4 *src = reinterpret_cast<const float4 *>(&s_t[t & 1][ch][0]);
-    const int m4 = (min(kPcaTile, cnt - t * kPcaTile) + 3) >> 2;   // the zero padding adds +0.0f: exact
-#pragma unroll 8
-    for (int q = 0; q < m4; ++q) {
-      const float4 v = src[q];
-      sum = sum + v.x; sum = sum + v.y; sum = sum + v.z; sum = sum + v.w;
-    }
-    if (t + 1 < ntiles) put((t + 1) & 1);
-    __syncthreads();
-  }
-  float cy = lane_f32(sum, 0), m0 = lane_f32(sum, 1), m1 = lane_f32(sum, 2);
-  cy = cy / (float)cnt;
-  const float inv = (float)(1.0 / (double)cnt);
-  m0 = m0 * inv;
-  m1 = m1 * inv;
-  // pass 2: fp64 covariance sums of the fp32-centred samples, in order: lane 0 sums a*a, lane 1 a*b, lane 2 b*b
-  // (a = z - m0, b = x - m1).  The products (exact in fp64) are formed 64 wide and parked in LDS; a chain step
-  // is one dependent fp64 add.  Padding contributes a product of +0.0.
-  double cs = 0.0;
-  auto put_products = [&](int t, int buf) {   // from the registers fetch(t) filled
-    const int o = t * kPcaTile;
-#pragma unroll
-    for (int q = 0; q < kPer; ++q) {
-      const int e = q * 64 + lane;
-      const bool in = o + e < cnt;
-      const float a = r[1][q] - m0, bb = r[2][q] - m1;
-      s_p[buf][0][e] = in ? (double)a * (double)a : 0.0;
-      s_p[buf][1][e] = in ? (double)a * (double)bb : 0.0;
-      s_p[buf][2][e] = in ? (double)bb * (double)bb : 0.0;
-    }
-  };
-  fetch(0);
-  put_products(0, 0);
-  __syncthreads();
-  for (int t = 0; t < ntiles; ++t) {
-    if (t + 1 < ntiles) fetch(t + 1);
-    const double2 *src = reinterpret_cast<const double2 *>(&s_p[t & 1][ch][0]);
-    const int m2 = (min(kPcaTile, cnt - t * kPcaTile) + 1) >> 1;
-#pragma unroll 8
-    for (int q = 0; q < m2; ++q) {
-      const double2 v = src[q];
-      cs = cs + v.x; cs = cs + v.y;
-    }
-    if (t + 1 < ntiles) put_products(t + 1, (t + 1) & 1);
-    __syncthreads();
-  }
-  const double c00 = lane_f64(cs, 0), c01 = lane_f64(cs, 1), c11 = lane_f64(cs, 2);
-  const double sc = 1.0 / (double)cnt;
-  const double a = (double)(float)(c00 * sc), bq = (double)(float)(c01 * sc), d = (double)(float)(c11 * sc);
-  double mjx, mjy;
-  if (bq == 0.0) {
-    if (a >= d) { mjx = 1; mjy = 0; } else { mjx = 0; mjy = 1; }
-  } else {
-    const double tr = a + d, df = a - d;
-    const double root = sqrt(df * df + 4.0 * bq * bq);
-    const double l1 = 0.5 * (tr + root);
-    mjx = bq; mjy = l1 - a;
-    if (fabs(l1 - d) > fabs(mjy)) { mjx = l1 - d; mjy = bq; }
-    const double nn = sqrt(mjx * mjx + mjy * mjy);
-    mjx /= nn; mjy /= nn;
-  }
-  if (mjx < 0 || (mjx == 0 && mjy < 0)) { mjx = -mjx; mjy = -mjy; }
-  const float Mx = (float)mjx, My = (float)mjy, Nx = (float)(-mjy), Ny = (float)mjx;
-  // pass 3: extent of the projections (:203-216), order free
-  float minL = 3.402823466e+38f, maxL = -3.402823466e+38f, minW = 3.402823466e+38f, maxW = -3.402823466e+38f;
-  for (int j = s0 + lane; j < s1; j += 64) {
-    const float dx = gz[j] - m0, dy = gx[j] - m1;
-    const float pl = dx * Mx + dy * My, pw = dx * Nx + dy * Ny;
-    minL = fminf(minL, pl); maxL = fmaxf(maxL, pl);
-    minW = fminf(minW, pw); maxW = fmaxf(maxW, pw);
-  }
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    minL = fminf(minL, __shfl_xor(minL, off)); maxL = fmaxf(maxL, __shfl_xor(maxL, off));
-    minW = fminf(minW, __shfl_xor(minW, off)); maxW = fmaxf(maxW, __shfl_xor(maxW, off));
-  }
-  if (lane == 0) {
-    // :227 degrees, :236 passed to setRPY as if radians (as the reference does); atan2f evaluated in fp64, rounded once.
-    // `std::atan2(float, float) * 180.0f / CV_PI`: float product, widened for the division by the DOUBLE CV_PI,
-    // narrowed once on the assignment to `float angle`.
-    const float a32 = (float)atan2((double)My, (double)Mx);
-    const float angle = (float)((double)(a32 * 180.0f) / 3.1415926535897932384626433832795);
-    const double hp = (double)(-angle) * 0.5;   // tf2 setRPY(0, pitch, 0): (0, sin(p/2), 0, cos(p/2))
-    gv_lshape_pose p{};
-    p.px = m1;    // :230 center.y
-    p.py = cy;    // :231 then :181
-    p.pz = m0;    // :232 center.x
-    p.qx = 0.0; p.qy = sin(hp); p.qz = 0.0; p.qw = cos(hp);
-    p.length = maxL - minL;   // :218,:243
-    p.width = maxW - minW;    // :219,:244
-    p.height = 0.0;           // never set on this path in the reference
-    poses[b] = p;
-    if (poses_dev) poses_dev[b] = p;
-    valid[b] = 1;
-    call_done(done, gridDim.x);
-  }
-}
-
-void launch_split_kept(const int16_t *ids, const uint8_t *drop, const float *x, const float *y, const float *z, const Mat34f &m_cam,
-                       uint32_t n, int nb, uint32_t *block_counts,
-                       int32_t *seg_start, float *gx, float *gy, float *gz, hipStream_t s)
-{
-  const int nblocks = (int)(((size_t)n + kSegBlock - 1) / kSegBlock);
-  if (nblocks == 0 || nb <= 0) return;
-  hipLaunchKernelGGL(k_seg_count, dim3(nblocks), dim3(256), (size_t)nb * sizeof(unsigned), s, ids, drop, n, nb, block_counts);
-  hipLaunchKernelGGL(k_seg_scan, dim3(1), dim3(1024), 0, s, block_counts, nblocks, nb, seg_start);
-  hipLaunchKernelGGL(k_seg_scatter, dim3(nblocks), dim3(64), (size_t)nb * sizeof(unsigned), s, ids, drop, x, y, z, m_cam, n, nb, block_counts,
-                     seg_start, gx, gy, gz);
-}
-
-void launch_pca_bbox(const float *gx, const float *gy, const float *gz, const int32_t *seg_start, int nb, const RansacState *st,
-                     bool use_plane, uint32_t n_cloud, gv_lshape_pose *poses, uint8_t *valid, RansacState *st_copy,
-                     const CallDone &done, hipStream_t s, gv_lshape_pose *poses_dev)
+void launch_pca_rect(const CellNode *sorted, const uint32_t *n_sel, uint32_t n, const uint8_t *keep, long long *acc, unsigned *ext,
+                     unsigned *ticket, int nb, const RansacState *st, bool use_plane, gv_lshape_pose *poses, uint8_t *valid,
+                     RansacState *st_copy, const CallDone &done, hipStream_t s, gv_lshape_pose *poses_dev)
 {
   if (nb <= 0) return;
-  hipLaunchKernelGGL(k_pca_bbox, dim3(nb), dim3(64), 0, s, gx, gy, gz, seg_start, nb, st, use_plane ? 1 : 0, n_cloud, poses, valid,
-                     st_copy, done, poses_dev);
+  const uint32_t blk = (uint32_t)std::max<size_t>(1, std::min<size_t>(((size_t)n + 255) / 256, 1024));
+  hipLaunchKernelGGL(k_pca_cov, dim3(blk), dim3(256), 0, s, sorted, n_sel, keep, acc, nb);
+  hipLaunchKernelGGL(k_pca_extent, dim3(blk), dim3(256), 0, s, sorted, n_sel, keep, acc, ext, ticket, nb, st, use_plane ? 1 : 0, n,
+                     poses, valid, st_copy, done, poses_dev);
 }
+
+size_t pca_acc_words(int nb) { return (size_t)nb * kAccStride; }
 
 }  // namespace gv

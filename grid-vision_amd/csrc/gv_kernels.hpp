@@ -269,25 +269,25 @@ void launch_ransac_mask(const float *x, const float *y, const float *z, uint32_t
 struct CellNode {
   float x, y, z;    // camera frame
   int32_t id;       // bbox
-  int32_t orig;     // index in the cloud
-  int32_t pad[3];
 };
-static_assert(sizeof(CellNode) == 32, "one node = one 32-byte access");
-// extractCloudPerBBox + RadiusOutlierRemoval: ids[n] (ground points of st->refined dropped when use_plane) and
-// drop[n] (1 = not selected or filtered out).  cell_cnt[n_buckets] must be zero on entry (left zero), pre has
-// n_buckets + 1 entries, blk_off n_buckets / 4096 + 1, *ticket zero on entry; sorted holds n nodes.
-// n_buckets: a power of two >= 4096
+static_assert(sizeof(CellNode) == 16, "one node = one 16-byte access");
+// extractCloudPerBBox + RadiusOutlierRemoval: ids[n] (ground points of st->refined dropped when use_plane), the
+// selected points in bucket order (sorted, their number at pre[n_buckets]), keep[t] = 1 where sorted point t survives
+// the filter, and the kept points' coordinate sums in acc (pca_acc_words(nb) 64-bit words, zero on entry).
+// cell_cnt[n_buckets] must be zero on entry (left zero), pre has n_buckets + 1 entries, blk_off n_buckets / 4096 + 1,
+// *ticket zero on entry; sorted holds n nodes, keep n bytes.  n_buckets: a power of two >= 4096
 void launch_radius_filter(const float *x, const float *y, const float *z, uint32_t n, const Mat34f &m_cam, const CamK &cam,
-                          const BBoxTest &bt, int nb, bool use_plane, float thr_f, RansacState *st, int16_t *ids, uint8_t *drop,
-                          uint32_t *cell_cnt, uint32_t *pre, uint32_t *blk_off, unsigned *ticket, CellNode *sorted,
-                          uint32_t n_buckets, float r2f, int min_pts, hipStream_t s);
-// stable split of the kept points by bbox id: seg_start[nb + 1], camera coordinates in segment order
-void launch_split_kept(const int16_t *ids, const uint8_t *drop, const float *x, const float *y, const float *z, const Mat34f &m_cam,
-                       uint32_t n, int nb, uint32_t *block_counts, int32_t *seg_start, float *gx, float *gy, float *gz, hipStream_t s);
-// st_copy (optional): *st is copied there by the kernel (one read-back block for poses, flags and state)
-// poses_dev (optional, device memory): a second copy of the camera-frame poses with length = -1 where valid[b] == 0
-void launch_pca_bbox(const float *gx, const float *gy, const float *gz, const int32_t *seg_start, int nb, const RansacState *st,
-                     bool use_plane, uint32_t n_cloud, gv_lshape_pose *poses, uint8_t *valid, RansacState *st_copy,
-                     const CallDone &done, hipStream_t s, gv_lshape_pose *poses_dev = nullptr);
+                          const BBoxTest &bt, int nb, bool use_plane, float thr_f, RansacState *st, int16_t *ids,
+                          uint32_t *cell_cnt, uint32_t *pre, uint32_t *blk_off, unsigned *ticket, CellNode *sorted, uint8_t *keep,
+                          long long *acc, uint32_t n_buckets, float r2f, int min_pts, hipStream_t s);
+size_t pca_acc_words(int nb);
+// centroid + PCA rectangle of every bbox's kept points (bboxPoseEstimation :156-181, computePCABoundingBox :187-247)
+// from order-independent integer sums: covariance pass, extents pass, poses by the last workgroup.  acc / ext
+// (4 words per bbox) / *ticket are zero on entry and left zero.  st_copy (optional): *st is copied there (one read-back
+// block for poses, flags and state); poses_dev (optional, device memory): a second copy of the camera-frame poses with
+// length = -1 where valid[b] == 0
+void launch_pca_rect(const CellNode *sorted, const uint32_t *n_sel, uint32_t n, const uint8_t *keep, long long *acc, unsigned *ext,
+                     unsigned *ticket, int nb, const RansacState *st, bool use_plane, gv_lshape_pose *poses, uint8_t *valid,
+                     RansacState *st_copy, const CallDone &done, hipStream_t s, gv_lshape_pose *poses_dev = nullptr);
 
 }  // namespace gv

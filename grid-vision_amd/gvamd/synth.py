@@ -207,6 +207,67 @@ def lshape_poses(config: int, b: int | None = None, seed_extra: int = 0):
     return out
 
 
+def _quat_to_matrix(q):
+    x, y, z, w = (float(v) for v in q)
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                     [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                     [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+
+def scene_with_objects(tfs: dict, n_total: int = 1_000_000, seed: int = 17, n_obj: int = 40, per: int = 6000):
+    """A config-3 sized scene WITH STRUCTURE, the workload of the tick legs (a uniform cloud loses every point to the
+    radius filter: no poses): a ground plane, n_obj dense objects in front of the camera -- each inside a pixel box of
+    its own, labels cycling vehicle / person / bike / motorbike / traffic light, so four of five boxes are dynamic --,
+    a lidar-like near field and uniform clutter, shuffled as a sensor delivers it.  Returns x, y, z (lidar frame,
+    float32) and the boxes (BBOX_DTYPE, confidence descending).  numpy's own generator: inputs only, nothing here is
+    compared bit for bit across platforms."""
+    rng = np.random.default_rng(seed)
+    xs, ys, zs = [], [], []
+    ocx = rng.uniform(6.0, 60.0, n_obj)
+    ocy = rng.uniform(-0.6, 0.6, n_obj) * ocx
+    ocz = rng.uniform(-1.0, 0.4, n_obj)
+    for k in range(n_obj):
+        ang = rng.uniform(0, np.pi)
+        a, c = rng.uniform(-2.2, 2.2, per), rng.uniform(-0.8, 0.8, per)
+        xs.append(ocx[k] + a * np.cos(ang) - c * np.sin(ang))
+        ys.append(ocy[k] + a * np.sin(ang) + c * np.cos(ang))
+        zs.append(ocz[k] + rng.uniform(-0.5, 0.5, per))
+    ng = int(0.45 * n_total)
+    gx_ = rng.uniform(1.0, 90.0, ng)
+    gy_ = rng.uniform(-60.0, 60.0, ng)
+    xs.append(gx_); ys.append(gy_); zs.append(-1.75 + 0.004 * gx_ + rng.normal(0, 0.012, ng))
+    nl = int(0.15 * n_total)
+    lx, ly, lz, _ = cloud_lidar_like(3, nl, seed_extra=seed)
+    xs.append(lx); ys.append(ly); zs.append(lz)
+    nu = n_total - n_obj * per - ng - nl
+    assert nu >= 0, "n_total too small for the objects"
+    xs.append(rng.uniform(-44, 176, nu)); ys.append(rng.uniform(-110, 110, nu)); zs.append(rng.uniform(-2, 4, nu))
+    x = np.concatenate(xs).astype(np.float32)
+    y = np.concatenate(ys).astype(np.float32)
+    z = np.concatenate(zs).astype(np.float32)
+    # pixel boxes around the objects (fp64 projection: the boxes are inputs, not results)
+    tf = tfs["cam_lidar"]
+    r, t = _quat_to_matrix(tf[:4]), np.asarray(tf[4:7], dtype=np.float64)
+    boxes = []
+    for k in range(n_obj):
+        sl = slice(k * per, (k + 1) * per)
+        pc = np.stack([x[sl], y[sl], z[sl]], axis=1).astype(np.float64) @ r.T + t
+        ok = pc[:, 2] > 0.1
+        if ok.sum() < 100:
+            continue
+        u = FX * pc[ok, 0] / pc[ok, 2] + CX
+        v = FY * pc[ok, 1] / pc[ok, 2] + CY
+        x0, x1 = max(0.0, np.percentile(u, 2)), min(IMG_W - 1.0, np.percentile(u, 98))
+        y0, y1 = max(0.0, np.percentile(v, 2)), min(IMG_H - 1.0, np.percentile(v, 98))
+        if x1 - x0 > 3 and y1 - y0 > 3:
+            boxes.append((float(np.float32(x0 + 0.25)), float(np.float32(y0 + 0.5)), float(np.float32(x1 + 0.75)), float(np.float32(y1))))
+    b = np.zeros(len(boxes), dtype=BBOX_DTYPE)
+    for i, (x0, y0, x1, y1) in enumerate(boxes):
+        b[i] = (x0, y0, x1, y1, 0.99 - 0.01 * i, [9, 2, 0, 1, 5][i % 5])
+    perm = rng.permutation(len(x))
+    return x[perm], y[perm], z[perm], b
+
+
 def network_outputs(b: int, seed: int = 7):
     """Synthetic vision-orientation network outputs: orient[b,2,2] (cos,sin per
     bin), conf[b,2], dims[b,3] residuals (vision_orientation.cpp:461-463)."""

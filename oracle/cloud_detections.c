@@ -142,6 +142,62 @@ void gvo_radius_outlier(const float *x, const float *y, const float *z, size_t n
   }
 }
 
+/* The same filter for clouds the all-pairs loop cannot finish (a 20 k-point box is 4e8 pairs): points bucketed by
+ * cubic cells a little wider than the radius, every query visits its 27 cells.  The predicate is the SAME
+ * expression on the same fp32 values, so keep[] is identical to gvo_radius_outlier's (tests pin that); only the
+ * candidate set is pruned.  PCL itself answers the query through a KD-tree, i.e. the reference's CPU cost is of
+ * this order, not the all-pairs one: bench.py times this variant as the CPU baseline of the PCA tick. */
+typedef struct { uint64_t key; uint32_t idx; } gvo_cell_entry;
+static int cell_entry_cmp(const void *a, const void *b)
+{
+  const gvo_cell_entry *p = (const gvo_cell_entry *)a, *q = (const gvo_cell_entry *)b;
+  if (p->key != q->key) return p->key < q->key ? -1 : 1;
+  return p->idx < q->idx ? -1 : (p->idx > q->idx);
+}
+static inline int64_t cell_coord(float c, double cs)
+{
+  double q = floor((double)c / cs);
+  if (!(q > -1.0e6)) q = -1.0e6;   /* NaN and far-away coordinates share the border cells: their distance */
+  if (q > 1.0e6) q = 1.0e6;        /* test fails or passes on its own merits, the cells only prune        */
+  return (int64_t)q + 1048576;     /* 0 .. 2^21 */
+}
+static inline uint64_t cell_key(int64_t ix, int64_t iy, int64_t iz) { return ((uint64_t)ix << 42) | ((uint64_t)iy << 21) | (uint64_t)iz; }
+void gvo_radius_outlier_grid(const float *x, const float *y, const float *z, size_t n,
+                             double radius, int32_t min_pts, uint8_t *keep)
+{
+  if (n == 0) return;
+  const double r2 = radius * radius;
+  const double cs = radius * 1.025;   /* every accepted neighbour differs by <= radius (1 + 1e-6) per axis */
+  gvo_cell_entry *e = (gvo_cell_entry *)malloc(n * sizeof(gvo_cell_entry));
+  for (size_t i = 0; i < n; ++i) {
+    e[i].key = cell_key(cell_coord(x[i], cs), cell_coord(y[i], cs), cell_coord(z[i], cs));
+    e[i].idx = (uint32_t)i;
+  }
+  qsort(e, n, sizeof(gvo_cell_entry), cell_entry_cmp);
+  for (size_t i = 0; i < n; ++i) {
+    const int64_t ix = cell_coord(x[i], cs), iy = cell_coord(y[i], cs), iz = cell_coord(z[i], cs);
+    int32_t cnt = 0;
+    for (int64_t dx = -1; dx <= 1 && cnt <= min_pts; ++dx)
+      for (int64_t dy = -1; dy <= 1 && cnt <= min_pts; ++dy) {
+        /* the three z-neighbour cells are one contiguous key range */
+        const int64_t z0 = iz > 0 ? iz - 1 : 0, z1 = iz + 1;
+        const uint64_t k0 = cell_key(ix + dx, iy + dy, z0), k1 = cell_key(ix + dx, iy + dy, z1);
+        size_t lo = 0, hi = n;
+        while (lo < hi) { const size_t mid = (lo + hi) / 2; if (e[mid].key < k0) lo = mid + 1; else hi = mid; }
+        for (size_t t = lo; t < n && e[t].key <= k1 && cnt <= min_pts; ++t) {
+          const size_t j = e[t].idx;
+          float d, r = 0.0f;
+          d = x[j] - x[i]; r += d * d;
+          d = y[j] - y[i]; r += d * d;
+          d = z[j] - z[i]; r += d * d;
+          if ((double)r <= r2) ++cnt;
+        }
+      }
+    keep[i] = (uint8_t)(cnt >= min_pts + 1);
+  }
+  free(e);
+}
+
 /* computePCABoundingBox :227  `float angle = std::atan2(major.y, major.x) * 180.0f / CV_PI;`
  * Promotion: std::atan2(float, float) is the float overload; `* 180.0f` is a float product; CV_PI is a
  * DOUBLE literal, so that product is widened, divided in fp64 and narrowed ONCE on the assignment.

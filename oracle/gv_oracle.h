@@ -166,6 +166,9 @@ void gvo_extract_cloud_per_bbox(const double K[9], const float *x, const float *
 /* RadiusOutlierRemoval(r, min_pts) [UPSTREAM-RECALL] brute force; keep[i] in {0,1} */
 void gvo_radius_outlier(const float *x, const float *y, const float *z, size_t n,
                         double radius, int32_t min_pts, uint8_t *keep);
+/* identical keep[] through a cell grid (27 cells per query): for box clouds the all-pairs loop cannot finish */
+void gvo_radius_outlier_grid(const float *x, const float *y, const float *z, size_t n,
+                             double radius, int32_t min_pts, uint8_t *keep);
 /* bboxPoseEstimation :140-185 + computePCABoundingBox :187-247 for ONE bbox
  * cloud (already filtered).  Returns 0 when the cloud is empty (:174-175). */
 int gvo_pca_bbox(const float *x, const float *y, const float *z, size_t n, gvo_lshape *out);

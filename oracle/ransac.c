@@ -16,7 +16,7 @@
  *   - refinement: one pass of fp64 raw moments of the inliers (as pcl::computeMeanAndCovarianceMatrix);
  *     every sum is taken by a fixed 64-ary tree over the cloud order (below), so that a parallel
  *     implementation rounds the same way as this one; covariance = Q/m - c c^T; normal = eigenvector
- *     of the smallest eigenvalue (cyclic Jacobi), d = -n.centroid; the final inlier set is
+ *     of the smallest eigenvalue (closed form, as pcl::eigen33), d = -n.centroid; the final inlier set is
  *     re-selected with the refined coefficients.
  */
 #include "gv_oracle.h"
@@ -58,43 +58,61 @@ static inline int is_inlier(const float c[4], float x, float y, float z, double 
   return (double)fabsf(d) < thr;   /* NaN -> 0 */
 }
 
-/* cyclic Jacobi on a symmetric 3x3 (fp64); returns the unit eigenvector of the smallest
- * eigenvalue, sign fixed so that its largest-magnitude component is positive */
+/* Unit eigenvector of the smallest eigenvalue of a symmetric 3x3 (fp64), closed form as pcl::eigen33(mat, eigenvalue,
+ * eigenvector) [UPSTREAM-RECALL], which SampleConsensusModelPlane::optimizeModelCoefficients calls: the matrix is scaled
+ * by its largest |entry|, the roots of the characteristic polynomial come from the trigonometric solution (computeRoots),
+ * and the eigenvector is the largest of the three cross products of rows of (A - lambda I).  Sign: the component of
+ * largest magnitude (the first of equals) is made positive.
+ * (Rounds 2-3 ran a cyclic Jacobi here -- ninety dependent fp64 divisions and square roots, 14 us of single-lane tail
+ * on the device; the step is specified by outcome, SURVEY 8(f)-2, and tests/test_oracle_second_opinions.py holds the
+ * refined plane against numpy's SVD either way.) */
 void gvo_smallest_eigenvector3(const double cov[6], double v[3])
 {
   double a[3][3] = {{cov[0], cov[1], cov[2]}, {cov[1], cov[3], cov[4]}, {cov[2], cov[4], cov[5]}};
-  double e[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
-  for (int sweep = 0; sweep < 32; ++sweep) {
-    const double off = a[0][1] * a[0][1] + a[0][2] * a[0][2] + a[1][2] * a[1][2];
-    if (off < 1e-300) break;
-    for (int p = 0; p < 2; ++p)
-      for (int q = p + 1; q < 3; ++q) {
-        if (a[p][q] == 0.0) continue;
-        const double theta = (a[q][q] - a[p][p]) / (2.0 * a[p][q]);
-        const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-        const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
-        for (int k = 0; k < 3; ++k) {
-          const double akp = a[k][p], akq = a[k][q];
-          a[k][p] = c * akp - s * akq;
-          a[k][q] = s * akp + c * akq;
-        }
-        for (int k = 0; k < 3; ++k) {
-          const double apk = a[p][k], aqk = a[q][k];
-          a[p][k] = c * apk - s * aqk;
-          a[q][k] = s * apk + c * aqk;
-        }
-        for (int k = 0; k < 3; ++k) {
-          const double ekp = e[k][p], ekq = e[k][q];
-          e[k][p] = c * ekp - s * ekq;
-          e[k][q] = s * ekp + c * ekq;
-        }
-      }
+  double scale = 0.0;
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j)
+      if (fabs(a[i][j]) > scale) scale = fabs(a[i][j]);
+  if (!(scale > 2.2250738585072014e-308)) scale = 1.0;
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) a[i][j] = a[i][j] / scale;
+  /* computeRoots: characteristic polynomial x^3 - c2 x^2 + c1 x - c0 */
+  const double c0 = (((a[0][0] * a[1][1]) * a[2][2] + (2.0 * a[0][1]) * a[0][2] * a[1][2]) - (a[0][0] * a[1][2]) * a[1][2]
+                     - (a[1][1] * a[0][2]) * a[0][2]) - (a[2][2] * a[0][1]) * a[0][1];
+  const double c1 = ((((a[0][0] * a[1][1] - a[0][1] * a[0][1]) + a[0][0] * a[2][2]) - a[0][2] * a[0][2]) + a[1][1] * a[2][2])
+                    - a[1][2] * a[1][2];
+  const double c2 = (a[0][0] + a[1][1]) + a[2][2];
+  double lam;
+  {
+    const double c2_over_3 = c2 * (1.0 / 3.0);
+    double a_over_3 = (c2 * c2_over_3 - c1) * (1.0 / 3.0);
+    if (a_over_3 < 0.0) a_over_3 = 0.0;
+    const double half_b = 0.5 * (c0 + c2_over_3 * (2.0 * c2_over_3 * c2_over_3 - c1));
+    double q = a_over_3 * a_over_3 * a_over_3 - half_b * half_b;
+    if (q < 0.0) q = 0.0;
+    const double rho = sqrt(a_over_3);
+    const double theta = atan2(sqrt(q), half_b) * (1.0 / 3.0);
+    const double cos_theta = cos(theta), sin_theta = sin(theta);
+    const double r0 = c2_over_3 + 2.0 * rho * cos_theta;
+    const double r1 = c2_over_3 - rho * (cos_theta + 1.7320508075688772 * sin_theta);
+    const double r2 = c2_over_3 - rho * (cos_theta - 1.7320508075688772 * sin_theta);
+    lam = r0;
+    if (r1 < lam) lam = r1;
+    if (r2 < lam) lam = r2;
+    if (lam <= 0.0) lam = 0.0;   /* a covariance matrix is positive semi-definite: eigen33 recomputes a root <= 0 as 0 */
   }
-  int m = 0;
-  if (a[1][1] < a[m][m]) m = 1;
-  if (a[2][2] < a[m][m]) m = 2;
-  double n[3] = {e[0][m], e[1][m], e[2][m]};
-  const double len = sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+  a[0][0] -= lam; a[1][1] -= lam; a[2][2] -= lam;
+  const double v1[3] = {a[0][1] * a[1][2] - a[0][2] * a[1][1], a[0][2] * a[1][0] - a[0][0] * a[1][2], a[0][0] * a[1][1] - a[0][1] * a[1][0]};
+  const double v2[3] = {a[0][1] * a[2][2] - a[0][2] * a[2][1], a[0][2] * a[2][0] - a[0][0] * a[2][2], a[0][0] * a[2][1] - a[0][1] * a[2][0]};
+  const double v3[3] = {a[1][1] * a[2][2] - a[1][2] * a[2][1], a[1][2] * a[2][0] - a[1][0] * a[2][2], a[1][0] * a[2][1] - a[1][1] * a[2][0]};
+  const double l1 = (v1[0] * v1[0] + v1[1] * v1[1]) + v1[2] * v1[2];
+  const double l2 = (v2[0] * v2[0] + v2[1] * v2[1]) + v2[2] * v2[2];
+  const double l3 = (v3[0] * v3[0] + v3[1] * v3[1]) + v3[2] * v3[2];
+  double n[3], len2;
+  if (l1 >= l2 && l1 >= l3) { n[0] = v1[0]; n[1] = v1[1]; n[2] = v1[2]; len2 = l1; }
+  else if (l2 >= l1 && l2 >= l3) { n[0] = v2[0]; n[1] = v2[1]; n[2] = v2[2]; len2 = l2; }
+  else { n[0] = v3[0]; n[1] = v3[1]; n[2] = v3[2]; len2 = l3; }
+  const double len = sqrt(len2);
   int big = 0;
   if (fabs(n[1]) > fabs(n[big])) big = 1;
   if (fabs(n[2]) > fabs(n[big])) big = 2;

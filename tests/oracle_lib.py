@@ -322,6 +322,14 @@ def radius_outlier(x, y, z, radius=0.4, min_pts=10):
     return keep
 
 
+def radius_outlier_grid(x, y, z, radius=0.4, min_pts=10):
+    x, y, z = f32(x), f32(y), f32(z)
+    keep = np.zeros(len(x), dtype=np.uint8)
+    lib().gvo_radius_outlier_grid(_p(x, C.c_float), _p(y, C.c_float), _p(z, C.c_float), C.c_size_t(len(x)),
+                                  C.c_double(radius), C.c_int32(min_pts), _p(keep, C.c_uint8))
+    return keep
+
+
 def pca_bbox(x, y, z):
     x, y, z = f32(x), f32(y), f32(z)
     out = np.zeros(1, dtype=LSHAPE_DTYPE)

@@ -589,10 +589,10 @@ def test_compute_depth_empty_and_behind(gvamd):
 
 def test_compute_bbox_pose_pca_path(gvamd):
     """use_vision_orientation=false path: extractCloudPerBBox + RadiusOutlierRemoval(0.4, 10)
-    + centroid + PCA rectangle per bbox, all on the device (cell-hash neighbour counts, stable split of the
-    kept points, sequential lane chains for the reference's order-dependent sums).  The RANSAC ground removal
-    is not part of this call.  The device follows the reference's accumulation order, so results equal the
-    oracle's; tolerance 1e-6 documents that nothing here is approximate."""
+    + centroid + PCA rectangle per bbox, all on the device (cell-hash neighbour counts, sixteen lanes per query;
+    the rectangle's sums as order-independent integers).  The RANSAC ground removal is not part of this call.
+    Against the oracle within SURVEY A11's 1e-4, against fp64 numpy much tighter (_check_pose_fp64); and the call
+    is bit-reproducible (integer sums: no dependence on the order workgroups arrive in)."""
     h, tfs = make_handle(gvamd, 2, perturbed=True)
     x, y, z, (cx, cy, cz), K, b = _cluster_scene(tfs, n_clusters=20, pts_per=500, seed=5)
     h.upload_xyz(x, y, z)
@@ -607,7 +607,11 @@ def test_compute_bbox_pose_pca_path(gvamd):
         if ok:
             n_valid += 1
             _check_pose(poses[i], e, i)
+            _check_pose_fp64(poses[i], cx[sel][keep], cy[sel][keep], cz[sel][keep], i)
     assert n_valid >= 10
+    for _ in range(3):   # bit-reproducible, call after call
+        p2, v2 = h.compute_bbox_pose(b)
+        assert p2.tobytes() == poses.tobytes() and v2.tobytes() == valid.tobytes()
     # and through the grid: transformLShapeObjects + updateMap(poses)
     g = synth.CONFIGS[2]["grid"]
     og = ol.OGrid(g.grid_x, g.grid_y, g.resolution)
@@ -619,12 +623,14 @@ def test_compute_bbox_pose_pca_path(gvamd):
     h.close()
 
 
-def test_compute_bbox_pose_more_than_64_boxes(gvamd):
-    """The kept-point split keeps its per-bbox cursors in one register up to 64 boxes and in LDS beyond: 90
-    clusters / boxes take the second form.  Same comparison as test_compute_bbox_pose_pca_path."""
+@pytest.mark.parametrize("n_clusters,pts_per", [(90, 150), (170, 120)])
+def test_compute_bbox_pose_many_boxes(gvamd, n_clusters, pts_per):
+    """Up to 128 boxes a workgroup keeps the boxes' integer sums / extents in an LDS table and flushes it once;
+    beyond that the atomics go to global memory directly: 90 and 170 clusters / boxes take the two forms.  Same
+    comparison as test_compute_bbox_pose_pca_path."""
     h, tfs = make_handle(gvamd, 2, perturbed=True)
-    x, y, z, (cx, cy, cz), K, b = _cluster_scene(tfs, n_clusters=90, pts_per=150, seed=23)
-    assert len(b) > 64
+    x, y, z, (cx, cy, cz), K, b = _cluster_scene(tfs, n_clusters=n_clusters, pts_per=pts_per, seed=23)
+    assert len(b) > (128 if n_clusters > 128 else 64)
     h.upload_xyz(x, y, z)
     poses, valid = h.compute_bbox_pose(b)
     ids = ol.extract_cloud_per_bbox(K, cx, cy, cz, b, synth.IMG_W, synth.IMG_H)
@@ -637,6 +643,7 @@ def test_compute_bbox_pose_more_than_64_boxes(gvamd):
         if ok:
             n_valid += 1
             _check_pose(poses[i], e, i)
+            _check_pose_fp64(poses[i], cx[sel][keep], cy[sel][keep], cz[sel][keep], i)
     assert n_valid >= 30
     h.close()
 
@@ -803,9 +810,9 @@ def test_gpu_matches_pca_fixture(gvamd):
         assert np.array_equal(depths, gold[f"knn_depth_{k}"])
         assert np.array_equal(d2, gold[f"knn_d2_{k}"])
     m, mask, coeff = h.segment_ground_plane()
-    assert m == int(gold["ground_n"][0])
-    assert np.array_equal(np.packbits(mask), gold["ground_mask_bits"])
-    assert np.array_equal(coeff, gold["ground_coeff"])
+    ccx, ccy, ccz = ol.transform_cloud(ol.tf_to_matrix4f(tfs["cam_lidar"]), x, y, z)
+    _check_plane(m, mask, coeff, int(gold["ground_n"][0]), np.unpackbits(gold["ground_mask_bits"])[:len(x)], gold["ground_coeff"],
+                 ccx, ccy, ccz)
     for call, vkey, pkey in ((lambda: h.compute_bbox_pose(b), "pose_valid", "poses"),
                              (lambda: h.compute_bbox_pose_ground_removed(b)[:2], "pose_valid_ground_removed", "poses_ground_removed")):
         poses, valid = call()
@@ -970,6 +977,21 @@ def test_config5_full_size(gvamd):
     h.close(); h2.close()
 
 
+def _check_plane(m, mask, coeff, em, emask, ecoeff, cx, cy, cz, thr=0.04, tag=None):
+    """RANSAC ground plane, specified by outcome: normally the device's refined plane equals the oracle's
+    to the last bit and so do the masks.  The closed-form eigenvector evaluates atan2 / cos / sin in fp64, where the device
+    library and glibc may differ in the last bit: a coefficient may then come out one fp32 ulp apart, and only points whose
+    distance sits within 1e-5 of the threshold may change sides."""
+    if np.array_equal(coeff, ecoeff):
+        assert m == em and np.array_equal(mask, emask), tag
+        return
+    assert np.allclose(coeff, ecoeff, rtol=3e-7, atol=1e-9), (tag, coeff, ecoeff)
+    d = np.abs(ecoeff[0] * cx + ecoeff[1] * cy + ecoeff[2] * cz + ecoeff[3])
+    far = np.abs(d - thr) > 1e-5
+    assert np.array_equal(mask[far], emask[far]), tag
+    assert abs(int(m) - int(em)) <= int(np.count_nonzero(~far)), tag
+
+
 def _ground_scene(tfs, seed=3):
     """ground plane (camera y ~ +1.6, slightly tilted, 2 cm noise) + the cluster scene on top"""
     x, y, z, _, K, b = _cluster_scene(tfs, n_clusters=16, pts_per=400, seed=seed)
@@ -992,9 +1014,8 @@ def test_segment_ground_plane_matches_oracle(gvamd):
     m, mask, coeff = h.segment_ground_plane()
     cx, cy, cz = ol.transform_cloud(ol.tf_to_matrix4f(tfs["cam_lidar"]), x, y, z)
     em, emask, ecoeff = ol.segment_ground_plane(cx, cy, cz)
-    assert m == em > 50_000
-    assert np.array_equal(mask, emask)
-    assert np.array_equal(coeff, ecoeff)
+    assert em > 50_000
+    _check_plane(m, mask, coeff, em, emask, ecoeff, cx, cy, cz)
     # planted ground points are (nearly all) found, cluster points above ground are not
     ng = 60_000
     assert mask[-ng:].mean() > 0.9
@@ -1025,21 +1046,44 @@ def test_compute_bbox_pose_ground_removed(gvamd):
         assert bool(valid[i]) == ok
         if ok:
             nv += 1
-            for f in ("px", "py", "pz", "length", "width"):
-                assert poses[i][f] == pytest.approx(e[f], rel=1e-6, abs=1e-6), (i, f)
+            _check_pose(poses[i], e, i)
     assert nv == npz >= 8
     h.close()
 
 
 def _check_pose(p, e, tag):
-    """centre and extents within 1e-6 of the oracle's arithmetic.  The orientation is setRPY(0, -angle, 0) with the
-    angle in DEGREES handed over as radians (cloud_detections.cpp:227,236): one ulp of the fp32 angle (up to
-    1.5e-5 at 180) moves sin / cos of half of it by up to 7.6e-6, and the device's atan2 (fp64, rounded once)
-    and glibc's atan2f do differ by one ulp now and then -- hence 8e-6 on the quaternion."""
+    """centre and extents within SURVEY A11's 1e-4 of the oracle's arithmetic.  The oracle follows the reference's
+    order-dependent sums (fp32 running sums for the means); the device takes the same sums exactly (fixed point,
+    gv_cloudops.hip), so the two differ by the rounding the REFERENCE accumulates (~sqrt(n) ulp of fp32), not by
+    anything the device approximates -- _check_pose_fp64 holds the device against fp64 numpy, much tighter.
+    The orientation is setRPY(0, -angle, 0) with the angle in DEGREES handed over as radians
+    (cloud_detections.cpp:227,236): an axis off by 1e-6 rad moves the fp32 angle by 6e-5, sin / cos of half of it by
+    3e-5."""
     for f in ("px", "py", "pz", "length", "width"):
-        assert p[f] == pytest.approx(e[f], rel=1e-6, abs=1e-6), (tag, f)
+        assert p[f] == pytest.approx(e[f], rel=1e-4, abs=1e-4), (tag, f)
     for f in ("qx", "qy", "qz", "qw"):
-        assert p[f] == pytest.approx(e[f], abs=8e-6), (tag, f)
+        assert p[f] == pytest.approx(e[f], abs=2e-4), (tag, f)
+
+
+def _check_pose_fp64(p, x, y, z, tag):
+    """second opinion that does not go through the oracle: the kept points' means in fp64 numpy.  The device's sums
+    are exact to 2^-28 m per term, so its centre is the fp64 mean rounded to fp32 (half an ulp + the quantisation)."""
+    for f, a in (("px", x), ("py", y), ("pz", z)):
+        m = float(np.mean(a.astype(np.float64)))
+        assert abs(p[f] - m) <= 1.3e-7 * max(1.0, abs(m)) + 1e-8, (tag, f, p[f], m)
+    D = np.stack([z.astype(np.float64), x.astype(np.float64)], axis=1)
+    mean = D.mean(axis=0)
+    cov = (D - mean).T @ (D - mean) / len(x)
+    wv, V = np.linalg.eigh(cov)
+    if not (wv[1] - wv[0] >= 1e-3 * wv[1] and wv[1] > 0):
+        return   # (nearly) isotropic or degenerate: the axes are ill-conditioned, extents are compared through the oracle only
+    major = V[:, 1] * (1.0 if V[0, 1] >= 0 else -1.0)
+    minor = np.array([-major[1], major[0]])
+    pl, pw = (D - mean) @ major, (D - mean) @ minor
+    cond = wv[1] / (wv[1] - wv[0])
+    tol = 1e-4 * max(1.0, float(pl.max() - pl.min())) * max(1.0, cond)
+    assert abs(p["length"] - (pl.max() - pl.min())) <= tol, (tag, "length")
+    assert abs(p["width"] - (pw.max() - pw.min())) <= tol, (tag, "width")
 
 
 def _radius_keep_ckdtree(x, y, z, r=0.4, min_pts=10):
@@ -1160,9 +1204,8 @@ def test_pca_path_at_config3_size(gvamd):
     # --- RANSAC ground plane (:105-138, by outcome)
     m, mask, coeff = h.segment_ground_plane()
     em, emask, ecoeff = ol.segment_ground_plane(cx, cy, cz)
-    assert m == em > 350_000
-    assert np.array_equal(coeff, ecoeff)
-    assert np.array_equal(mask, emask)
+    assert em > 350_000
+    _check_plane(m, mask, coeff, em, emask, ecoeff, cx, cy, cz)
     # --- computeBBoxPose without / with ground removal (:140-321)
     poses, valid = h.compute_bbox_pose(b)
     ids, ref = _pose_reference(cx, cy, cz, K, b, _radius_keep_ckdtree)
@@ -1173,8 +1216,8 @@ def test_pca_path_at_config3_size(gvamd):
         if ok:
             n_valid += 1
             _check_pose(poses[i], e, (i, nk))
-    assert n_valid >= 25
-    assert max(r[2] for r in ref) >= 4000   # a bbox with thousands of kept points: several LDS tiles of the chains
+    assert n_valid == sum(1 for r in ref if r[0]) >= 15   # the oracle's own count; the scene gives a few dozen
+    assert max(r[2] for r in ref) >= 4000   # a bbox with thousands of kept points
     poses2, valid2, npz = h.compute_bbox_pose_ground_removed(b)
     g = emask == 0
     _, ref2 = _pose_reference(cx[g], cy[g], cz[g], K, b, _radius_keep_ckdtree)
@@ -1184,7 +1227,7 @@ def test_pca_path_at_config3_size(gvamd):
         if ok:
             nv += 1
             _check_pose(poses2[i], e, (i, nk))
-    assert nv == npz >= 25
+    assert nv == npz == sum(1 for r in ref2 if r[0]) >= 15
     h.close()
 
 
@@ -1208,7 +1251,7 @@ def test_bbox_pose_beyond_one_million_points(gvamd):
         if ok:
             n_valid += 1
             _check_pose(poses[i], e, (i, nk))
-    assert n_valid >= 15
+    assert n_valid == sum(1 for r in ref if r[0]) >= 10   # the oracle's own count (round-3 verdict: not a constant)
     h.close()
 
 
@@ -1390,9 +1433,7 @@ def test_ransac_tree_levels_and_failure_paths(gvamd):
         for iters, seed in ((50, 12345), (7, 99)) + (((2500, 5),) if n == 70_001 else ()):
             m, mask, coeff = h.segment_ground_plane(0.04, iters, seed)
             em, emask, ecoeff = ol.segment_ground_plane(cx, cy, cz, 0.04, iters, seed)
-            assert m == em, (n, iters)
-            assert np.array_equal(coeff, ecoeff), (n, iters)
-            assert np.array_equal(mask, emask), (n, iters)
+            _check_plane(m, mask, coeff, em, emask, ecoeff, cx, cy, cz, tag=(n, iters))
     # everything on one plane: computeBBoxPose's "empty segmented cloud" (:307-309)
     n = 20_000
     gx_ = rng.uniform(1.0, 60.0, n); gy_ = rng.uniform(-30.0, 30.0, n)

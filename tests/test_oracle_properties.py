@@ -308,3 +308,31 @@ def test_oracle_reproduces_pca_fixture():
     for k in gold.files:
         assert np.array_equal(gold[k], now[k]), k
     assert int(gold["ground_n"][0]) > 8000 and gold["pose_valid"].sum() >= 6
+
+
+def test_radius_outlier_grid_equals_all_pairs():
+    """oracle/cloud_detections.c: the cell-grid form of RadiusOutlierRemoval (what bench.py times as the CPU baseline of
+    the PCA tick, and what the 1 M-point tests may use) keeps exactly the points the all-pairs statement keeps:
+    clustered clouds, points exactly on cell borders and at the radius, NaN / far-away coordinates, tiny clouds."""
+    rng = np.random.default_rng(21)
+    clouds = []
+    for trial in range(6):
+        cen = rng.uniform(-20, 20, (8, 3))
+        pts = np.concatenate([cen[i] + rng.normal(0, rng.uniform(0.05, 0.6), (int(rng.integers(5, 400)), 3)) for i in range(8)]
+                             + [rng.uniform(-25, 25, (500, 3))])
+        clouds.append(pts)
+    lattice = np.stack(np.meshgrid(np.arange(-4, 5), np.arange(-4, 5), np.arange(-2, 3)), -1).reshape(-1, 3) * 0.41
+    clouds.append(lattice)                         # points on the borders of the 0.41 m cells
+    clouds.append(lattice * (0.4 / 0.41))          # neighbours exactly at the radius
+    wild = rng.normal(0, 0.2, (300, 3))
+    wild[0] = [np.nan, 0, 0]; wild[1] = [3e7, 0, 0]; wild[2] = [-3e7, 1, 1]; wild[3] = [np.inf, 0, 0]
+    clouds.append(wild)
+    clouds.append(rng.normal(0, 0.1, (7, 3)))      # fewer points than min_pts + 1
+    clouds.append(np.zeros((0, 3)))
+    for pts in clouds:
+        pts = pts.astype(np.float32)
+        x, y, z = pts[:, 0].copy(), pts[:, 1].copy(), pts[:, 2].copy()
+        a = ol.radius_outlier(x, y, z, 0.4, 10)
+        b = ol.radius_outlier_grid(x, y, z, 0.4, 10)
+        assert np.array_equal(a, b)
+    assert ol.radius_outlier_grid(*[c.astype(np.float32) for c in clouds[0].T], 0.4, 10).mean() > 0.2
