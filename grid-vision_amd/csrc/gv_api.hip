@@ -2562,9 +2562,9 @@ static int enqueue_bbox_pose(gv_context *h, int32_t nb, bool with_ground, float 
     h->pca_cap = 0;
     const size_t want = (size_t)nb + (size_t)nb / 4 + 64;
     GV_HIP(hipMalloc(reinterpret_cast<void **>(&h->d_pca_acc), pca_acc_words((int)want) * sizeof(long long)));
-    GV_HIP(hipMalloc(reinterpret_cast<void **>(&h->d_pca_ext), want * 4 * sizeof(unsigned)));
+    GV_HIP(hipMalloc(reinterpret_cast<void **>(&h->d_pca_ext), pca_ext_words((int)want) * sizeof(unsigned)));
     GV_HIP(hipMemsetAsync(h->d_pca_acc, 0, pca_acc_words((int)want) * sizeof(long long), h->stream));   // every call leaves them zero
-    GV_HIP(hipMemsetAsync(h->d_pca_ext, 0, want * 4 * sizeof(unsigned), h->stream));
+    GV_HIP(hipMemsetAsync(h->d_pca_ext, 0, pca_ext_words((int)want) * sizeof(unsigned), h->stream));
     h->pca_cap = want;
   }
   if (!h->d_pca_ticket) {
@@ -2600,7 +2600,7 @@ static int enqueue_bbox_pose(gv_context *h, int32_t nb, bool with_ground, float 
                        host::floor_to_float(radius * radius), 10, s);
   h->have_bbox_id = true;
   // centroid + PCA rectangle per bbox from order-independent integer sums over the kept points (:156-247)
-  launch_pca_rect(h->d_nodes, h->d_cellpre + n_buckets, (uint32_t)n, h->d_keep, h->d_pca_acc, h->d_pca_ext, h->d_pca_ticket, nb,
+  launch_pca_rect(h->d_nodes, h->d_celloff + n_buckets / 4096, (uint32_t)n, h->d_keep, h->d_pca_acc, h->d_pca_ext, h->d_pca_ticket, nb,
                   h->d_rstate, with_ground, reinterpret_cast<gv_lshape_pose *>(out), out + pose_block_valid_off(nb),
                   reinterpret_cast<RansacState *>(out + (size_t)nb * sizeof(gv_lshape_pose)), done, s, poses_dev);
   GV_HIP(hipGetLastError());

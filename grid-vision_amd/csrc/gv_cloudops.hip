@@ -34,13 +34,12 @@ __device__ __forceinline__ unsigned long long splitmix64_dev(unsigned long long 
 
 // hypothesis t: three draws of the counter-based stream seed + 3t + {0,1,2} (mod n), plane through the
 // three camera-frame points as PCL's SampleConsensusModelPlane (isSampleGood + computeModelCoefficients,
-// fp32).  An unusable sample gets a NaN plane: it can never collect an inlier.
-__global__ void __launch_bounds__(64) k_ransac_hypotheses(const float *__restrict__ x, const float *__restrict__ y,
-                                                          const float *__restrict__ z, uint32_t n, Mat34f m,
-                                                          unsigned long long seed, int iters, float4 *__restrict__ planes)
+// fp32).  An unusable sample gets a NaN plane: it can never collect an inlier.  Every workgroup of the counting
+// pass makes the planes itself (150 loads: cheaper than a launch of its own and the 4 us of a one-wavefront kernel).
+__device__ __forceinline__ float4 ransac_hypothesis(const float *__restrict__ x, const float *__restrict__ y,
+                                                    const float *__restrict__ z, uint32_t n, const Mat34f &m,
+                                                    unsigned long long seed, int t)
 {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= iters) return;
   float p[3][3];
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
@@ -65,7 +64,7 @@ __global__ void __launch_bounds__(64) k_ransac_hypotheses(const float *__restric
       }
     }
   }
-  planes[t] = out;
+  return out;
 }
 
 // |n.p + d| < thr with the oracle's operation order.  thr_f is the smallest float >= the fp64 threshold:
@@ -81,13 +80,13 @@ __device__ __forceinline__ bool plane_inlier_dev(const float4 &pl, float px, flo
 // wavefront the four ballots are counted on the scalar unit and one lane adds them to the plane's LDS counter.
 __global__ void __launch_bounds__(kCoThreads) k_ransac_count_all(const float *__restrict__ x, const float *__restrict__ y,
                                                                  const float *__restrict__ z, uint32_t n, Mat34f m,
-                                                                 const float4 *__restrict__ planes, int iters, float thr_f,
+                                                                 unsigned long long seed, int h0, int iters, float thr_f,
                                                                  unsigned *__restrict__ counts, int stride)
 {
   extern __shared__ float4 s_pl[];   // iters planes, then iters counters
   unsigned *s_cnt = reinterpret_cast<unsigned *>(s_pl + iters);
   const int tid = threadIdx.x;
-  for (int t = tid; t < iters; t += kCoThreads) { s_pl[t] = planes[t]; s_cnt[t] = 0u; }
+  for (int t = tid; t < iters; t += kCoThreads) { s_pl[t] = ransac_hypothesis(x, y, z, n, m, seed, h0 + t); s_cnt[t] = 0u; }
   const float qnan = __uint_as_float(0x7fc00000u);
   float px[kCoPts], py[kCoPts], pz[kCoPts];
   const size_t base = (size_t)blockIdx.x * kCoBlock;
@@ -205,7 +204,7 @@ __device__ __forceinline__ double wave_butterfly(double v)
 // the device rounds exactly as the oracle does, whatever the number of workgroups.
 __global__ void __launch_bounds__(kCoThreads) k_ransac_moments(const float *__restrict__ x, const float *__restrict__ y,
                                                                const float *__restrict__ z, uint32_t n, Mat34f m,
-                                                               const float4 *__restrict__ planes, unsigned *__restrict__ counts,
+                                                               unsigned long long seed, unsigned *__restrict__ counts,
                                                                int iters, float thr_f, double *__restrict__ part_a,
                                                                double *__restrict__ part_b, RansacState *__restrict__ st)
 {
@@ -232,7 +231,7 @@ __global__ void __launch_bounds__(kCoThreads) k_ransac_moments(const float *__re
   }
   __syncthreads();
   const unsigned bestc = s_bestc;
-  const float4 pl = bestc ? planes[s_best] : make_float4(0.f, 0.f, 0.f, 0.f);
+  const float4 pl = bestc ? ransac_hypothesis(x, y, z, n, m, seed, s_best) : make_float4(0.f, 0.f, 0.f, 0.f);
   // A wavefront owns four level-0 groups (256 consecutive points).  Row q of 16 lanes takes group 4 w + q, and
   // lane r of the row the group's points r, r + 16, r + 32, r + 48: the butterfly's steps 32 and 16 are then adds
   // between the lane's own four values, and steps 8 .. 1 are DPP shifts inside the row -- for the four groups at
@@ -445,14 +444,14 @@ void launch_ransac_plane(const float *x, const float *y, const float *z, uint32_
                          hipStream_t s)
 {
   const uint32_t nblk = (uint32_t)(((size_t)n + kCoBlock - 1) / kCoBlock);
-  hipLaunchKernelGGL(k_ransac_hypotheses, dim3((iters + 63) / 64), dim3(64), 0, s, x, y, z, n, m_cam, seed, iters, planes);
+  (void)planes;   // (the hypotheses are no longer materialised: every workgroup makes the ones it needs)
   for (int h0 = 0; h0 < iters; h0 += 2048) {   // planes + counters of one launch sit in LDS (20 bytes per hypothesis)
     const int hn = std::min(2048, iters - h0);
     hipLaunchKernelGGL(k_ransac_count_all, dim3(nblk), dim3(kCoThreads), (size_t)hn * (sizeof(float4) + sizeof(unsigned)), s, x, y, z,
-                       n, m_cam, planes + h0, hn, thr_f, counts + h0, iters);
+                       n, m_cam, seed, h0, hn, thr_f, counts + h0, iters);
   }
   double *part_a = scratch, *part_b = scratch + (size_t)kMom * (nblk + 1);
-  hipLaunchKernelGGL(k_ransac_moments, dim3(nblk), dim3(kCoThreads), 0, s, x, y, z, n, m_cam, planes, counts, iters, thr_f, part_a,
+  hipLaunchKernelGGL(k_ransac_moments, dim3(nblk), dim3(kCoThreads), 0, s, x, y, z, n, m_cam, seed, counts, iters, thr_f, part_a,
                      part_b, st);
 }
 
@@ -536,8 +535,8 @@ __global__ void __launch_bounds__(kCoThreads) k_pose_classify(const float *__res
 
 // Exclusive prefix of the bucket counts, one launch: every workgroup scans its 4096 buckets (pre[b] = points
 // of its earlier buckets) and publishes its total; the workgroup whose ticket comes last turns the totals into
-// block offsets (k_cell_starts then adds them: pre[b] = first slot of bucket b, pre[n_buckets] = the number of
-// selected points).
+// block offsets: first slot of bucket b = pre[b] + blk_off[b >> 12] (bucket_start below), blk_off[n_buckets >> 12] =
+// the number of selected points, pre[n_buckets] = 0 so that the formula also gives the end of the last bucket.
 constexpr int kScanBlock = 4096;
 __global__ void __launch_bounds__(1024) k_cell_scan(const uint32_t *__restrict__ cell_cnt, uint32_t n_buckets,
                                                     uint32_t *__restrict__ pre, uint32_t *__restrict__ blk_off,
@@ -619,18 +618,12 @@ __global__ void __launch_bounds__(1024) k_cell_scan(const uint32_t *__restrict__
   }
 }
 
-// pre[b] += blk_off[b >> 12]: first slot of every bucket; entry n_buckets = the number of selected points
-__global__ void __launch_bounds__(1024) k_cell_starts(uint32_t *__restrict__ pre, const uint32_t *__restrict__ blk_off, uint32_t n_buckets)
+// first slot of bucket b = its offset inside its scan block + the block's offset (the scan leaves the two apart: a pass
+// that adds them up was a launch of its own, 5 us + a gap; the table of block offsets has n_buckets / 4096 entries and
+// sits in the caches of every consumer); bucket n_buckets = the number of selected points
+__device__ __forceinline__ uint32_t bucket_start(const uint32_t *__restrict__ pre, const uint32_t *__restrict__ blk_off, uint32_t b)
 {
-  const size_t b0 = (size_t)blockIdx.x * kScanBlock + (size_t)threadIdx.x * 4;
-  if (b0 < n_buckets) {
-    const unsigned o = blk_off[blockIdx.x];
-    uint4 v = *reinterpret_cast<uint4 *>(pre + b0);
-    v.x += o; v.y += o; v.z += o; v.w += o;
-    *reinterpret_cast<uint4 *>(pre + b0) = v;
-  } else if (b0 == n_buckets) {
-    pre[n_buckets] = blk_off[blockIdx.x];   // the extra workgroup: the total
-  }
+  return pre[b] + blk_off[b >> 12];
 }
 
 // selected points -> bucket order: slot = first slot of the bucket + a ticket out of the bucket's count, which
@@ -639,8 +632,8 @@ __global__ void __launch_bounds__(1024) k_cell_starts(uint32_t *__restrict__ pre
 __global__ void __launch_bounds__(kCoThreads) k_cell_scatter(const float *__restrict__ x, const float *__restrict__ y,
                                                              const float *__restrict__ z, uint32_t n, Mat34f m,
                                                              const int16_t *__restrict__ ids, uint32_t *__restrict__ cell_cnt,
-                                                             const uint32_t *__restrict__ start, uint32_t hi_mask,
-                                                             CellNode *__restrict__ sorted)
+                                                             const uint32_t *__restrict__ pre, const uint32_t *__restrict__ blk_off,
+                                                             uint32_t hi_mask, CellNode *__restrict__ sorted)
 {
 #pragma unroll
   for (int j = 0; j < kCoPts; ++j) {
@@ -655,7 +648,7 @@ __global__ void __launch_bounds__(kCoThreads) k_cell_scatter(const float *__rest
     CellNode nd;
     nd.x = cx; nd.y = cy; nd.z = cz;
     nd.id = id;
-    sorted[start[b] + k] = nd;
+    sorted[bucket_start(pre, blk_off, b) + k] = nd;
   }
 }
 
@@ -670,7 +663,10 @@ __global__ void __launch_bounds__(kCoThreads) k_cell_scatter(const float *__rest
 constexpr double kFixCoord = 268435456.0;    // 2^28: |coordinate| < 2^11 m and < 2^23 points keep the sum below 2^62
 constexpr double kFixProd = 67108864.0;      // 2^26: |centred sample| < 2^7 m
 constexpr float kCoordClamp = 2047.0f, kCentredClamp = 127.0f;
-constexpr int kAccStride = 8;                // per bbox: sum y, z, x, count, sum aa, ab, bb, (unused)
+constexpr int kAccStride = 16;               // per bbox: sum y, z, x, count, sum aa, ab, bb -- one 128-byte line each: the
+                                             // workgroups' flushes are same-line atomics otherwise (k_pca_extent with four
+                                             // boxes per line: 60 us of queueing at the L2)
+constexpr int kExtStride = 32;               // per bbox: four extent keys, one line each
 constexpr int kPcaTab = 128;                 // bboxes whose accumulators a workgroup keeps in LDS (more: global atomics)
 
 __device__ __forceinline__ long long fix_coord(float v) { return __double2ll_rn((double)fminf(fmaxf(v, -kCoordClamp), kCoordClamp) * kFixCoord); }
@@ -708,107 +704,213 @@ __device__ __forceinline__ void pca_means(const long long *__restrict__ a, float
 // Cells that are neighbours along x and share ix >> 3 are neighbouring BUCKETS (the low bucket bits are ix & 7), so a
 // row of up to three cells is one contiguous run of the sorted array (two when it straddles a multiple of 8).
 //
-// SIXTEEN lanes per point (one DPP row).  Round 3 used four, which walked the nine rows one after the other -- every
-// step a dependent trip to the L2 behind the running count: 9 to 18 trips per point, 65-116 us.  Now the eight rows
-// around the centre row have a lane each and the centre row (the point's own cell: where the hits are) eight lanes
-// that stride it; every step looks at up to sixteen candidates, the row-wide sum of hits and of lanes that still have
-// candidates is one DPP reduction, and the walk ends as soon as min_pts + 1 hits are in -- one or two trips for a
-// point inside an object, as many as its longest row for an outlier.  The kept points' coordinates are added to their
-// bbox's integer sums on the way out (LDS table per workgroup, flushed once).
+// Two phases per pass of 32 points and wavefront:
+//   A  one LANE per point: its cell, the cell range the fp32 test can reach, and its runs -- the point's OWN cell
+//      first (six candidates in ten of it are hits, a quarter in the cells beside it), then the cells beside it in
+//      its row, then the (up to two) runs of each of the eight rows around -- every bound requested before any is
+//      used; the non-empty runs are parked in LDS in that order;
+//   B  kRadLanes lanes per point, 64 / kRadLanes points at a time: the runs are one virtual list that the lanes
+//      stride together, kRadCand candidates per lane and step (all requested before any is looked at); the sum of
+//      hits and of lanes that still have candidates over the point's lanes is one DPP reduction, and the walk ends as
+//      soon as min_pts + 1 hits are in -- for a point inside an object after the first step.
+// (Round 3: four lanes per point walked the nine rows one after the other, x-neighbour cell first, every step a
+// dependent trip to the L2 behind the running count: 65-116 us.  The variants tried on the way here are in
+// profiles/r04/radius_filter_ab.txt.)  The kept points' coordinates are added to their bbox's integer sums on the way
+// out (LDS table per workgroup, flushed once; consecutive points of the bucket order belong to the same box, so a
+// workgroup flushes a handful of entries).
 template <int CTRL>
 __device__ __forceinline__ int dpp_i32(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, false); }
-__device__ __forceinline__ int row16_sum(int v)   // every lane of the row of 16 ends with the row's sum
+// every lane of a group of LANES consecutive lanes (8 or 16, aligned) ends with the group's sum
+template <int LANES>
+__device__ __forceinline__ int group_sum(int v)
 {
-  v += dpp_i32<0x128>(v);   // row_ror:8
-  v += dpp_i32<0x124>(v);   // row_ror:4
-  v += dpp_i32<0x122>(v);   // row_ror:2
-  v += dpp_i32<0x121>(v);   // row_ror:1
+  if constexpr (LANES == 16) {
+    v += dpp_i32<0x128>(v);   // row_ror:8
+    v += dpp_i32<0x124>(v);   // row_ror:4
+    v += dpp_i32<0x122>(v);   // row_ror:2
+    v += dpp_i32<0x121>(v);   // row_ror:1
+  } else {
+    v += dpp_i32<0x141>(v);   // row_half_mirror: lane i <-> 7 - i of its half row
+    v += dpp_i32<0xB1>(v);    // quad_perm [1,0,3,2]
+    v += dpp_i32<0x4E>(v);    // quad_perm [2,3,0,1]
+  }
   return v;
 }
 
-__global__ void __launch_bounds__(256) k_radius_sorted(const CellNode *__restrict__ sorted, const uint32_t *__restrict__ start,
-                                                       uint32_t n_buckets, uint32_t hi_mask, float r2f, int min_pts,
-                                                       uint8_t *__restrict__ keep, long long *__restrict__ acc, int nb)
+#ifndef GV_RAD_LANES
+#define GV_RAD_LANES 8
+#endif
+#ifndef GV_RAD_CAND
+#define GV_RAD_CAND 4
+#endif
+#ifndef GV_RAD_GRID
+#define GV_RAD_GRID 2048
+#endif
+constexpr int kRadPts = 32;                 // points per wavefront and pass
+constexpr int kRadLanes = GV_RAD_LANES;     // lanes per point in phase B
+constexpr int kRadCand = GV_RAD_CAND;       // candidates per lane and step
+constexpr int kRadRuns = 20;                // own cell + 2 beside it + 8 rows x 2 runs, the empty ones dropped
+constexpr int kBoffLds = 256;               // block offsets of the bucket scan kept in LDS (n_buckets < 1 M: clouds up to
+                                            // 2 M points; beyond that they are read from global memory)
+
+__global__ void __launch_bounds__(256) k_radius_sorted(const CellNode *__restrict__ sorted, const uint32_t *__restrict__ pre,
+                                                       const uint32_t *__restrict__ blk_off, uint32_t n_buckets, uint32_t hi_mask,
+                                                       float r2f, int min_pts, uint8_t *__restrict__ keep,
+                                                       long long *__restrict__ acc, int nb)
 {
   __shared__ long long s_acc[kPcaTab][4];
+  __shared__ uint2 s_run[4][kRadRuns][kRadPts];   // [begin, end) of a point's non-empty runs in visiting order
+  __shared__ float4 s_pt[4][kRadPts];
+  __shared__ uint32_t s_boff[kBoffLds];
   const bool tab = nb <= kPcaTab;
+  const uint32_t n_off = n_buckets >> 12;
+  // n_off + 1 entries: the end of the LAST bucket is start_of(n_buckets) = pre[n_buckets] (0) + the total
+  const bool staged = n_off + 1u <= (uint32_t)kBoffLds;
   if (tab)
     for (int i = threadIdx.x; i < nb * 4; i += 256) (&s_acc[0][0])[i] = 0;
+  if (staged)
+    for (uint32_t i = threadIdx.x; i <= n_off; i += 256) s_boff[i] = blk_off[i];
   __syncthreads();
-  const uint32_t n_sel = start[n_buckets];
-  const uint32_t g = threadIdx.x & 15u;
+  auto start_of = [&](uint32_t b) -> uint32_t { return pre[b] + (staged ? s_boff[b >> 12] : blk_off[b >> 12]); };
+  const uint32_t n_sel = blk_off[n_off];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const uint32_t g = (uint32_t)lane & (uint32_t)(kRadLanes - 1);
   const float4 *nodes = reinterpret_cast<const float4 *>(sorted);
-  for (uint32_t t = (blockIdx.x * 256u + threadIdx.x) >> 4; t < n_sel; t += gridDim.x * 16u) {
-    const float4 pv = nodes[t];
-    const float px = pv.x, py = pv.y, pz = pv.z;
-    const int myid = __float_as_int(pv.w);
-    const int ix = cell_of(px), iy = cell_of(py), iz = cell_of(pz);
-    int x0, x1, y0, y1, z0, z1;
-    cell_range(px, ix, x0, x1);
-    cell_range(py, iy, y0, y1);
-    cell_range(pz, iz, z0, z1);
-    int cnt = 0;   // the same in the sixteen lanes
-    auto test = [&](uint32_t j, bool on) -> int {
-      const float4 c = nodes[on ? j : t];
-      float d = c.x - px;
-      float r = __fmul_rn(d, d);
-      d = c.y - py; r = __fadd_rn(r, __fmul_rn(d, d));
-      d = c.z - pz; r = __fadd_rn(r, __fmul_rn(d, d));
-      return (on && __float_as_int(c.w) == myid && r <= r2f) ? 1 : 0;
-    };
-    if (x0 >= ix - 1 && x1 <= ix + 1 && y0 >= iy - 1 && y1 <= iy + 1 && z0 >= iz - 1 && z1 <= iz + 1) {
-      // lanes 0..7: the eight rows around the centre, one each; lanes 8..15: the centre row, strided by 8
-      const int q = (g < 8u) ? (int)g + ((int)g >= 4 ? 1 : 0) : 4;   // row number 0..8, 4 = centre
-      const int t3 = (q * 11) >> 5;                                   // q / 3
-      const int cy = iy + (q - 3 * t3) - 1, cz = iz + t3 - 1;
-      const bool in = cy >= y0 && cy <= y1 && cz >= z0 && cz <= z1;
+  const uint32_t n_pass = (n_sel + kRadPts - 1) / kRadPts;
+  for (uint32_t pass = blockIdx.x * 4u + (uint32_t)w; pass < n_pass; pass += gridDim.x * 4u) {
+    const uint32_t t0 = pass * kRadPts;
+    // ---- phase A: lane p < 32 prepares point t0 + p
+    if (lane < kRadPts) {
+      const uint32_t t = t0 + (uint32_t)lane;
+      float4 pv = make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
+      if (t < n_sel) pv = nodes[t];
+      const int myid = __float_as_int(pv.w);
+      const int ix = cell_of(pv.x), iy = cell_of(pv.y), iz = cell_of(pv.z);
+      int x0, x1, y0, y1, z0, z1;
+      cell_range(pv.x, ix, x0, x1);
+      cell_range(pv.y, iy, y0, y1);
+      cell_range(pv.z, iz, z0, z1);
+      const bool fast = x0 >= ix - 1 && x1 <= ix + 1 && y0 >= iy - 1 && y1 <= iy + 1 && z0 >= iz - 1 && z1 <= iz + 1;
+      const bool live = fast && t < n_sel;
       // cells x0..x1 are one run, or two when they straddle a multiple of 8
       const int xs = ((x0 >> 3) != (x1 >> 3)) ? (x1 & ~7) : x1 + 1;   // first cell of the second run (none: x1 + 1)
-      uint32_t a0 = 0, e0 = 0, a1 = 0, e1 = 0;
-      if (in) {
-        a0 = start[bucket_of(x0, cy, cz, myid, hi_mask)];
-        e0 = start[bucket_of(min(xs - 1, x1), cy, cz, myid, hi_mask) + 1u];
-        if (xs <= x1) {
-          a1 = start[bucket_of(xs, cy, cz, myid, hi_mask)];
-          e1 = start[bucket_of(x1, cy, cz, myid, hi_mask) + 1u];
-        }
+      const bool two = xs <= x1;
+      uint2 own = make_uint2(0u, 0u), lft = make_uint2(0u, 0u), rgt = make_uint2(0u, 0u);
+      if (live) {
+        const uint32_t b = bucket_of(ix, iy, iz, myid, hi_mask);
+        own = make_uint2(start_of(b), start_of(b + 1u));
+        if (x0 < ix) { const uint32_t bl = bucket_of(ix - 1, iy, iz, myid, hi_mask); lft = make_uint2(start_of(bl), start_of(bl + 1u)); }
+        if (x1 > ix) { const uint32_t br = bucket_of(ix + 1, iy, iz, myid, hi_mask); rgt = make_uint2(start_of(br), start_of(br + 1u)); }
       }
-      const uint32_t step = (g < 8u) ? 1u : 8u;
-      uint32_t j = a0 + ((g < 8u) ? 0u : g - 8u), e = e0;
-      bool second = false;
-      for (;;) {
-        if (j >= e && !second) {   // on to the row's second run (same stride phase)
-          second = true;
-          j = a1 + (j - e);
-          e = e1;
-        }
-        const bool on = j < e;
-        const int v = row16_sum(test(j, on) | (on ? 0x10000 : 0));
-        cnt += v & 0xffff;
-        if (cnt > min_pts || (v >> 16) == 0) break;
-        j += step;
-      }
-    } else {   // coordinates so large that fp32 spacing widens the range (capped at +-3 cells): cell by cell, 16 lanes per run
-      for (int cz = z0; cz <= z1 && cnt <= min_pts; ++cz)
-        for (int cy = y0; cy <= y1 && cnt <= min_pts; ++cy)
-          for (int cx = x0; cx <= x1 && cnt <= min_pts; ++cx) {
-            const uint32_t b = bucket_of(cx, cy, cz, myid, hi_mask);
-            const uint32_t e = start[b + 1u];
-            for (uint32_t j = start[b]; j < e && cnt <= min_pts; j += 16u) cnt += row16_sum(test(j + g, j + g < e));
+      uint4 rr[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int q = k + (k >= 4 ? 1 : 0);   // the eight rows around the centre
+        const int cy = iy + (q % 3) - 1, cz = iz + (q / 3) - 1;
+        const bool in = live && cy >= y0 && cy <= y1 && cz >= z0 && cz <= z1;
+        uint4 r = make_uint4(0u, 0u, 0u, 0u);
+        if (in) {
+          r.x = start_of(bucket_of(x0, cy, cz, myid, hi_mask));
+          r.y = start_of(bucket_of(min(xs - 1, x1), cy, cz, myid, hi_mask) + 1u);
+          if (two) {
+            r.z = start_of(bucket_of(xs, cy, cz, myid, hi_mask));
+            r.w = start_of(bucket_of(x1, cy, cz, myid, hi_mask) + 1u);
           }
+        }
+        rr[k] = r;
+      }
+      int nr = 0;
+      auto put_run = [&](uint32_t a, uint32_t e) {
+        if (e > a) { s_run[w][nr][lane] = make_uint2(a, e); ++nr; }
+      };
+      put_run(own.x, own.y);
+      put_run(lft.x, lft.y);
+      put_run(rgt.x, rgt.y);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { put_run(rr[k].x, rr[k].y); put_run(rr[k].z, rr[k].w); }
+      // (ids are below 2^15) id | runs << 16 | "cell by cell" << 30; negative: past the last selected point
+      if (t < n_sel) pv.w = __int_as_float(myid | (nr << 16) | (fast ? 0 : 0x40000000));
+      s_pt[w][lane] = pv;
     }
-    if (g == 0u) {
-      const bool kept = cnt >= min_pts + 1;
-      keep[t] = kept ? 1 : 0;
-      if (kept && myid < nb) {
-        const long long fy = fix_coord(py), fz = fix_coord(pz), fx = fix_coord(px);
-        if (tab) {
-          atomicAdd(reinterpret_cast<unsigned long long *>(&s_acc[myid][0]), (unsigned long long)fy);
-          atomicAdd(reinterpret_cast<unsigned long long *>(&s_acc[myid][1]), (unsigned long long)fz);
-          atomicAdd(reinterpret_cast<unsigned long long *>(&s_acc[myid][2]), (unsigned long long)fx);
-          atomicAdd(reinterpret_cast<unsigned long long *>(&s_acc[myid][3]), 1ull);
-        } else {
-          unsigned long long *a = reinterpret_cast<unsigned long long *>(acc + (size_t)myid * kAccStride);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // ---- phase B: kRadLanes lanes per point, 64 / kRadLanes points at a time
+    constexpr int kAtOnce = 64 / kRadLanes;
+    for (int sub = 0; sub < kRadPts / kAtOnce; ++sub) {
+      const int pi = sub * kAtOnce + lane / kRadLanes;
+      const uint32_t t = t0 + (uint32_t)pi;
+      const float4 pv = s_pt[w][pi];
+      const float px = pv.x, py = pv.y, pz = pv.z;
+      const int idw = __float_as_int(pv.w);
+      if (idw < 0) continue;   // past the last selected point (a point's lanes take this together)
+      const int myid = idw & 0xffff;
+      int cnt = 0;   // the same in all lanes of the point
+      auto hit = [&](const float4 &c, bool on) -> int {
+        float d = c.x - px;
+        float r = __fmul_rn(d, d);
+        d = c.y - py; r = __fadd_rn(r, __fmul_rn(d, d));
+        d = c.z - pz; r = __fadd_rn(r, __fmul_rn(d, d));
+        return (on && __float_as_int(c.w) == myid && r <= r2f) ? 1 : 0;
+      };
+      if (!(idw & 0x40000000)) {
+        // the runs as one list: lane g looks at entries g, g + kRadLanes, ...; a cursor (run, index, end of the run) that
+        // hops to the next run carrying its overshoot
+        const int nr = (idw >> 16) & 31;
+        int r = 0;
+        uint2 ae = nr ? s_run[w][0][pi] : make_uint2(0u, 0u);
+        uint32_t j = ae.x + g, e = ae.y;
+        for (;;) {
+          uint32_t jj[kRadCand];
+          bool on[kRadCand];
+          bool any = false;
+#pragma unroll
+          for (int u = 0; u < kRadCand; ++u) {
+            while (j >= e && r + 1 < nr) {
+              const uint32_t over = j - e;
+              ++r;
+              ae = s_run[w][r][pi];
+              j = ae.x + over;
+              e = ae.y;
+            }
+            jj[u] = j;
+            on[u] = j < e;
+            any = any || on[u];
+            j += (uint32_t)kRadLanes;
+          }
+          float4 c[kRadCand];
+#pragma unroll
+          for (int u = 0; u < kRadCand; ++u) c[u] = nodes[on[u] ? jj[u] : t];
+          int hs = 0;
+#pragma unroll
+          for (int u = 0; u < kRadCand; ++u) hs += hit(c[u], on[u]);
+          const int v = group_sum<kRadLanes>(hs | (any ? 0x10000 : 0));
+          cnt += v & 0xffff;
+          if (cnt > min_pts || (v >> 16) == 0) break;
+        }
+      } else {   // coordinates so large that fp32 spacing widens the range (capped at +-3 cells): cell by cell
+        const int ix = cell_of(px), iy = cell_of(py), iz = cell_of(pz);
+        int x0, x1, y0, y1, z0, z1;
+        cell_range(px, ix, x0, x1);
+        cell_range(py, iy, y0, y1);
+        cell_range(pz, iz, z0, z1);
+        for (int cz = z0; cz <= z1 && cnt <= min_pts; ++cz)
+          for (int cy = y0; cy <= y1 && cnt <= min_pts; ++cy)
+            for (int cx = x0; cx <= x1 && cnt <= min_pts; ++cx) {
+              const uint32_t b = bucket_of(cx, cy, cz, myid, hi_mask);
+              const uint32_t e = start_of(b + 1u);
+              for (uint32_t j = start_of(b); j < e && cnt <= min_pts; j += (uint32_t)kRadLanes) {
+                const bool on = j + g < e;
+                cnt += group_sum<kRadLanes>(hit(nodes[on ? j + g : t], on));
+              }
+            }
+      }
+      if (g == 0u) {
+        const bool kept = cnt >= min_pts + 1;
+        keep[t] = kept ? 1 : 0;
+        if (kept && myid < nb) {
+          const long long fy = fix_coord(py), fz = fix_coord(pz), fx = fix_coord(px);
+          unsigned long long *a = tab ? reinterpret_cast<unsigned long long *>(&s_acc[myid][0])
+                                      : reinterpret_cast<unsigned long long *>(acc + (size_t)myid * kAccStride);
           atomicAdd(a + 0, (unsigned long long)fy);
           atomicAdd(a + 1, (unsigned long long)fz);
           atomicAdd(a + 2, (unsigned long long)fx);
@@ -816,6 +918,8 @@ __global__ void __launch_bounds__(256) k_radius_sorted(const CellNode *__restric
         }
       }
     }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
   }
   if (!tab) return;
   __syncthreads();
@@ -937,7 +1041,7 @@ __global__ void __launch_bounds__(256) k_pca_extent(const CellNode *__restrict__
     const PcaAxes ax = tab ? s_ax[id] : pca_axes(acc + (size_t)id * kAccStride);
     const float dx = p.z - ax.m0, dy = p.x - ax.m1;
     const float pl = dx * ax.Mx + dy * ax.My, pw = dx * ax.Nx + dy * ax.Ny;
-    unsigned *e = tab ? &s_ext[id][0] : ext + (size_t)id * 4;
+    unsigned *e = tab ? &s_ext[id][0] : ext + (size_t)id * kExtStride;
     const unsigned kl = fkey(pl), kw = fkey(pw);
     atomicMax(e + 0, ~kl); atomicMax(e + 1, kl);
     atomicMax(e + 2, ~kw); atomicMax(e + 3, kw);
@@ -946,7 +1050,7 @@ __global__ void __launch_bounds__(256) k_pca_extent(const CellNode *__restrict__
   if (tab)
     for (int i = threadIdx.x; i < nb * 4; i += 256) {
       const unsigned v = (&s_ext[0][0])[i];
-      if (v != 0u) atomicMax(ext + i, v);
+      if (v != 0u) atomicMax(ext + (size_t)(i >> 2) * kExtStride + (i & 3), v);
     }
   // ---- the last workgroup to arrive writes the poses
   __threadfence();
@@ -964,17 +1068,17 @@ __global__ void __launch_bounds__(256) k_pca_extent(const CellNode *__restrict__
   // computeBBoxPose :307-309: an empty segmented cloud (no plane found, or everything is ground) -> no poses
   const bool none = use_plane && (st->best_count == 0 || st->n_inliers == 0ull || st->n_inliers == (unsigned long long)n_cloud);
   for (int b = threadIdx.x; b < nb; b += 256) {
-    long long a[kAccStride];
+    long long a[7];
 #pragma unroll
-    for (int k = 0; k < kAccStride; ++k) {
+    for (int k = 0; k < 7; ++k) {
       a[k] = __hip_atomic_load(acc + (size_t)b * kAccStride + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       acc[(size_t)b * kAccStride + k] = 0;
     }
     unsigned e[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      e[k] = __hip_atomic_load(ext + (size_t)b * 4 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      ext[(size_t)b * 4 + k] = 0u;
+      e[k] = __hip_atomic_load(ext + (size_t)b * kExtStride + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      ext[(size_t)b * kExtStride + k] = 0u;
     }
     gv_lshape_pose p{};
     bool ok = false;
@@ -1021,11 +1125,10 @@ void launch_radius_filter(const float *x, const float *y, const float *z, uint32
   hipLaunchKernelGGL(k_pose_classify, dim3(nblk), dim3(kCoThreads), 0, s, x, y, z, n, m_cam, cam, bt, nb, use_plane ? 1 : 0, thr_f, st,
                      ids, cell_cnt, hi_mask);
   hipLaunchKernelGGL(k_cell_scan, dim3(n_buckets / kScanBlock), dim3(1024), 0, s, cell_cnt, n_buckets, pre, blk_off, ticket);
-  hipLaunchKernelGGL(k_cell_starts, dim3(n_buckets / kScanBlock + 1), dim3(1024), 0, s, pre, blk_off, n_buckets);
-  hipLaunchKernelGGL(k_cell_scatter, dim3(nblk), dim3(kCoThreads), 0, s, x, y, z, n, m_cam, ids, cell_cnt, pre, hi_mask, sorted);
-  // sixteen lanes per selected point; their number is only known on the device: a fixed grid strides over them
-  const uint32_t rblk = (uint32_t)std::min<size_t>(((size_t)n * 16 + 255) / 256, 4096);
-  hipLaunchKernelGGL(k_radius_sorted, dim3(rblk), dim3(256), 0, s, sorted, pre, n_buckets, hi_mask, r2f, min_pts, keep, acc, nb);
+  hipLaunchKernelGGL(k_cell_scatter, dim3(nblk), dim3(kCoThreads), 0, s, x, y, z, n, m_cam, ids, cell_cnt, pre, blk_off, hi_mask, sorted);
+  // 32 selected points per wavefront and pass; their number is only known on the device: a fixed grid strides over them
+  const uint32_t rblk = (uint32_t)std::max<size_t>(1, std::min<size_t>(((size_t)n + 4 * kRadPts - 1) / (4 * kRadPts), GV_RAD_GRID));
+  hipLaunchKernelGGL(k_radius_sorted, dim3(rblk), dim3(256), 0, s, sorted, pre, blk_off, n_buckets, hi_mask, r2f, min_pts, keep, acc, nb);
 }
 
 void launch_pca_rect(const CellNode *sorted, const uint32_t *n_sel, uint32_t n, const uint8_t *keep, long long *acc, unsigned *ext,
@@ -1033,12 +1136,14 @@ void launch_pca_rect(const CellNode *sorted, const uint32_t *n_sel, uint32_t n, 
                      RansacState *st_copy, const CallDone &done, hipStream_t s, gv_lshape_pose *poses_dev)
 {
   if (nb <= 0) return;
-  const uint32_t blk = (uint32_t)std::max<size_t>(1, std::min<size_t>(((size_t)n + 255) / 256, 1024));
+  // few workgroups: every one of them ends with a flush of its table into the boxes' accumulators
+  const uint32_t blk = (uint32_t)std::max<size_t>(1, std::min<size_t>(((size_t)n + 1023) / 1024, 256));
   hipLaunchKernelGGL(k_pca_cov, dim3(blk), dim3(256), 0, s, sorted, n_sel, keep, acc, nb);
   hipLaunchKernelGGL(k_pca_extent, dim3(blk), dim3(256), 0, s, sorted, n_sel, keep, acc, ext, ticket, nb, st, use_plane ? 1 : 0, n,
                      poses, valid, st_copy, done, poses_dev);
 }
 
 size_t pca_acc_words(int nb) { return (size_t)nb * kAccStride; }
+size_t pca_ext_words(int nb) { return (size_t)nb * kExtStride; }
 
 }  // namespace gv

@@ -280,10 +280,12 @@ void launch_radius_filter(const float *x, const float *y, const float *z, uint32
                           const BBoxTest &bt, int nb, bool use_plane, float thr_f, RansacState *st, int16_t *ids,
                           uint32_t *cell_cnt, uint32_t *pre, uint32_t *blk_off, unsigned *ticket, CellNode *sorted, uint8_t *keep,
                           long long *acc, uint32_t n_buckets, float r2f, int min_pts, hipStream_t s);
-size_t pca_acc_words(int nb);
+size_t pca_acc_words(int nb);   // 64-bit words of acc
+size_t pca_ext_words(int nb);   // 32-bit words of ext
 // centroid + PCA rectangle of every bbox's kept points (bboxPoseEstimation :156-181, computePCABoundingBox :187-247)
 // from order-independent integer sums: covariance pass, extents pass, poses by the last workgroup.  acc / ext
-// (4 words per bbox) / *ticket are zero on entry and left zero.  st_copy (optional): *st is copied there (one read-back
+// (pca_acc_words / pca_ext_words) / *ticket are zero on entry and left zero.  n_sel: device address of the number of
+// selected points (blk_off[n_buckets / 4096] of the bucket scan).  st_copy (optional): *st is copied there (one read-back
 // block for poses, flags and state); poses_dev (optional, device memory): a second copy of the camera-frame poses with
 // length = -1 where valid[b] == 0
 void launch_pca_rect(const CellNode *sorted, const uint32_t *n_sel, uint32_t n, const uint8_t *keep, long long *acc, unsigned *ext,
