@@ -283,20 +283,20 @@ __global__ void __launch_bounds__(kCoThreads) k_ransac_moments(const float *__re
   __syncthreads();
   if (w < kMom) {   // level 1: one wavefront per quantity
     const double t = wave_butterfly(s_l0[lane][w]);
-    if (lane == 0) part_a[(size_t)blockIdx.x * kMom + w] = t;
+    // (agent-scope atomic store: written through to the device's coherence point, where the last workgroup's atomic
+    //  loads read it -- see the note at the ticket)
+    if (lane == 0) __hip_atomic_store(&part_a[(size_t)blockIdx.x * kMom + w], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
+  // The ticket.  What the last workgroup reads -- the partial sums -- was written by agent-scope atomic stores and is
+  // read by agent-scope atomic loads; the ticket itself only has to come after this workgroup's stores have been
+  // acknowledged (vmcnt, then the barrier).  A release FENCE instead (rounds 2-3) is a write-back of the whole L2 of the
+  // XCD by every workgroup (buffer_wbl2): 10 us of this kernel, 15 us of k_pca_extent (profiles/r04/ticket_fence_ab.txt).
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (tid == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const unsigned ticket = __hip_atomic_fetch_add(&st->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const bool last = ticket == gridDim.x - 1u;
-    if (last) {
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __hip_atomic_store(&st->ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next call
-    }
+    if (last) __hip_atomic_store(&st->ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next call
     s_last = last ? 1u : 0u;
   }
   __syncthreads();
@@ -418,9 +418,10 @@ __global__ void __launch_bounds__(kCoThreads) k_ransac_mask(const float *__restr
   __syncthreads();
   if (threadIdx.x == 0) {
     if (s_n) atomicAdd(&st->n_inliers, (unsigned long long)s_n);
-    if (st_copy) {   // the workgroup that finishes last hands the final state out (its count read past the L1)
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      const unsigned t = __hip_atomic_fetch_add(&st->ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    if (st_copy) {   // the workgroup that finishes last hands the final state out (the count is an agent-scope atomic:
+      // no fence, only this thread's atomic acknowledged before its ticket)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const unsigned t = __hip_atomic_fetch_add(&st->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (t == gridDim.x - 1u) {
         __hip_atomic_store(&st->ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         RansacState o = *st;
@@ -495,13 +496,30 @@ __device__ __forceinline__ void cell_range(float c, int own, int &lo, int &hi)
 // extractCloudPerBBox (:250-298) on the cloud with the ground removed (:306-314): per point the camera
 // transform, the ground test against the refined plane (use_plane) and the first-match bbox.  A selected point
 // is counted into its (cell, id) bucket.  Also counts the ground points (st->n_inliers) when the plane is in use.
+// Phase by phase over the thread's four points (loads, transforms + ground test + projection, bbox test, stores +
+// atomics) so that the four dependent chains overlap; the bbox test's tables (float thresholds, 16x16-pixel tile
+// masks) are staged in LDS when they fit (LDS_TAB): the test's two dependent look-ups per candidate are then LDS
+// round trips, not trips to the L2.  29 -> 17 us on the objects scene (profiles/r04/).
+#ifndef GV_CLS_ABLATE
+#define GV_CLS_ABLATE 0
+#endif
+template <bool LDS_TAB>
 __global__ void __launch_bounds__(kCoThreads) k_pose_classify(const float *__restrict__ x, const float *__restrict__ y,
                                                               const float *__restrict__ z, uint32_t n, Mat34f m, CamK cam,
                                                               BBoxTest bt, int nb, int use_plane, float thr_f,
                                                               RansacState *__restrict__ st, int16_t *__restrict__ ids,
                                                               uint32_t *__restrict__ cell_cnt, uint32_t hi_mask)
 {
+  extern __shared__ __attribute__((aligned(16))) unsigned char s_tab[];   // LDS_TAB: nb_pad float4 thresholds, then the tile masks
   __shared__ unsigned s_n;
+  const int nb_pad = (nb + 3) & ~3;
+  float4 *s_bf = reinterpret_cast<float4 *>(s_tab);
+  unsigned long long *s_tm = reinterpret_cast<unsigned long long *>(s_tab + (size_t)nb_pad * sizeof(float4));
+  if (LDS_TAB) {
+    for (int b = threadIdx.x; b < nb; b += kCoThreads) s_bf[b] = bt.bbox_f[b];
+    const int nmask = bt.tiles_x * bt.tiles_y * bt.mask_words;
+    for (int i = threadIdx.x; i < nmask; i += kCoThreads) s_tm[i] = bt.tile_mask[i];
+  }
   float4 pl = make_float4(0.f, 0.f, 0.f, 0.f);
   bool have = false;
   if (use_plane) {
@@ -510,21 +528,69 @@ __global__ void __launch_bounds__(kCoThreads) k_pose_classify(const float *__res
   }
   if (threadIdx.x == 0) s_n = 0u;
   __syncthreads();
+  // ---- loads
+  size_t idx[kCoPts];
+  bool in[kCoPts];
+  float lx[kCoPts], ly[kCoPts], lz[kCoPts];
+#pragma unroll
+  for (int j = 0; j < kCoPts; ++j) {
+    idx[j] = (size_t)blockIdx.x * kCoBlock + (size_t)j * kCoThreads + threadIdx.x;
+    in[j] = idx[j] < n;
+    const size_t i = in[j] ? idx[j] : (size_t)0;
+    lx[j] = x[i]; ly[j] = y[i]; lz[j] = z[i];
+  }
+  // ---- camera transform, ground test, projection (first_bbox's first half, gv_device.hpp)
+  float cx[kCoPts], cy[kCoPts], cz[kCoPts], u[kCoPts], v[kCoPts];
+  bool ground[kCoPts], cand[kCoPts];
   unsigned c = 0;
 #pragma unroll
   for (int j = 0; j < kCoPts; ++j) {
-    const size_t i = (size_t)blockIdx.x * kCoBlock + (size_t)j * kCoThreads + threadIdx.x;
-    bool ground = false;
-    if (i < n) {
-      float cx, cy, cz;
-      xform34(m, x[i], y[i], z[i], cx, cy, cz);
-      ground = have && plane_inlier_dev(pl, cx, cy, cz, thr_f);
-      int id = ground ? -1 : first_bbox(cam, bt, cx, cy, cz);
-      if (id >= nb) id = -1;
-      ids[i] = (int16_t)id;
-      if (id >= 0) atomicAdd(&cell_cnt[bucket_of(cell_of(cx), cell_of(cy), cell_of(cz), id, hi_mask)], 1u);
+    xform34(m, lx[j], ly[j], lz[j], cx[j], cy[j], cz[j]);
+    ground[j] = in[j] && have && plane_inlier_dev(pl, cx[j], cy[j], cz[j], thr_f);
+    c += (unsigned)__popcll(__ballot(ground[j]));
+    cand[j] = in[j] && !ground[j] && isfinite(cx[j]) && isfinite(cy[j]) && isfinite(cz[j]) && !(cz[j] <= 0.001f);   // :264
+    u[j] = v[j] = -1.0f;
+  }
+#pragma unroll
+  for (int j = 0; j < kCoPts; ++j) {
+    if (cand[j]) {
+      const double X = (double)cx[j], Y = (double)cy[j], Z = (double)cz[j];
+      const double riz = rcp_newton(Z);
+      div2_to_float(cam.k[0] * X + cam.k[2] * Z, cam.k[4] * Y + cam.k[5] * Z, Z, riz, u[j], v[j]);   // :268-273
+      cand[j] = !(u[j] < 0 || u[j] >= (float)cam.W || v[j] < 0 || v[j] >= (float)cam.H);             // :276
     }
-    c += (unsigned)__popcll(__ballot(ground));
+  }
+  // ---- first match (:280-288)
+  int id[kCoPts];
+#pragma unroll
+  for (int j = 0; j < kCoPts; ++j) {
+    id[j] = -1;
+    if (cand[j] && !(GV_CLS_ABLATE & 4)) {
+      const int tx = (int)u[j] >> 4, ty = (int)v[j] >> 4;
+      const size_t off = ((size_t)ty * bt.tiles_x + tx) * bt.mask_words;
+      for (int wd = 0; wd < bt.mask_words && id[j] < 0; ++wd) {
+        unsigned long long mk = LDS_TAB ? s_tm[off + wd] : bt.tile_mask[off + wd];
+        while (mk) {
+          const int b = wd * 64 + (__ffsll((long long)mk) - 1);
+          mk &= mk - 1;
+          const float4 f = LDS_TAB ? s_bf[b] : bt.bbox_f[b];
+          if (u[j] >= f.x && u[j] <= f.z && v[j] >= f.y && v[j] <= f.w) {
+            id[j] = b;
+            break;
+          }
+        }
+      }
+      if (id[j] >= nb) id[j] = -1;
+    }
+  }
+  // ---- stores and bucket counts
+#pragma unroll
+  for (int j = 0; j < kCoPts; ++j) {
+    if (in[j]) {
+      if (!(GV_CLS_ABLATE & 2)) ids[idx[j]] = (int16_t)id[j];
+      if (!(GV_CLS_ABLATE & 1))
+        if (id[j] >= 0) atomicAdd(&cell_cnt[bucket_of(cell_of(cx[j]), cell_of(cy[j]), cell_of(cz[j]), id[j], hi_mask)], 1u);
+    }
   }
   if (use_plane) {
     if ((threadIdx.x & 63) == 0 && c) atomicAdd(&s_n, c);
@@ -566,16 +632,12 @@ __global__ void __launch_bounds__(1024) k_cell_scan(const uint32_t *__restrict__
   const unsigned e = wbase + inc - t4;
   *reinterpret_cast<uint4 *>(pre + b0) = make_uint4(e, e + c.x, e + c.x + c.y, e + c.x + c.y + c.z);
   if (tid == 0) {
+    // (the last workgroup reads only these totals, by agent-scope atomic loads: no fence -- see k_ransac_moments)
     __hip_atomic_store(&blk_off[blockIdx.x], total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const unsigned tk = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const bool last = tk == gridDim.x - 1u;
-    if (last) {
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    if (last) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     s_last = last ? 1u : 0u;
   }
   __syncthreads();
@@ -635,20 +697,40 @@ __global__ void __launch_bounds__(kCoThreads) k_cell_scatter(const float *__rest
                                                              const uint32_t *__restrict__ pre, const uint32_t *__restrict__ blk_off,
                                                              uint32_t hi_mask, CellNode *__restrict__ sorted)
 {
+  // phase by phase over the thread's four points: ids, coordinates, then the four tickets (returning atomics) and the
+  // four bucket starts all in flight together, then the stores
+  size_t idx[kCoPts];
+  int id[kCoPts];
 #pragma unroll
   for (int j = 0; j < kCoPts; ++j) {
-    const size_t i = (size_t)blockIdx.x * kCoBlock + (size_t)j * kCoThreads + threadIdx.x;
-    if (i >= n) continue;
-    const int id = ids[i];
-    if (id < 0) continue;
-    float cx, cy, cz;
-    xform34(m, x[i], y[i], z[i], cx, cy, cz);
-    const uint32_t b = bucket_of(cell_of(cx), cell_of(cy), cell_of(cz), id, hi_mask);
-    const uint32_t k = atomicSub(&cell_cnt[b], 1u) - 1u;
-    CellNode nd;
-    nd.x = cx; nd.y = cy; nd.z = cz;
-    nd.id = id;
-    sorted[bucket_start(pre, blk_off, b) + k] = nd;
+    idx[j] = (size_t)blockIdx.x * kCoBlock + (size_t)j * kCoThreads + threadIdx.x;
+    id[j] = (idx[j] < n) ? (int)ids[idx[j]] : -1;
+  }
+  float cx[kCoPts], cy[kCoPts], cz[kCoPts];
+  uint32_t b[kCoPts];
+#pragma unroll
+  for (int j = 0; j < kCoPts; ++j) {
+    const size_t i = (id[j] >= 0) ? idx[j] : (size_t)0;
+    xform34(m, x[i], y[i], z[i], cx[j], cy[j], cz[j]);
+    b[j] = bucket_of(cell_of(cx[j]), cell_of(cy[j]), cell_of(cz[j]), id[j] >= 0 ? id[j] : 0, hi_mask);
+  }
+  uint32_t k[kCoPts], st[kCoPts];
+#pragma unroll
+  for (int j = 0; j < kCoPts; ++j) {
+    k[j] = st[j] = 0u;
+    if (id[j] >= 0) {
+      k[j] = atomicSub(&cell_cnt[b[j]], 1u) - 1u;
+      st[j] = bucket_start(pre, blk_off, b[j]);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < kCoPts; ++j) {
+    if (id[j] >= 0) {
+      CellNode nd;
+      nd.x = cx[j]; nd.y = cy[j]; nd.z = cz[j];
+      nd.id = id[j];
+      sorted[st[j] + k[j]] = nd;
+    }
   }
 }
 
@@ -791,7 +873,10 @@ __global__ void __launch_bounds__(256) k_radius_sorted(const CellNode *__restric
       cell_range(pv.y, iy, y0, y1);
       cell_range(pv.z, iz, z0, z1);
       const bool fast = x0 >= ix - 1 && x1 <= ix + 1 && y0 >= iy - 1 && y1 <= iy + 1 && z0 >= iz - 1 && z1 <= iz + 1;
-      const bool live = fast && t < n_sel;
+#ifndef GV_RAD_ABLATE
+#define GV_RAD_ABLATE 0
+#endif
+      const bool live = fast && t < n_sel && !(GV_RAD_ABLATE & 2);   // (timing experiments: 2 = no look-ups, 1 = no walk)
       // cells x0..x1 are one run, or two when they straddle a multiple of 8
       const int xs = ((x0 >> 3) != (x1 >> 3)) ? (x1 & ~7) : x1 + 1;   // first cell of the second run (none: x1 + 1)
       const bool two = xs <= x1;
@@ -852,7 +937,9 @@ __global__ void __launch_bounds__(256) k_radius_sorted(const CellNode *__restric
         d = c.z - pz; r = __fadd_rn(r, __fmul_rn(d, d));
         return (on && __float_as_int(c.w) == myid && r <= r2f) ? 1 : 0;
       };
-      if (!(idw & 0x40000000)) {
+      if (GV_RAD_ABLATE & 1) {
+        cnt = min_pts + 1;
+      } else if (!(idw & 0x40000000)) {
         // the runs as one list: lane g looks at entries g, g + kRadLanes, ...; a cursor (run, index, end of the run) that
         // hops to the next run carrying its overshoot
         const int nr = (idw >> 16) & 31;
@@ -929,6 +1016,19 @@ __global__ void __launch_bounds__(256) k_radius_sorted(const CellNode *__restric
   }
 }
 
+__device__ __forceinline__ long long wave_sum_i64(long long v)
+{
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+  return v;
+}
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v)
+{
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = max(v, (unsigned)__shfl_xor((int)v, off));
+  return v;
+}
+
 // covariance sums of the fp32-centred samples (cv::PCA: rows (z, x) minus the fp32 mean, products accumulated in
 // fp64 -- here: each product, exact in fp64, rounded once to 2^-26 m^2 and added as an integer)
 __global__ void __launch_bounds__(256) k_pca_cov(const CellNode *__restrict__ sorted, const uint32_t *__restrict__ n_sel_p,
@@ -950,25 +1050,51 @@ __global__ void __launch_bounds__(256) k_pca_cov(const CellNode *__restrict__ so
   __syncthreads();
   const uint32_t n_sel = *n_sel_p;
   const float4 *nodes = reinterpret_cast<const float4 *>(sorted);
-  for (uint32_t t = blockIdx.x * 256u + threadIdx.x; t < n_sel; t += gridDim.x * 256u) {
-    if (!keep[t]) continue;
-    const float4 p = nodes[t];
-    const int id = __float_as_int(p.w);
-    if (id >= nb) continue;
-    float m0, m1;
-    if (tab) { m0 = s_m[id][0]; m1 = s_m[id][1]; }
-    else {
-      float cy;
-      unsigned long long cnt;
-      pca_means(acc + (size_t)id * kAccStride, cy, m0, m1, cnt);
+  const int lane = threadIdx.x & 63;
+  // whole wavefronts per trip (the reductions below need them); the points of a wavefront nearly always belong to ONE box
+  // (bucket order: same cell block, same box), and 64 lanes adding to the same three LDS words are 192 serialised
+  // atomics: the wavefront adds them up first and one lane does three
+  for (uint32_t t0 = blockIdx.x * 256u + (threadIdx.x & ~63u); t0 < n_sel; t0 += gridDim.x * 256u) {
+    const uint32_t t = t0 + (uint32_t)lane;
+    int id = -1;
+    float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (t < n_sel && keep[t]) {
+      p = nodes[t];
+      id = __float_as_int(p.w);
+      if (id >= nb) id = -1;
     }
-    const float a = p.z - m0, b = p.x - m1;
-    const long long aa = fix_prod(a, a), ab = fix_prod(a, b), bb = fix_prod(b, b);
-    unsigned long long *d = tab ? reinterpret_cast<unsigned long long *>(&s_acc[id][0])
-                                : reinterpret_cast<unsigned long long *>(acc + (size_t)id * kAccStride + 4);
-    atomicAdd(d + 0, (unsigned long long)aa);
-    atomicAdd(d + 1, (unsigned long long)ab);
-    atomicAdd(d + 2, (unsigned long long)bb);
+    const unsigned long long have = __ballot(id >= 0);
+    if (!have) continue;
+    const int id0 = __builtin_amdgcn_readlane(id, __ffsll((long long)have) - 1);
+    const bool uniform = __ballot(id >= 0 && id != id0) == 0ull;
+    long long aa = 0, ab = 0, bb = 0;
+    if (id >= 0) {
+      float m0, m1;
+      if (tab) { m0 = s_m[id][0]; m1 = s_m[id][1]; }
+      else {
+        float cy;
+        unsigned long long cnt;
+        pca_means(acc + (size_t)id * kAccStride, cy, m0, m1, cnt);
+      }
+      const float a = p.z - m0, b = p.x - m1;
+      aa = fix_prod(a, a); ab = fix_prod(a, b); bb = fix_prod(b, b);
+    }
+    if (uniform) {
+      aa = wave_sum_i64(aa); ab = wave_sum_i64(ab); bb = wave_sum_i64(bb);
+      if (lane == 0) {
+        unsigned long long *d = tab ? reinterpret_cast<unsigned long long *>(&s_acc[id0][0])
+                                    : reinterpret_cast<unsigned long long *>(acc + (size_t)id0 * kAccStride + 4);
+        atomicAdd(d + 0, (unsigned long long)aa);
+        atomicAdd(d + 1, (unsigned long long)ab);
+        atomicAdd(d + 2, (unsigned long long)bb);
+      }
+    } else if (id >= 0) {
+      unsigned long long *d = tab ? reinterpret_cast<unsigned long long *>(&s_acc[id][0])
+                                  : reinterpret_cast<unsigned long long *>(acc + (size_t)id * kAccStride + 4);
+      atomicAdd(d + 0, (unsigned long long)aa);
+      atomicAdd(d + 1, (unsigned long long)ab);
+      atomicAdd(d + 2, (unsigned long long)bb);
+    }
   }
   if (!tab) return;
   __syncthreads();
@@ -1033,18 +1159,38 @@ __global__ void __launch_bounds__(256) k_pca_extent(const CellNode *__restrict__
   __syncthreads();
   const uint32_t n_sel = *n_sel_p;
   const float4 *nodes = reinterpret_cast<const float4 *>(sorted);
-  for (uint32_t t = blockIdx.x * 256u + threadIdx.x; t < n_sel; t += gridDim.x * 256u) {
-    if (!keep[t]) continue;
-    const float4 p = nodes[t];
-    const int id = __float_as_int(p.w);
-    if (id >= nb) continue;
-    const PcaAxes ax = tab ? s_ax[id] : pca_axes(acc + (size_t)id * kAccStride);
-    const float dx = p.z - ax.m0, dy = p.x - ax.m1;
-    const float pl = dx * ax.Mx + dy * ax.My, pw = dx * ax.Nx + dy * ax.Ny;
-    unsigned *e = tab ? &s_ext[id][0] : ext + (size_t)id * kExtStride;
-    const unsigned kl = fkey(pl), kw = fkey(pw);
-    atomicMax(e + 0, ~kl); atomicMax(e + 1, kl);
-    atomicMax(e + 2, ~kw); atomicMax(e + 3, kw);
+  const int lane = threadIdx.x & 63;
+  for (uint32_t t0 = blockIdx.x * 256u + (threadIdx.x & ~63u); t0 < n_sel; t0 += gridDim.x * 256u) {   // (as in k_pca_cov)
+    const uint32_t t = t0 + (uint32_t)lane;
+    int id = -1;
+    float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (t < n_sel && keep[t]) {
+      p = nodes[t];
+      id = __float_as_int(p.w);
+      if (id >= nb) id = -1;
+    }
+    const unsigned long long have = __ballot(id >= 0);
+    if (!have) continue;
+    const int id0 = __builtin_amdgcn_readlane(id, __ffsll((long long)have) - 1);
+    const bool uniform = __ballot(id >= 0 && id != id0) == 0ull;
+    unsigned k0 = 0u, k1 = 0u, k2 = 0u, k3 = 0u;   // zero = "nothing": the identity of the max below
+    if (id >= 0) {
+      const PcaAxes ax = tab ? s_ax[id] : pca_axes(acc + (size_t)id * kAccStride);
+      const float dx = p.z - ax.m0, dy = p.x - ax.m1;
+      const float pl = dx * ax.Mx + dy * ax.My, pw = dx * ax.Nx + dy * ax.Ny;
+      const unsigned kl = fkey(pl), kw = fkey(pw);
+      k0 = ~kl; k1 = kl; k2 = ~kw; k3 = kw;
+    }
+    if (uniform) {
+      k0 = wave_max_u32(k0); k1 = wave_max_u32(k1); k2 = wave_max_u32(k2); k3 = wave_max_u32(k3);
+      if (lane == 0) {
+        unsigned *e = tab ? &s_ext[id0][0] : ext + (size_t)id0 * kExtStride;
+        atomicMax(e + 0, k0); atomicMax(e + 1, k1); atomicMax(e + 2, k2); atomicMax(e + 3, k3);
+      }
+    } else if (id >= 0) {
+      unsigned *e = tab ? &s_ext[id][0] : ext + (size_t)id * kExtStride;
+      atomicMax(e + 0, k0); atomicMax(e + 1, k1); atomicMax(e + 2, k2); atomicMax(e + 3, k3);
+    }
   }
   __syncthreads();
   if (tab)
@@ -1052,63 +1198,92 @@ __global__ void __launch_bounds__(256) k_pca_extent(const CellNode *__restrict__
       const unsigned v = (&s_ext[0][0])[i];
       if (v != 0u) atomicMax(ext + (size_t)(i >> 2) * kExtStride + (i & 3), v);
     }
-  // ---- the last workgroup to arrive writes the poses
-  __threadfence();
+  // ---- the last workgroup to arrive writes the poses.  Everything it reads was written by agent-scope ATOMICS (the
+  // flushes above) and is read by agent-scope atomic loads: those meet at the device's coherence point whatever L2 the
+  // workgroups sit behind, so all the ticket needs is that this workgroup's atomics have been acknowledged (vmcnt) --
+  // a release FENCE here makes every workgroup write its L2 back first: 20 us of this kernel with 256 workgroups
+  // (profiles/r04/ticket_fence_ab.txt).
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x == 0) {
-    const unsigned tk = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned tk = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const bool last = tk == gridDim.x - 1u;
     if (last) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     s_last = last ? 1u : 0u;
   }
   __syncthreads();
   if (!s_last) return;
-  __threadfence();
-  if (threadIdx.x == 0 && st_copy) *st_copy = *st;   // the state rides home in the same block as the poses
   // computeBBoxPose :307-309: an empty segmented cloud (no plane found, or everything is ground) -> no poses
   const bool none = use_plane && (st->best_count == 0 || st->n_inliers == 0ull || st->n_inliers == (unsigned long long)n_cloud);
-  for (int b = threadIdx.x; b < nb; b += 256) {
-    long long a[7];
+  // The poses are staged in LDS and leave as consecutive 16-byte stores of consecutive lanes: `poses` is usually the
+  // host's pinned result block, and forty lanes storing ten doubles each at a stride of 80 bytes are four hundred
+  // partial writes over PCIe (23 us of this kernel, measured with nothing selected at all).
+  __shared__ __attribute__((aligned(16))) double s_out[kPcaTab][10];
+  __shared__ uint8_t s_ok[kPcaTab];
+  static_assert(sizeof(gv_lshape_pose) == 80, "ten doubles");
+  for (int b0 = 0; b0 < nb; b0 += kPcaTab) {
+    const int nbc = min(kPcaTab, nb - b0);
+    for (int bl = threadIdx.x; bl < nbc; bl += 256) {
+      const int b = b0 + bl;
+      long long a[7];
 #pragma unroll
-    for (int k = 0; k < 7; ++k) {
-      a[k] = __hip_atomic_load(acc + (size_t)b * kAccStride + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      acc[(size_t)b * kAccStride + k] = 0;
-    }
-    unsigned e[4];
+      for (int k = 0; k < 7; ++k) {
+        a[k] = __hip_atomic_load(acc + (size_t)b * kAccStride + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        acc[(size_t)b * kAccStride + k] = 0;
+      }
+      unsigned e[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      e[k] = __hip_atomic_load(ext + (size_t)b * kExtStride + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      ext[(size_t)b * kExtStride + k] = 0u;
+      for (int k = 0; k < 4; ++k) {
+        e[k] = __hip_atomic_load(ext + (size_t)b * kExtStride + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ext[(size_t)b * kExtStride + k] = 0u;
+      }
+      double o[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+      bool ok = false;
+      if (!none && a[3] != 0) {   // :174-175 an empty cloud has no pose
+        const PcaAxes ax = pca_axes(a);
+        const float minL = fkey_inv(~e[0]), maxL = fkey_inv(e[1]), minW = fkey_inv(~e[2]), maxW = fkey_inv(e[3]);
+        // :227 degrees, :236 passed to setRPY as if radians (as the reference does); atan2f evaluated in fp64, rounded once.
+        // `std::atan2(float, float) * 180.0f / CV_PI`: float product, widened for the division by the DOUBLE CV_PI,
+        // narrowed once on the assignment to `float angle`.
+        const float a32 = (float)atan2((double)ax.My, (double)ax.Mx);
+        const float angle = (float)((double)(a32 * 180.0f) / 3.1415926535897932384626433832795);
+        const double hp = (double)(-angle) * 0.5;   // tf2 setRPY(0, pitch, 0): (0, sin(p/2), 0, cos(p/2))
+        o[0] = ax.m1;    // position.x  :230 center.y
+        o[1] = ax.cy;    // position.y  :231 then :181
+        o[2] = ax.m0;    // position.z  :232 center.x
+        o[3] = 0.0; o[4] = sin(hp); o[5] = 0.0; o[6] = cos(hp);
+        o[7] = maxL - minL;   // length :218,:243
+        o[8] = maxW - minW;   // width  :219,:244
+        o[9] = 0.0;           // height: never set on this path in the reference
+        ok = true;
+      }
+#pragma unroll
+      for (int k = 0; k < 10; ++k) s_out[bl][k] = o[k];
+      s_ok[bl] = ok ? 1 : 0;
     }
-    gv_lshape_pose p{};
-    bool ok = false;
-    if (!none && a[3] != 0) {   // :174-175 an empty cloud has no pose
-      const PcaAxes ax = pca_axes(a);
-      const float minL = fkey_inv(~e[0]), maxL = fkey_inv(e[1]), minW = fkey_inv(~e[2]), maxW = fkey_inv(e[3]);
-      // :227 degrees, :236 passed to setRPY as if radians (as the reference does); atan2f evaluated in fp64, rounded once.
-      // `std::atan2(float, float) * 180.0f / CV_PI`: float product, widened for the division by the DOUBLE CV_PI,
-      // narrowed once on the assignment to `float angle`.
-      const float a32 = (float)atan2((double)ax.My, (double)ax.Mx);
-      const float angle = (float)((double)(a32 * 180.0f) / 3.1415926535897932384626433832795);
-      const double hp = (double)(-angle) * 0.5;   // tf2 setRPY(0, pitch, 0): (0, sin(p/2), 0, cos(p/2))
-      p.px = ax.m1;    // :230 center.y
-      p.py = ax.cy;    // :231 then :181
-      p.pz = ax.m0;    // :232 center.x
-      p.qx = 0.0; p.qy = sin(hp); p.qz = 0.0; p.qw = cos(hp);
-      p.length = maxL - minL;   // :218,:243
-      p.width = maxW - minW;    // :219,:244
-      p.height = 0.0;           // never set on this path in the reference
-      ok = true;
-    }
-    poses[b] = p;
-    valid[b] = ok ? 1 : 0;
+    __syncthreads();
+    const double2 *src = reinterpret_cast<const double2 *>(&s_out[0][0]);
+    double2 *dst = reinterpret_cast<double2 *>(poses + b0);
+    for (int i = threadIdx.x; i < nbc * 5; i += 256) dst[i] = src[i];
+    for (int i = threadIdx.x; i < nbc; i += 256) valid[b0 + i] = s_ok[i];
     if (poses_dev) {
-      if (!ok) p.length = -1.0;   // k_rects_from_poses skips it
-      poses_dev[b] = p;
+      double2 *dd = reinterpret_cast<double2 *>(poses_dev + b0);
+      for (int i = threadIdx.x; i < nbc * 5; i += 256) {
+        double2 v = src[i];
+        if (i % 5 == 3 && !s_ok[i / 5]) v.y = -1.0;   // length (double 7 of 10) = -1: k_rects_from_poses skips the box
+        dd[i] = v;
+      }
     }
+    __syncthreads();
+  }
+  if (st_copy) {   // the state rides home in the same block as the poses
+    static_assert(sizeof(RansacState) % 8 == 0, "copied as 64-bit words");
+    const unsigned long long *ss = reinterpret_cast<const unsigned long long *>(st);
+    unsigned long long *sd = reinterpret_cast<unsigned long long *>(st_copy);
+    for (int i = threadIdx.x; i < (int)(sizeof(RansacState) / 8); i += 256) sd[i] = ss[i];
   }
   if (done.flag) {
-    __threadfence_system();
+    __threadfence_system();   // every thread's result stores (they go to the host: call_done)
     __syncthreads();
     if (threadIdx.x == 0) call_done(done, 1u);
   }
@@ -1122,8 +1297,14 @@ void launch_radius_filter(const float *x, const float *y, const float *z, uint32
   if (!n) return;
   const uint32_t nblk = (uint32_t)(((size_t)n + kCoBlock - 1) / kCoBlock);
   const uint32_t hi_mask = n_buckets / 512u - 1u;
-  hipLaunchKernelGGL(k_pose_classify, dim3(nblk), dim3(kCoThreads), 0, s, x, y, z, n, m_cam, cam, bt, nb, use_plane ? 1 : 0, thr_f, st,
-                     ids, cell_cnt, hi_mask);
+  // the bbox test's tables in LDS when they fit (40 boxes, 640 x 480: 10 KB)
+  const size_t tab_bytes = (size_t)((nb + 3) & ~3) * sizeof(float4) + (size_t)bt.tiles_x * bt.tiles_y * bt.mask_words * sizeof(unsigned long long);
+  if (tab_bytes <= 48 * 1024)
+    hipLaunchKernelGGL(k_pose_classify<true>, dim3(nblk), dim3(kCoThreads), tab_bytes, s, x, y, z, n, m_cam, cam, bt, nb, use_plane ? 1 : 0,
+                       thr_f, st, ids, cell_cnt, hi_mask);
+  else
+    hipLaunchKernelGGL(k_pose_classify<false>, dim3(nblk), dim3(kCoThreads), 0, s, x, y, z, n, m_cam, cam, bt, nb, use_plane ? 1 : 0,
+                       thr_f, st, ids, cell_cnt, hi_mask);
   hipLaunchKernelGGL(k_cell_scan, dim3(n_buckets / kScanBlock), dim3(1024), 0, s, cell_cnt, n_buckets, pre, blk_off, ticket);
   hipLaunchKernelGGL(k_cell_scatter, dim3(nblk), dim3(kCoThreads), 0, s, x, y, z, n, m_cam, ids, cell_cnt, pre, blk_off, hi_mask, sorted);
   // 32 selected points per wavefront and pass; their number is only known on the device: a fixed grid strides over them

@@ -224,7 +224,12 @@ struct CallDone {
   unsigned seq = 0;
 };
 #if defined(__HIPCC__)
-// by ONE lane of every workgroup of the grid, after that lane's result stores
+// by ONE lane of every workgroup of the grid, after that lane's result stores (other lanes that stored: a system-scope
+// fence of their own, then a barrier, first).  The system-scope fences stay: the results go to the HOST, and stores
+// from different CUs reach it on different paths -- with only "my stores are acknowledged" (s_waitcnt vmcnt(0)) before
+// the ticket the host saw the flag ahead of another workgroup's payload in 4 calls of 10 (tools/result_block_soak.py,
+// profiles/r04/ticket_fence_ab.txt).  Tickets BETWEEN WORKGROUPS OF ONE KERNEL over device memory need no fence when
+// the data goes through agent-scope atomics (k_ransac_moments, k_pca_extent, k_cell_scan).
 __device__ __forceinline__ void call_done(const CallDone &d, unsigned n_wg)
 {
   if (!d.flag) return;
