@@ -820,7 +820,7 @@ __device__ __forceinline__ int group_sum(int v)
 }
 
 #ifndef GV_RAD_LANES
-#define GV_RAD_LANES 8
+#define GV_RAD_LANES 16
 #endif
 #ifndef GV_RAD_CAND
 #define GV_RAD_CAND 4
@@ -828,14 +828,20 @@ __device__ __forceinline__ int group_sum(int v)
 #ifndef GV_RAD_GRID
 #define GV_RAD_GRID 2048
 #endif
-constexpr int kRadPts = 32;                 // points per wavefront and pass
+#ifndef GV_RAD_PTS
+#define GV_RAD_PTS 32
+#endif
+#ifndef GV_RAD_OCC
+#define GV_RAD_OCC 1
+#endif
+constexpr int kRadPts = GV_RAD_PTS;         // points per wavefront and pass
 constexpr int kRadLanes = GV_RAD_LANES;     // lanes per point in phase B
 constexpr int kRadCand = GV_RAD_CAND;       // candidates per lane and step
 constexpr int kRadRuns = 20;                // own cell + 2 beside it + 8 rows x 2 runs, the empty ones dropped
 constexpr int kBoffLds = 256;               // block offsets of the bucket scan kept in LDS (n_buckets < 1 M: clouds up to
                                             // 2 M points; beyond that they are read from global memory)
 
-__global__ void __launch_bounds__(256) k_radius_sorted(const CellNode *__restrict__ sorted, const uint32_t *__restrict__ pre,
+__global__ void __launch_bounds__(256, GV_RAD_OCC) k_radius_sorted(const CellNode *__restrict__ sorted, const uint32_t *__restrict__ pre,
                                                        const uint32_t *__restrict__ blk_off, uint32_t n_buckets, uint32_t hi_mask,
                                                        float r2f, int min_pts, uint8_t *__restrict__ keep,
                                                        long long *__restrict__ acc, int nb)
@@ -940,39 +946,39 @@ __global__ void __launch_bounds__(256) k_radius_sorted(const CellNode *__restric
       if (GV_RAD_ABLATE & 1) {
         cnt = min_pts + 1;
       } else if (!(idw & 0x40000000)) {
-        // the runs as one list: lane g looks at entries g, g + kRadLanes, ...; a cursor (run, index, end of the run) that
-        // hops to the next run carrying its overshoot
+        // A step has kRadCand SLOTS of kRadLanes consecutive candidates each; a slot takes the next kRadLanes entries of the
+        // current run and hands over to the next run when that one is exhausted (a short run leaves lanes of its slot
+        // idle).  Which run and where in it is the same for all lanes of the point, so the bookkeeping is a handful of
+        // selects -- the per-lane cursor over one virtual list of this kernel's first form cost 65 instructions per
+        // candidate, six times the distance test.
         const int nr = (idw >> 16) & 31;
         int r = 0;
-        uint2 ae = nr ? s_run[w][0][pi] : make_uint2(0u, 0u);
-        uint32_t j = ae.x + g, e = ae.y;
+        uint32_t a = 0u, e = 0u, off = 0u;
+        if (nr) { const uint2 ae = s_run[w][0][pi]; a = ae.x; e = ae.y; }
         for (;;) {
           uint32_t jj[kRadCand];
           bool on[kRadCand];
-          bool any = false;
 #pragma unroll
           for (int u = 0; u < kRadCand; ++u) {
-            while (j >= e && r + 1 < nr) {
-              const uint32_t over = j - e;
-              ++r;
-              ae = s_run[w][r][pi];
-              j = ae.x + over;
-              e = ae.y;
-            }
-            jj[u] = j;
-            on[u] = j < e;
-            any = any || on[u];
-            j += (uint32_t)kRadLanes;
+            const uint32_t c = a + off + g;
+            on[u] = r < nr && c < e;
+            jj[u] = c;
+            off += (uint32_t)kRadLanes;
+            const bool adv = r < nr && a + off >= e;
+            const uint2 nx = s_run[w][min(r + 1, kRadRuns - 1)][pi];
+            r += adv ? 1 : 0;
+            a = adv ? nx.x : a;
+            e = adv ? nx.y : e;
+            off = adv ? 0u : off;
           }
-          float4 c[kRadCand];
+          float4 c4[kRadCand];
 #pragma unroll
-          for (int u = 0; u < kRadCand; ++u) c[u] = nodes[on[u] ? jj[u] : t];
+          for (int u = 0; u < kRadCand; ++u) c4[u] = nodes[on[u] ? jj[u] : t];
           int hs = 0;
 #pragma unroll
-          for (int u = 0; u < kRadCand; ++u) hs += hit(c[u], on[u]);
-          const int v = group_sum<kRadLanes>(hs | (any ? 0x10000 : 0));
-          cnt += v & 0xffff;
-          if (cnt > min_pts || (v >> 16) == 0) break;
+          for (int u = 0; u < kRadCand; ++u) hs += hit(c4[u], on[u]);
+          cnt += group_sum<kRadLanes>(hs);
+          if (cnt > min_pts || r >= nr) break;
         }
       } else {   // coordinates so large that fp32 spacing widens the range (capped at +-3 cells): cell by cell
         const int ix = cell_of(px), iy = cell_of(py), iz = cell_of(pz);
