@@ -202,6 +202,7 @@ struct gv_context {
   // kNN depth / PCA pose scratch
   Cand2 *knn_partial = nullptr; size_t knn_partial_cap = 0;
   CellNode *d_nodes = nullptr; uint8_t *d_keep = nullptr; size_t pc_cap = 0;   // selected points in bucket order; 1 = survives the radius filter
+  uint32_t *d_ticket_of = nullptr;   // per cloud point: its slot inside its bucket (selected points only)
   long long *d_pca_acc = nullptr; unsigned *d_pca_ext = nullptr; size_t pca_cap = 0;   // per bbox: integer sums / extent keys of the PCA rectangle (zero between calls)
   unsigned *d_pca_ticket = nullptr;
   uint32_t *d_cellcnt = nullptr, *d_cellpre = nullptr, *d_celloff = nullptr; size_t head_cap = 0;   // cell buckets: counts, prefix, block offsets (+ ticket)
@@ -524,7 +525,7 @@ BBoxTest bbox_test_of(const gv_context *h, const DetSet &d)
 // tick keeps [all | static | dynamic] boxes in one block: one copy).
 int upload_det(gv_context *h, DetSet &d, const gv_bbox *bboxes, int32_t nb, const gv_lshape_pose *poses,
                int32_t n_poses, const float *orient, const float *conf, const float *dims, hipStream_t s, bool masks = true,
-               int32_t n_net = -1, int32_t nb_test = -1)
+               int32_t n_net = -1, int32_t nb_test = -1, bool fused = false)
 {
   if (n_net < 0) n_net = nb;
   if (nb_test < 0) nb_test = nb;
@@ -544,9 +545,16 @@ int upload_det(gv_context *h, DetSet &d, const gv_bbox *bboxes, int32_t nb, cons
   if (orient) put(L.orient, orient, (size_t)n_net * 4 * sizeof(float));
   if (conf) put(L.conf, conf, (size_t)n_net * 2 * sizeof(float));
   if (dims) put(L.dims, dims, (size_t)n_net * 3 * sizeof(float));
-  if (used) GV_HIP(hipMemcpyAsync(d.block, d.stage, used, hipMemcpyHostToDevice, s));
   d.mask_words = std::max(1, (nb_test + 63) / 64);
-  if (masks) launch_bbox_prepare(d.bboxes, nb_test, h->bt_tiles_x, h->bt_tiles_y, d.mask_words, d.bbox_f, d.tile_mask, s);
+  if (fused && used) {
+    // fused: ONE kernel reads the pinned staging (device visible) -- copies the block and builds the tables from the
+    // staged boxes -- instead of a copy command (7 us as a blit kernel) + the table kernel behind it
+    launch_bbox_prepare(reinterpret_cast<const gv_bbox *>(d.stage + L.bboxes), masks ? nb_test : 0, h->bt_tiles_x, h->bt_tiles_y,
+                        d.mask_words, d.bbox_f, d.tile_mask, s, d.stage, d.block, used);
+  } else {
+    if (used) GV_HIP(hipMemcpyAsync(d.block, d.stage, used, hipMemcpyHostToDevice, s));
+    if (masks) launch_bbox_prepare(d.bboxes, nb_test, h->bt_tiles_x, h->bt_tiles_y, d.mask_words, d.bbox_f, d.tile_mask, s);
+  }
   GV_HIP(hipGetLastError());
   d.nb = nb_test;
   d.n_poses = n_poses;
@@ -1569,7 +1577,7 @@ int gv_destroy(gv_handle h)
   if (h->stream_x) (void)hipStreamDestroy(h->stream_x);
   void *bufs[] = {h->log_odds, h->occupancy, h->occ_i8, h->clip_end, h->miss8, h->sh_xchg, h->ray_list, h->ray_count, h->scratch_i32,
                   h->tx, h->ty, h->tz, h->d_pts, h->knn_partial,
-                  h->d_nodes, h->d_keep, h->d_pca_acc, h->d_pca_ext, h->d_pca_ticket, h->d_cellcnt, h->d_cellpre, h->d_celloff, h->d_planes,
+                  h->d_nodes, h->d_keep, h->d_ticket_of, h->d_pca_acc, h->d_pca_ext, h->d_pca_ticket, h->d_cellcnt, h->d_cellpre, h->d_celloff, h->d_planes,
                   h->d_plane_counts, h->d_ground, h->d_rscratch, h->d_rstate, h->d_res_ticket};
   for (void *p : bufs)
     if (p) (void)hipFree(p);
@@ -2550,10 +2558,12 @@ static int enqueue_bbox_pose(gv_context *h, int32_t nb, bool with_ground, float 
   if (n > h->pc_cap) {
     if (h->d_nodes) { GV_HIP(hipFree(h->d_nodes)); h->d_nodes = nullptr; }
     if (h->d_keep) { GV_HIP(hipFree(h->d_keep)); h->d_keep = nullptr; }
+    if (h->d_ticket_of) { GV_HIP(hipFree(h->d_ticket_of)); h->d_ticket_of = nullptr; }
     h->pc_cap = 0;
     const size_t want = n + n / 8 + 1024;
     GV_HIP(hipMalloc(reinterpret_cast<void **>(&h->d_nodes), want * sizeof(CellNode)));
     GV_HIP(hipMalloc(reinterpret_cast<void **>(&h->d_keep), want));
+    GV_HIP(hipMalloc(reinterpret_cast<void **>(&h->d_ticket_of), want * sizeof(uint32_t)));
     h->pc_cap = want;
   }
   if ((size_t)nb > h->pca_cap) {
@@ -2596,7 +2606,7 @@ static int enqueue_bbox_pose(gv_context *h, int32_t nb, bool with_ground, float 
   const double radius = 0.4;
   launch_radius_filter(h->cx, h->cy, h->cz, (uint32_t)n, h->m_cam, h->camk, bbox_test_of(h, h->det[2]), nb, with_ground, thr_f,
                        h->d_rstate, h->bbox_id, h->d_cellcnt, h->d_cellpre, h->d_celloff,
-                       h->d_celloff + n_buckets / 4096 + 2, h->d_nodes, h->d_keep, h->d_pca_acc, (uint32_t)n_buckets,
+                       h->d_celloff + n_buckets / 4096 + 2, h->d_nodes, h->d_keep, h->d_ticket_of, h->d_pca_acc, (uint32_t)n_buckets,
                        host::floor_to_float(radius * radius), 10, s);
   h->have_bbox_id = true;
   // centroid + PCA rectangle per bbox from order-independent integer sums over the kept points (:156-247)
@@ -2963,7 +2973,7 @@ int gv_tick_enqueue(gv_handle h, const gv_tick_desc *d)
   DetSet &D = h->det[2];
   if (n_all) {
     if ((rc = upload_det(h, D, cat.data(), 2 * n_all, nullptr, 0, net ? d->orient : nullptr, net ? d->conf : nullptr,
-                         net ? d->dims : nullptr, s, pca, net ? nd : 0, n_all)))
+                         net ? d->dims : nullptr, s, pca, net ? nd : 0, n_all, true)))
       return rc;
     GV_HIP(hipEventRecord(D.ready, s));
   }

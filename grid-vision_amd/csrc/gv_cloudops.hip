@@ -500,15 +500,13 @@ __device__ __forceinline__ void cell_range(float c, int own, int &lo, int &hi)
 // atomics) so that the four dependent chains overlap; the bbox test's tables (float thresholds, 16x16-pixel tile
 // masks) are staged in LDS when they fit (LDS_TAB): the test's two dependent look-ups per candidate are then LDS
 // round trips, not trips to the L2.  29 -> 17 us on the objects scene (profiles/r04/).
-#ifndef GV_CLS_ABLATE
-#define GV_CLS_ABLATE 0
-#endif
 template <bool LDS_TAB>
 __global__ void __launch_bounds__(kCoThreads) k_pose_classify(const float *__restrict__ x, const float *__restrict__ y,
                                                               const float *__restrict__ z, uint32_t n, Mat34f m, CamK cam,
                                                               BBoxTest bt, int nb, int use_plane, float thr_f,
                                                               RansacState *__restrict__ st, int16_t *__restrict__ ids,
-                                                              uint32_t *__restrict__ cell_cnt, uint32_t hi_mask)
+                                                              uint32_t *__restrict__ cell_cnt, uint32_t *__restrict__ ticket_of,
+                                                              uint32_t hi_mask)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char s_tab[];   // LDS_TAB: nb_pad float4 thresholds, then the tile masks
   __shared__ unsigned s_n;
@@ -565,7 +563,7 @@ __global__ void __launch_bounds__(kCoThreads) k_pose_classify(const float *__res
 #pragma unroll
   for (int j = 0; j < kCoPts; ++j) {
     id[j] = -1;
-    if (cand[j] && !(GV_CLS_ABLATE & 4)) {
+    if (cand[j]) {
       const int tx = (int)u[j] >> 4, ty = (int)v[j] >> 4;
       const size_t off = ((size_t)ty * bt.tiles_x + tx) * bt.mask_words;
       for (int wd = 0; wd < bt.mask_words && id[j] < 0; ++wd) {
@@ -583,13 +581,20 @@ __global__ void __launch_bounds__(kCoThreads) k_pose_classify(const float *__res
       if (id[j] >= nb) id[j] = -1;
     }
   }
-  // ---- stores and bucket counts
+  // ---- bucket counts: the value the atomic returns is the point's slot inside its bucket -- kept, so that the
+  // scatter pass needs no atomic of its own (one global atomic per selected point instead of two: they bound both
+  // passes, ~10 G/s on random addresses) -- then the stores
+  uint32_t tk[kCoPts];
+#pragma unroll
+  for (int j = 0; j < kCoPts; ++j) {
+    tk[j] = 0u;
+    if (id[j] >= 0) tk[j] = atomicAdd(&cell_cnt[bucket_of(cell_of(cx[j]), cell_of(cy[j]), cell_of(cz[j]), id[j], hi_mask)], 1u);
+  }
 #pragma unroll
   for (int j = 0; j < kCoPts; ++j) {
     if (in[j]) {
-      if (!(GV_CLS_ABLATE & 2)) ids[idx[j]] = (int16_t)id[j];
-      if (!(GV_CLS_ABLATE & 1))
-        if (id[j] >= 0) atomicAdd(&cell_cnt[bucket_of(cell_of(cx[j]), cell_of(cy[j]), cell_of(cz[j]), id[j], hi_mask)], 1u);
+      ids[idx[j]] = (int16_t)id[j];
+      if (id[j] >= 0) ticket_of[idx[j]] = tk[j];
     }
   }
   if (use_plane) {
@@ -604,7 +609,7 @@ __global__ void __launch_bounds__(kCoThreads) k_pose_classify(const float *__res
 // block offsets: first slot of bucket b = pre[b] + blk_off[b >> 12] (bucket_start below), blk_off[n_buckets >> 12] =
 // the number of selected points, pre[n_buckets] = 0 so that the formula also gives the end of the last bucket.
 constexpr int kScanBlock = 4096;
-__global__ void __launch_bounds__(1024) k_cell_scan(const uint32_t *__restrict__ cell_cnt, uint32_t n_buckets,
+__global__ void __launch_bounds__(1024) k_cell_scan(uint32_t *__restrict__ cell_cnt, uint32_t n_buckets,
                                                     uint32_t *__restrict__ pre, uint32_t *__restrict__ blk_off,
                                                     unsigned *__restrict__ ticket)
 {
@@ -613,6 +618,7 @@ __global__ void __launch_bounds__(1024) k_cell_scan(const uint32_t *__restrict__
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const size_t b0 = (size_t)blockIdx.x * kScanBlock + (size_t)tid * 4;
   const uint4 c = *reinterpret_cast<const uint4 *>(cell_cnt + b0);   // n_buckets is a multiple of 4096
+  *reinterpret_cast<uint4 *>(cell_cnt + b0) = make_uint4(0u, 0u, 0u, 0u);   // ready for the next call (nobody else reads them)
   const unsigned t4 = c.x + c.y + c.z + c.w;
   unsigned inc = t4;
 #pragma unroll
@@ -688,17 +694,16 @@ __device__ __forceinline__ uint32_t bucket_start(const uint32_t *__restrict__ pr
   return pre[b] + blk_off[b >> 12];
 }
 
-// selected points -> bucket order: slot = first slot of the bucket + a ticket out of the bucket's count, which
-// is counted back down to zero (ready for the next call).  The order inside a bucket is arbitrary: nothing
-// downstream depends on it (neighbour counts, integer sums, min / max).
+// selected points -> bucket order: slot = first slot of the bucket + the ticket the classify pass drew from the bucket's
+// count.  The order inside a bucket is arbitrary: nothing downstream depends on it (neighbour counts, integer sums,
+// min / max).
 __global__ void __launch_bounds__(kCoThreads) k_cell_scatter(const float *__restrict__ x, const float *__restrict__ y,
                                                              const float *__restrict__ z, uint32_t n, Mat34f m,
-                                                             const int16_t *__restrict__ ids, uint32_t *__restrict__ cell_cnt,
+                                                             const int16_t *__restrict__ ids, const uint32_t *__restrict__ ticket_of,
                                                              const uint32_t *__restrict__ pre, const uint32_t *__restrict__ blk_off,
                                                              uint32_t hi_mask, CellNode *__restrict__ sorted)
 {
-  // phase by phase over the thread's four points: ids, coordinates, then the four tickets (returning atomics) and the
-  // four bucket starts all in flight together, then the stores
+  // phase by phase over the thread's four points: ids, coordinates + tickets, bucket starts, stores
   size_t idx[kCoPts];
   int id[kCoPts];
 #pragma unroll
@@ -707,22 +712,17 @@ __global__ void __launch_bounds__(kCoThreads) k_cell_scatter(const float *__rest
     id[j] = (idx[j] < n) ? (int)ids[idx[j]] : -1;
   }
   float cx[kCoPts], cy[kCoPts], cz[kCoPts];
-  uint32_t b[kCoPts];
+  uint32_t b[kCoPts], k[kCoPts];
 #pragma unroll
   for (int j = 0; j < kCoPts; ++j) {
     const size_t i = (id[j] >= 0) ? idx[j] : (size_t)0;
+    k[j] = ticket_of[i];
     xform34(m, x[i], y[i], z[i], cx[j], cy[j], cz[j]);
     b[j] = bucket_of(cell_of(cx[j]), cell_of(cy[j]), cell_of(cz[j]), id[j] >= 0 ? id[j] : 0, hi_mask);
   }
-  uint32_t k[kCoPts], st[kCoPts];
+  uint32_t st[kCoPts];
 #pragma unroll
-  for (int j = 0; j < kCoPts; ++j) {
-    k[j] = st[j] = 0u;
-    if (id[j] >= 0) {
-      k[j] = atomicSub(&cell_cnt[b[j]], 1u) - 1u;
-      st[j] = bucket_start(pre, blk_off, b[j]);
-    }
-  }
+  for (int j = 0; j < kCoPts; ++j) st[j] = (id[j] >= 0) ? bucket_start(pre, blk_off, b[j]) : 0u;
 #pragma unroll
   for (int j = 0; j < kCoPts; ++j) {
     if (id[j] >= 0) {
@@ -1298,7 +1298,7 @@ __global__ void __launch_bounds__(256) k_pca_extent(const CellNode *__restrict__
 void launch_radius_filter(const float *x, const float *y, const float *z, uint32_t n, const Mat34f &m_cam, const CamK &cam,
                           const BBoxTest &bt, int nb, bool use_plane, float thr_f, RansacState *st, int16_t *ids,
                           uint32_t *cell_cnt, uint32_t *pre, uint32_t *blk_off, unsigned *ticket, CellNode *sorted, uint8_t *keep,
-                          long long *acc, uint32_t n_buckets, float r2f, int min_pts, hipStream_t s)
+                          uint32_t *ticket_of, long long *acc, uint32_t n_buckets, float r2f, int min_pts, hipStream_t s)
 {
   if (!n) return;
   const uint32_t nblk = (uint32_t)(((size_t)n + kCoBlock - 1) / kCoBlock);
@@ -1307,12 +1307,12 @@ void launch_radius_filter(const float *x, const float *y, const float *z, uint32
   const size_t tab_bytes = (size_t)((nb + 3) & ~3) * sizeof(float4) + (size_t)bt.tiles_x * bt.tiles_y * bt.mask_words * sizeof(unsigned long long);
   if (tab_bytes <= 48 * 1024)
     hipLaunchKernelGGL(k_pose_classify<true>, dim3(nblk), dim3(kCoThreads), tab_bytes, s, x, y, z, n, m_cam, cam, bt, nb, use_plane ? 1 : 0,
-                       thr_f, st, ids, cell_cnt, hi_mask);
+                       thr_f, st, ids, cell_cnt, ticket_of, hi_mask);
   else
     hipLaunchKernelGGL(k_pose_classify<false>, dim3(nblk), dim3(kCoThreads), 0, s, x, y, z, n, m_cam, cam, bt, nb, use_plane ? 1 : 0,
-                       thr_f, st, ids, cell_cnt, hi_mask);
+                       thr_f, st, ids, cell_cnt, ticket_of, hi_mask);
   hipLaunchKernelGGL(k_cell_scan, dim3(n_buckets / kScanBlock), dim3(1024), 0, s, cell_cnt, n_buckets, pre, blk_off, ticket);
-  hipLaunchKernelGGL(k_cell_scatter, dim3(nblk), dim3(kCoThreads), 0, s, x, y, z, n, m_cam, ids, cell_cnt, pre, blk_off, hi_mask, sorted);
+  hipLaunchKernelGGL(k_cell_scatter, dim3(nblk), dim3(kCoThreads), 0, s, x, y, z, n, m_cam, ids, ticket_of, pre, blk_off, hi_mask, sorted);
   // 32 selected points per wavefront and pass; their number is only known on the device: a fixed grid strides over them
   const uint32_t rblk = (uint32_t)std::max<size_t>(1, std::min<size_t>(((size_t)n + 4 * kRadPts - 1) / (4 * kRadPts), GV_RAD_GRID));
   hipLaunchKernelGGL(k_radius_sorted, dim3(rblk), dim3(256), 0, s, sorted, pre, blk_off, n_buckets, hi_mask, r2f, min_pts, keep, acc, nb);

@@ -143,10 +143,15 @@ void launch_points(const PointsArgs &a, hipStream_t s)
 constexpr int kPrepBoxes = 256;   // boxes staged per round
 __global__ void __launch_bounds__(256) k_bbox_prepare(const gv_bbox *__restrict__ bb, int32_t nb, int32_t tiles_x,
                                                       int32_t tiles_y, int32_t mask_words, float4 *__restrict__ bbox_f,
-                                                      unsigned long long *__restrict__ tile_mask)
+                                                      unsigned long long *__restrict__ tile_mask,
+                                                      const uint4 *__restrict__ copy_src, uint4 *__restrict__ copy_dst,
+                                                      uint32_t copy_words)
 {
   __shared__ int4 s_r[kPrepBoxes];   // tile range {tx0, ty0, tx1, ty1} of a box (empty range: tx0 > tx1)
   const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  // optional rider (gv_tick): the detection block goes from its pinned staging to the device in this kernel instead of
+  // a copy command in front of it (`bb` then points INTO the staging: the boxes are read over PCIe by every workgroup)
+  for (uint32_t i = (uint32_t)gid; i < copy_words; i += gridDim.x * blockDim.x) copy_dst[i] = copy_src[i];
   const int nwords = tiles_x * tiles_y * mask_words;
   const int wd = (gid < nwords) ? gid % mask_words : 0, tile = (gid < nwords) ? gid / mask_words : 0;
   const int tx = tile % tiles_x, ty = tile / tiles_x;
@@ -184,11 +189,13 @@ __global__ void __launch_bounds__(256) k_bbox_prepare(const gv_bbox *__restrict_
 }
 
 void launch_bbox_prepare(const gv_bbox *bboxes, int32_t nb, int32_t tiles_x, int32_t tiles_y, int32_t mask_words,
-                         float4 *bbox_f, unsigned long long *tile_mask, hipStream_t s)
+                         float4 *bbox_f, unsigned long long *tile_mask, hipStream_t s, const void *copy_src, void *copy_dst,
+                         size_t copy_bytes)
 {
   const int n = std::max(tiles_x * tiles_y * mask_words, 1);   // (>= 1 workgroup: it also stores the thresholds)
   hipLaunchKernelGGL(k_bbox_prepare, dim3((n + 255) / 256), dim3(256), 0, s, bboxes, nb, tiles_x, tiles_y, mask_words,
-                     bbox_f, tile_mask);
+                     bbox_f, tile_mask, static_cast<const uint4 *>(copy_src), static_cast<uint4 *>(copy_dst),
+                     (uint32_t)((copy_bytes + 15) / 16));
 }
 
 // A1 standalone: camera-frame copy of the cloud (transformLidarToCamera)

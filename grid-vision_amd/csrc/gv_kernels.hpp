@@ -47,8 +47,11 @@ struct PointsArgs {
 };
 void launch_points(const PointsArgs &a, hipStream_t s);
 // float thresholds + 16x16-pixel tile candidate masks of the bbox test, from the device copy of the bboxes
+// copy_src / copy_dst / copy_bytes (optional): the kernel also copies that many bytes (rounded up to 16) first -- the
+// detection block from its pinned, device-visible staging, `bboxes` then pointing into the staging
 void launch_bbox_prepare(const gv_bbox *bboxes, int32_t nb, int32_t tiles_x, int32_t tiles_y, int32_t mask_words,
-                         float4 *bbox_f, unsigned long long *tile_mask, hipStream_t s);
+                         float4 *bbox_f, unsigned long long *tile_mask, hipStream_t s, const void *copy_src = nullptr,
+                         void *copy_dst = nullptr, size_t copy_bytes = 0);
 
 void launch_transform_cloud(const float *x, const float *y, const float *z, uint32_t n, const Mat34f &m,
                             float *ox, float *oy, float *oz, hipStream_t s);
@@ -280,11 +283,12 @@ static_assert(sizeof(CellNode) == 16, "one node = one 16-byte access");
 // selected points in bucket order (sorted, their number at pre[n_buckets]), keep[t] = 1 where sorted point t survives
 // the filter, and the kept points' coordinate sums in acc (pca_acc_words(nb) 64-bit words, zero on entry).
 // cell_cnt[n_buckets] must be zero on entry (left zero), pre has n_buckets + 1 entries, blk_off n_buckets / 4096 + 1,
-// *ticket zero on entry; sorted holds n nodes, keep n bytes.  n_buckets: a power of two >= 4096
+// *ticket zero on entry; sorted holds n nodes, keep n bytes, ticket_of n words (a selected point's slot inside its
+// bucket).  n_buckets: a power of two >= 4096
 void launch_radius_filter(const float *x, const float *y, const float *z, uint32_t n, const Mat34f &m_cam, const CamK &cam,
                           const BBoxTest &bt, int nb, bool use_plane, float thr_f, RansacState *st, int16_t *ids,
                           uint32_t *cell_cnt, uint32_t *pre, uint32_t *blk_off, unsigned *ticket, CellNode *sorted, uint8_t *keep,
-                          long long *acc, uint32_t n_buckets, float r2f, int min_pts, hipStream_t s);
+                          uint32_t *ticket_of, long long *acc, uint32_t n_buckets, float r2f, int min_pts, hipStream_t s);
 size_t pca_acc_words(int nb);   // 64-bit words of acc
 size_t pca_ext_words(int nb);   // 32-bit words of ext
 // centroid + PCA rectangle of every bbox's kept points (bboxPoseEstimation :156-181, computePCABoundingBox :187-247)
