@@ -1,5 +1,8 @@
 // grid_vision_hip_node.cpp -- ROS2 node shim over libgridvision_hip.so.
-// NOT COMPILED IN THIS REPOSITORY'S IMAGE (no ROS2 here); see ros2/README.md.
+// NOT COMPILED IN THIS REPOSITORY'S IMAGE (no ROS2 here); see ros2/README.md.  Build: cmake -DGV_WITH_ROS2=ON (CMakeLists.txt).
+// Everything this file decides is message / tf conversion; the callback's decisions live in grid_vision/frame_flow.hpp
+// and the contents of the markers and of the detection overlay in grid_vision/viz_specs.hpp, both compiled and tested
+// without ROS (tests/test_gpu_parity.py::test_cpp_flow_demo, tests/test_host_side.py).
 // Same ROS surface as the reference node (src/grid_vision_node.cpp): parameters :8-32,
 // subscriptions :43-47, 50 ms wall timer :49-50, publishers :52-54, tf frames :290,:348,:371.
 #include <functional>
@@ -7,8 +10,11 @@
 #include <string>
 #include <vector>
 
+#include <cv_bridge/cv_bridge.h>
 #include <geometry_msgs/msg/transform_stamped.hpp>
+#include <image_transport/image_transport.hpp>
 #include <nav_msgs/msg/occupancy_grid.hpp>
+#include <opencv2/imgproc.hpp>
 #include <rclcpp/rclcpp.hpp>
 #include <sensor_msgs/msg/image.hpp>
 #include <sensor_msgs/msg/point_cloud2.hpp>
@@ -17,6 +23,7 @@
 #include <visualization_msgs/msg/marker_array.hpp>
 
 #include <grid_vision/frame_flow.hpp>
+#include <grid_vision/viz_specs.hpp>
 
 namespace {
 gv_transform toGv(const geometry_msgs::msg::Transform &t)
@@ -87,8 +94,9 @@ public:
     cloud_sub_ = create_subscription<sensor_msgs::msg::PointCloud2>(
       lidar_topic_, 1, [this](sensor_msgs::msg::PointCloud2::ConstSharedPtr msg) { cloudCallback(*msg); });
     timer_ = create_wall_timer(std::chrono::milliseconds(50), [this] { timerCallback(); });
-    occupancy_pub_ = create_publisher<nav_msgs::msg::OccupancyGrid>("occupancy_grid", 10);
-    viz_pub_ = create_publisher<visualization_msgs::msg::MarkerArray>("objects_viz", 10);
+    detection_pub_ = image_transport::create_publisher(this, "carla/front/detections");             // :52
+    occupancy_pub_ = create_publisher<nav_msgs::msg::OccupancyGrid>("occupancy_grid", 10);           // :53
+    viz_pub_ = create_publisher<visualization_msgs::msg::MarkerArray>("objects_viz", 10);            // :54
     tf_buffer_ = std::make_unique<tf2_ros::Buffer>(get_clock());
     tf_listener_ = std::make_unique<tf2_ros::TransformListener>(*tf_buffer_);
   }
@@ -152,9 +160,55 @@ private:
     if (!r.warning.empty()) RCLCPP_WARN(get_logger(), "%s", r.warning.c_str());
     depth_vec_ = r.depth_vec;
     static_points_ = r.cam_points;
+    // the reference's order: detections, grid, markers (:239-243); the early-return paths publish the grid only
+    if (r.publish_detections && image_) publishObjectDetections(r.bboxes);
     if (r.publish_grid) publishOccupancyGrid();
-    // (publishObjectDetections / publishObjectVisualizations, :246-263,405-523: r.publish_detections, r.bboxes,
-    //  r.bboxes_pose, r.cam_points carry what they draw)
+    if (r.publish_detections) publishObjectVisualizations(r.bboxes_pose, r.cam_points, r.static_bboxes);
+  }
+
+  // GridVision::publishObjectDetections (:246-263): the boxes drawn into a copy of the camera image.  What is drawn
+  // where is grid_vision::buildDetectionOverlay (object_detection::draw_bboxes, src/object_detection.cpp:213-224)
+  void publishObjectDetections(const std::vector<BoundingBox> &bboxes)
+  {
+    cv_bridge::CvImagePtr img;
+    try {
+      img = cv_bridge::toCvCopy(image_, "rgb8");   // imageCallback's conversion (:84), on a copy (:251)
+    } catch (const cv_bridge::Exception &e) {
+      RCLCPP_ERROR(get_logger(), "cv_bridge error: %s", e.what());
+      return;
+    }
+    for (const grid_vision::OverlaySpec &o : grid_vision::buildDetectionOverlay(bboxes)) {
+      const cv::Scalar colour(o.r, o.g, o.b);
+      cv::rectangle(img->image, cv::Rect(o.x, o.y, o.w, o.h), colour, o.box_thickness);
+      cv::putText(img->image, o.label, cv::Point(o.text_x, o.text_y), cv::FONT_HERSHEY_SIMPLEX, o.font_scale, colour, o.text_thickness);
+    }
+    std_msgs::msg::Header header;
+    header.stamp = rclcpp::Clock(RCL_ROS_TIME).now();   // :257
+    detection_pub_.publish(*cv_bridge::CvImage(header, "rgb8", img->image).toImageMsg());
+  }
+
+  // GridVision::publishObjectVisualizations (:405-523): one Marker per grid_vision::MarkerSpec, field by field
+  void publishObjectVisualizations(const std::vector<LShapePose> &lshape_boxes, const std::vector<geometry::Point> &static_positions,
+                                   const std::vector<BoundingBox> &static_bboxes)
+  {
+    visualization_msgs::msg::MarkerArray arr;
+    for (const grid_vision::MarkerSpec &m : grid_vision::buildObjectVisualizations(lshape_boxes, static_positions, static_bboxes, base_frame_)) {
+      visualization_msgs::msg::Marker k;
+      k.header.frame_id = m.frame_id;
+      k.header.stamp = rclcpp::Clock().now();   // :427 (system clock, as the reference)
+      k.ns = m.ns;
+      k.id = m.id;
+      k.type = m.type;
+      k.action = m.action;
+      k.lifetime = rclcpp::Duration::from_seconds(m.lifetime_s);
+      k.pose.position.x = m.px; k.pose.position.y = m.py; k.pose.position.z = m.pz;
+      k.pose.orientation.x = m.qx; k.pose.orientation.y = m.qy; k.pose.orientation.z = m.qz; k.pose.orientation.w = m.qw;
+      k.scale.x = m.sx; k.scale.y = m.sy; k.scale.z = m.sz;
+      k.color.r = m.r; k.color.g = m.g; k.color.b = m.b; k.color.a = m.a;
+      k.text = m.text;
+      arr.markers.push_back(k);
+    }
+    viz_pub_->publish(arr);
   }
 
   void publishOccupancyGrid()
@@ -189,6 +243,7 @@ private:
   rclcpp::Subscription<sensor_msgs::msg::Image>::SharedPtr image_sub_;
   rclcpp::Subscription<sensor_msgs::msg::PointCloud2>::SharedPtr cloud_sub_;
   rclcpp::TimerBase::SharedPtr timer_;
+  image_transport::Publisher detection_pub_;
   rclcpp::Publisher<nav_msgs::msg::OccupancyGrid>::SharedPtr occupancy_pub_;
   rclcpp::Publisher<visualization_msgs::msg::MarkerArray>::SharedPtr viz_pub_;
   std::unique_ptr<tf2_ros::Buffer> tf_buffer_;
