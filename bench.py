@@ -60,6 +60,8 @@ def parse():
     ap.add_argument("--min-reps", type=int, default=5, help="repetitions of the K-step timed region (median reported)")
     ap.add_argument("--force-sharded", action="store_true",
                     help="config 5 through the sharded (RCCL) frame even with one rank: rehearses the code path on one GPU")
+    ap.add_argument("--slice-of", type=int, default=0,
+                    help="(PMC child passes) with --force-sharded on one rank: keep only the first 1 / W of the points, what a rank of a W-rank job bins")
     ap.add_argument("--rehearsal", action="store_true",
                     help="allow more ranks than GPUs (ranks share devices, gloo barrier): reported as rehearsal")
     return ap.parse_args()
@@ -664,7 +666,7 @@ def leg_pca_path(gvamd, synth, g, tfs, config, bboxes, local_rank, reps=10, cpu_
     return out
 
 
-def pmc_child_passes(config, budget_note):
+def pmc_child_passes(config, budget_note, sharded_world=0):
     """HBM traffic and issue counters of every kernel, measured in THIS run: the script runs itself
     (--plain, serial frame so that dispatches do not overlap) under `rocprofv3 --pmc`, one counter group
     per pass and no trace domain (MI355X_MICROARCH.md, rocprofv3 PMC slots / HBM).  FETCH_SIZE is in KB
@@ -684,6 +686,11 @@ def pmc_child_passes(config, budget_note):
             d = os.path.join(tmp, f"p{k}")
             cmd = [rocprof, "--pmc", *grp.split(), "--output-format", "csv", "-d", d, "--", sys.executable,
                    os.path.join(ROOT, "bench.py"), "--plain", "--steps", "10", "--warmup", "3", "--config", str(config)]
+            if sharded_world:
+                # the sharded frame's kernels on ONE rank's share of the points, through a 1-rank communicator (a
+                # profiler child cannot join the job's communicator): same kernels, same per-rank point count; the
+                # sector stage runs all of its workgroups here, 1 / world of them in the job
+                cmd += ["--force-sharded", "--slice-of", str(sharded_world)]
             try:
                 p = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=150)
             except subprocess.TimeoutExpired:
@@ -790,6 +797,8 @@ def main():
         xb, yb, zb, _ = synth.cloud_uniform(config, cfg["n"] - cfg["n"] // 2)
         xf, yf, zf = np.concatenate([xa, xb]), np.concatenate([ya, yb]), np.concatenate([za, zb])
         lo_i, hi_i = (len(xf) * rank // world, len(xf) * (rank + 1) // world) if sharded else (0, len(xf))
+        if sharded and world == 1 and a.slice_of > 1:
+            hi_i = len(xf) // a.slice_of
         x, y, z = xf[lo_i:hi_i], yf[lo_i:hi_i], zf[lo_i:hi_i]
         N_total = len(xf)
     else:
@@ -807,6 +816,12 @@ def main():
         if dist is not None:
             dist.broadcast_object_list(uid, src=0)
         h.comm_init(uid[0], rank, world)
+        # what RCCL itself reports, from every rank: the line must show that `world` ranks on `world` devices took part
+        info = h.comm_info()
+        infos = [info]
+        if dist is not None:
+            infos = [None] * world
+            dist.all_gather_object(infos, info)
 
     def barrier():
         h.synchronize()
@@ -916,13 +931,15 @@ def main():
         if rehearsal:
             out["rehearsal"] = True
         if shard_extra:
+            shard_extra["rccl_ranks"] = int(infos[0][0])
+            shard_extra["rccl"] = [{"rank": int(i[1]), "device": int(i[2]), "ranks_seen": int(i[0])} for i in infos]
             out["sharded"] = shard_extra
         pmc, pmc_err = (None, "skipped")
         if not a.plain and not a.no_pmc and not rehearsal:
             # (at N > 1 too: the other ranks idle at the closing barrier while rank 0's children profile the same
             #  workload on its own GPU, so that the roofline object is filled at every N)
             h.synchronize()
-            pmc, pmc_err = pmc_child_passes(3 if config == 4 else config, "") if not sharded else (None, "skipped for the sharded frame")
+            pmc, pmc_err = pmc_child_passes(3 if config == 4 else config, "", sharded_world=world if sharded else 0)
         kernels = []
         for st, ms in stages.items():
             if st == "detections":

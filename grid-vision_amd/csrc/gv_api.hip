@@ -2775,6 +2775,20 @@ int gv_comm_init(gv_handle h, const uint8_t id[128], int32_t rank, int32_t world
   GV_CATCH
 }
 
+int gv_comm_info(gv_handle h, int32_t *n_ranks, int32_t *rank, int32_t *device)
+{
+  if (!h) return GV_ERR_BAD_ARG;
+  if (!h->comm) return GV_ERR_STATE;
+  int nr = 0, rk = 0, dev = 0;
+  GV_NCCL(ncclCommCount(h->comm, &nr));
+  GV_NCCL(ncclCommUserRank(h->comm, &rk));
+  GV_NCCL(ncclCommCuDevice(h->comm, &dev));
+  if (n_ranks) *n_ranks = nr;
+  if (rank) *rank = rk;
+  if (device) *device = dev;
+  return GV_OK;
+}
+
 int gv_comm_destroy(gv_handle h)
 {
   if (!h) return GV_ERR_BAD_ARG;

@@ -49,6 +49,7 @@ ABI_SYMBOLS = [
     "gv_host_free", "gv_frame_set_detections_async", "gv_frame_fence", "gv_debug_frame_sharded_emulated",
     "gv_to_occupancy_grid_async", "gv_frame_enqueue_sharded", "gv_time_frame_sharded_stages", "gv_shard_band_rows",
     "gv_shard_slice_words", "gv_device_layers", "gv_tick_enqueue", "gv_tick_wait", "gv_tick",
+    "gv_comm_info",
 ]
 
 
@@ -530,6 +531,12 @@ class GridVisionHIP:
     def comm_init(self, uid: bytes, rank: int, world: int):
         buf = (C.c_uint8 * 128).from_buffer_copy(uid)
         self._ck(self._lib.gv_comm_init(self._h, buf, C.c_int32(rank), C.c_int32(world)), "gv_comm_init")
+
+    def comm_info(self):
+        """(ranks in the communicator, this rank, its device) as RCCL reports them"""
+        a, b, c = C.c_int32(), C.c_int32(), C.c_int32()
+        self._ck(self._lib.gv_comm_info(self._h, C.byref(a), C.byref(b), C.byref(c)), "gv_comm_info")
+        return a.value, b.value, c.value
 
     def comm_destroy(self):
         self._ck(self._lib.gv_comm_destroy(self._h), "gv_comm_destroy")

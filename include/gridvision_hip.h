@@ -382,6 +382,10 @@ int gv_time_frame_stages(gv_handle h, int32_t frames, float *stage_ms);
 int gv_comm_unique_id(uint8_t id_out[128]);
 int gv_comm_init(gv_handle h, const uint8_t id[128], int32_t rank, int32_t world);
 int gv_comm_destroy(gv_handle h);
+/* What RCCL itself says about the communicator (ncclCommCount / ncclCommUserRank / ncclCommCuDevice): the number of
+ * ranks that joined, this rank, and the device it runs on -- bench.py prints them, so that a scaling line proves that
+ * N ranks on N devices took part.  GV_ERR_STATE before gv_comm_init. */
+int gv_comm_info(gv_handle h, int32_t *n_ranks, int32_t *rank, int32_t *device);
 /* Sharded frame, asynchronous: the counterpart of gv_frame_enqueue (same detection sets, same back-pressure of
  * four frames in flight on two lanes, results on the public stream behind it) for a resident cloud that is this rank's
  * slice.  Binning, sector share and band packing run on the frame's lane, the RCCL exchanges on the handle's

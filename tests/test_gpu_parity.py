@@ -661,6 +661,7 @@ def test_sharded_frame_world1_matches_plain(gvamd):
     hb, _ = make_handle(gvamd, config, perturbed=True)
     hb.comm_init(gvamd.GridVisionHIP.comm_unique_id(), 0, 1)
     assert hb.comm_band() == (0, hb.G)
+    assert hb.comm_info()[:2] == (1, 0)        # what RCCL says: one rank, this is rank 0
     for h in (ha, hb):
         h.upload_xyz(x, y, z)
     for frame in range(3):
