@@ -979,6 +979,7 @@ int enqueue_frame_tiles(gv_context *h, bool pipelined, bool stage_events)
     GV_HIP(hipStreamWaitEvent(h->stream, h->ev_sec[slot], 0));
     s = h->stream;
   }
+
   mark(s);
   // ev_fin[slot] completes with the grid pass: this frame done => every earlier frame done
   if (stage_events) {   // stage timing: the kernel carries its own start / end events, ev_fin follows as a marker
@@ -2147,6 +2148,41 @@ int gv_to_occupancy_grid_async(gv_handle h, int8_t *data)
   GV_CATCH
 }
 
+// The packed grid to PINNED host memory by a small kernel on the public stream, right behind the grid pass.  Measured
+// with a cloud streaming in per frame (tools/stream_run.py, profiles/r04/publish_variants.txt): hipMemcpyAsync on the
+// public stream 292-349 us per frame and erratic (the download's copy engine interleaves with the upload's: one
+// download in six took 300 us instead of 85); the download ordered on the upload stream between two uploads 381 us
+// (steady, but every copy command costs ~25 us of engine turn-around); this kernel 262 us, within 0.3 % frame after
+// frame -- the copy engines stay with the uploads, PCIe carries both directions at once.
+static int publish_by_kernel(gv_context *h, int8_t *data, hipStream_t s, bool *done)
+{
+  *done = false;
+  hipPointerAttribute_t at{};
+  if (hipPointerGetAttributes(&at, data) != hipSuccess || at.type != hipMemoryTypeHost || !at.devicePointer) {
+    (void)hipGetLastError();   // pageable memory: the caller gets the copy command instead
+    return GV_OK;
+  }
+  const size_t G = (size_t)h->g.G, body = G & ~(size_t)15;
+  launch_publish_grid(h->occ_i8, static_cast<int8_t *>(at.devicePointer), body, 32, s);
+  GV_HIP(hipGetLastError());
+  if (G > body) GV_HIP(hipMemcpyAsync(data + body, h->occ_i8 + body, G - body, hipMemcpyDeviceToHost, s));
+  *done = true;
+  return GV_OK;
+}
+
+int gv_publish_grid_async(gv_handle h, int8_t *data)
+{
+  if (!h || !data) return GV_ERR_BAD_ARG;
+  GV_TRY
+  int rc = set_device_only(h);
+  if (rc) return rc;
+  bool done = false;
+  if ((rc = publish_by_kernel(h, data, h->stream, &done))) return rc;
+  if (!done) GV_HIP(hipMemcpyAsync(data, h->occ_i8, (size_t)h->g.G, hipMemcpyDeviceToHost, h->stream));
+  return GV_OK;
+  GV_CATCH
+}
+
 static int copy_out(gv_context *h, void *dst, const void *src, size_t bytes)
 {
   int rc = use_device(h);
@@ -3054,6 +3090,8 @@ int gv_tick_enqueue(gv_handle h, const gv_tick_desc *d)
     h->have_miss = true;
   } else if ((rc = enqueue_plain_update(h, n_rects)))
     return rc;
+  // a copy command, not gv_publish_grid_async's kernel: no upload competes for the copy engines inside a tick, and the
+  // kernel measured no faster here (0.326 vs 0.321 ms PCA tick, 0.167 vs 0.161 ms vision tick)
   if (d->grid_out) GV_HIP(hipMemcpyAsync(d->grid_out, h->occ_i8, (size_t)h->g.G, hipMemcpyDeviceToHost, s));
   if (knn_forked) GV_HIP(hipStreamWaitEvent(s, T.join, 0));
   GV_HIP(hipEventRecord(T.done, s));

@@ -198,6 +198,20 @@ void launch_bbox_prepare(const gv_bbox *bboxes, int32_t nb, int32_t tiles_x, int
                      (uint32_t)((copy_bytes + 15) / 16));
 }
 
+// The packed grid to pinned host memory by a kernel of its own (gv_publish_grid_async): 16-byte stores of consecutive
+// lanes, i.e. posted PCIe writes of whole lines, from a few workgroups -- the copy engines stay with the cloud uploads.
+__global__ void __launch_bounds__(256) k_publish_grid(const uint4 *__restrict__ src, uint4 *__restrict__ dst, uint32_t n16)
+{
+  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n16; i += gridDim.x * 256u) dst[i] = src[i];
+}
+
+void launch_publish_grid(const int8_t *src, int8_t *dst_host, size_t bytes, int blocks, hipStream_t s)
+{
+  const uint32_t n16 = (uint32_t)(bytes / 16);
+  if (n16) hipLaunchKernelGGL(k_publish_grid, dim3(blocks), dim3(256), 0, s, reinterpret_cast<const uint4 *>(src),
+                              reinterpret_cast<uint4 *>(dst_host), n16);
+}
+
 // A1 standalone: camera-frame copy of the cloud (transformLidarToCamera)
 __global__ void __launch_bounds__(256) k_transform(const float *__restrict__ x, const float *__restrict__ y,
                                                    const float *__restrict__ z, uint32_t n, Mat34f m,

@@ -92,6 +92,8 @@ struct FinalizeArgs {
 void launch_finalize(const FinalizeArgs &a, hipStream_t s);
 
 void launch_fill_f32(float *p, float v, size_t n, hipStream_t s);
+// bytes (a multiple of 16) from device memory to pinned, device-visible host memory by `blocks` workgroups
+void launch_publish_grid(const int8_t *src, int8_t *dst_host, size_t bytes, int blocks, hipStream_t s);
 void launch_hold(unsigned long long ticks_100mhz, hipStream_t s);   // one idle wavefront for that long (queue probe)
 void launch_u8_to_i32(const uint8_t *in, int32_t *out, size_t n, hipStream_t s);
 void launch_i16_to_i32(const int16_t *in, int32_t *out, size_t n, hipStream_t s);

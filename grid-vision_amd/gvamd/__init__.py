@@ -49,7 +49,7 @@ ABI_SYMBOLS = [
     "gv_host_free", "gv_frame_set_detections_async", "gv_frame_fence", "gv_debug_frame_sharded_emulated",
     "gv_to_occupancy_grid_async", "gv_frame_enqueue_sharded", "gv_time_frame_sharded_stages", "gv_shard_band_rows",
     "gv_shard_slice_words", "gv_device_layers", "gv_tick_enqueue", "gv_tick_wait", "gv_tick",
-    "gv_comm_info",
+    "gv_comm_info", "gv_publish_grid_async",
 ]
 
 
@@ -393,6 +393,11 @@ class GridVisionHIP:
         """pinned_i8: int8 view of G bytes of pinned memory; complete once gv_stream has passed this point"""
         assert pinned_i8.dtype == np.int8 and pinned_i8.size == self.G
         self._ck(self._lib.gv_to_occupancy_grid_async(self._h, _ptr(pinned_i8)), "to_occupancy_grid_async")
+
+    def publish_grid_async(self, pinned_i8):
+        """the packed grid to PINNED host memory by a kernel on the public stream (the copy engines stay with the uploads)"""
+        assert pinned_i8.dtype == np.int8 and pinned_i8.size == self.G
+        self._ck(self._lib.gv_publish_grid_async(self._h, _ptr(pinned_i8)), "gv_publish_grid_async")
 
     def log_odds(self):
         out = np.empty(self.G, np.float32)

@@ -237,6 +237,13 @@ int gv_to_occupancy_grid(gv_handle h, int8_t *data, gv_grid_info *info);
  * should be pinned (gv_host_alloc); it is complete once an event recorded on gv_stream(h) after this
  * call has passed, or after gv_synchronize. */
 int gv_to_occupancy_grid_async(gv_handle h, int8_t *data);
+/* The same for a node that publishes the grid EVERY tick while clouds stream in (the reference does:
+ * grid_vision_node.cpp:240, :265-278).  data must be pinned (gv_host_alloc): the grid is then written there by a small
+ * kernel on gv_stream(h) instead of a copy command, so the copy engines stay with the cloud uploads and PCIe carries
+ * both directions at once -- 262 us per frame, steady, against 292-349 us and erratic for the copy command beside an
+ * upload (profiles/r04/publish_variants.txt).  Pageable memory falls back to the copy command.  Same completion rule as
+ * gv_to_occupancy_grid_async. */
+int gv_publish_grid_async(gv_handle h, int8_t *data);
 /* Layer read-back (grid_map_["log_odds"], ["occupancy"]; occupancy_grid.hpp:22) */
 int gv_get_log_odds(gv_handle h, float *out);
 int gv_get_occupancy(gv_handle h, float *out);

@@ -1680,6 +1680,50 @@ def test_stream_contract_public_stream(gvamd):
         p.close()
 
 
+def test_publish_grid_every_frame_while_clouds_stream(gvamd):
+    """gv_publish_grid_async: the node's "publish the grid every tick" while clouds stream in.  Eight frames, each with a
+    fresh cloud (asynchronous upload) and the grid of the frame written to pinned host memory by a kernel on the public
+    stream; a ninth and tenth frame on the resident cloud; one grid into PAGEABLE memory (falls back to the copy
+    command).  Every grid received equals the oracle's after that many frames, nothing synchronised in between."""
+    config = 2
+    g = synth.CONFIGS[config]["grid"]
+    og = ol.OGrid(g.grid_x, g.grid_y, g.resolution)
+    h, tfs = make_handle(gvamd, config, perturbed=True)
+    flags = gvamd.FRAME_BIN | gvamd.FRAME_RAYMARCH
+    h.set_detections(flags)
+    n_frames = 10
+    outs = [gvamd.PinnedI8(h.G) for _ in range(n_frames)]
+    pageable = np.zeros(h.G, np.int8)
+    clouds, want = [], []
+    for f in range(8):
+        x, y, z, _ = (synth.cloud_lidar_like if f % 2 else synth.cloud_uniform)(config, 150_000 + 7_000 * f, seed_extra=70 + f)
+        pin = [gvamd.PinnedF32(len(x)) for _ in range(3)]
+        for p, a in zip(pin, (x, y, z)):
+            p.array[:] = a
+        clouds.append((x, y, z, pin))
+    for f in range(n_frames):
+        x, y, z, pin = clouds[min(f, 7)]
+        if f < 8:
+            h.upload_xyz_async(pin[0].array, pin[1].array, pin[2].array)
+        h.enqueue_frame()
+        h.publish_grid_async(outs[f].array)
+        if f == 5:
+            h.publish_grid_async(pageable)
+        oracle_frame(og, tfs, x, y, z)
+        want.append(og.to_occupancy_grid()[0].copy())
+    h.synchronize()
+    assert np.array_equal(pageable, outs[5].array)
+    for f in range(n_frames):
+        diff = np.abs(outs[f].array.astype(np.int16) - want[f].astype(np.int16))
+        assert diff.max() <= 1 and np.count_nonzero(diff) <= 1e-4 * h.G, f
+    h.close()
+    for o in outs:
+        o.close()
+    for _, _, _, pin in clouds:
+        for p in pin:
+            p.close()
+
+
 def test_device_layers_are_the_resident_grid(gvamd):
     """gv_device_layers: the device pointers a device-side consumer reads behind a frame on gv_stream hold what the
     host getters return"""

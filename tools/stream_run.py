@@ -37,9 +37,13 @@ while done < frames:
         h.upload_xyz_async(px, py, pz)
         h.set_detections_async(flags, bboxes=dets[f % 3][0], poses=dets[f % 3][1])
         h.enqueue_frame()
-        if pub is not None:   # "pub": the packed grid goes back to pinned host memory behind every grid pass
-            h.to_occupancy_grid_async(pub[f % 2].array.view("int8")[:h.G])
-    h.synchronize()
+        if pub is not None:   # "pub": the packed grid goes back to pinned host memory for every frame:
+            if "sched" in sys.argv:   # by a kernel on the public stream (gv_publish_grid_async)
+                h.publish_grid_async(pub[f % 2].array.view("int8")[:h.G])
+            else:                     # on the public stream right behind the grid pass (round 3)
+                h.to_occupancy_grid_async(pub[f % 2].array.view("int8")[:h.G])
+    if "nosync" not in sys.argv or done + nchunk >= frames:
+        h.synchronize()
     per.append(round((time.perf_counter() - t0) / nchunk * 1e6, 1))
     done += nchunk
 print("us/frame per chunk of 100:", per)
