@@ -114,6 +114,7 @@ struct gv_context {
   uint64_t frame_no = 0;
   bool pipe_busy = false;         // lane frames enqueued since the streams were last drained
   bool no_pipeline = false;       // GV_PIPELINE=0
+  int32_t env_sector_rev = -1;    // GV_SECTOR_REV (sweeps)
 #ifdef GV_DIAG
   std::vector<hipEvent_t> *trace = nullptr;   // timing events around every pipelined kernel (gv_debug_pipeline_trace)
   unsigned long long *d_dbg = nullptr;        // GV_SECTOR_DBG=1: phase stamps of the sector kernel
@@ -649,6 +650,30 @@ int fill_sector_args(gv_context *h, SectorArgs &sa, int p)
     if (h->env_log2s_oct[o] > 0) { l2 = h->env_log2s_oct[o]; est = 1.5 * dens * (double)len[o] * (double)len[o] / (double)(2 << l2); }
     sa.log2s_oct[o] = (uint8_t)l2;
     est_max = std::max(est_max, est);
+  }
+  // Rows of 512 columns, 8 blocks of 64 each, one block per wavefront: a row goes to the wavefronts in ascending or in
+  // descending order, whichever keeps the fullest wavefront lightest (far columns are wider: weight ~ column number),
+  // rows taken from the heaviest (last) one down.  GV_SECTOR_REV=0 / 1: never / always alternate (experiments).
+  for (int o = 0; o < 8; ++o) {
+    const int rows = (len[o] + 511) / 512;
+    double load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint16_t mask = 0;
+    const double wbase = (double)(1 << sa.log2s_oct[o]);   // a column's cost: its cells (a / S + 1), times S
+    for (int r = std::min(rows, 16) - 1; r >= 0; --r) {
+      double w[8];
+      for (int b = 0; b < 8; ++b) {
+        const int a0 = 512 * r + 64 * b + 1, a1 = std::min(a0 + 63, len[o]);
+        w[b] = a1 >= a0 ? (double)(a1 - a0 + 1) * (0.5 * (double)(a0 + a1) + wbase) : 0.0;
+      }
+      double up = 0.0, down = 0.0;
+      for (int b = 0; b < 8; ++b) { up = std::max(up, load[b] + w[b]); down = std::max(down, load[b] + w[7 - b]); }
+      bool rev = down < up;
+      if (h->env_sector_rev == 0) rev = false;
+      if (h->env_sector_rev == 1) rev = (r & 1) != 0;
+      if (rev) mask |= (uint16_t)(1u << r);
+      for (int b = 0; b < 8; ++b) load[b] += rev ? w[7 - b] : w[b];
+    }
+    sa.rev_oct[o] = mask;
   }
   sa.cap = h->env_cap > 0 ? std::max(2048, h->env_cap) : ((est_max <= 1700.0 && h->env_log2s <= 0) ? 2048 : 4096);
   sa.ablate = 0;
@@ -1470,6 +1495,7 @@ int gv_create(gv_handle *out, uint8_t grid_x, uint8_t grid_y, double resolution,
     if (const char *e = std::getenv("GV_FLAT_DIRECT")) h->env_flat_direct = (uint32_t)std::max(0, std::atoi(e));
     if (const char *e = std::getenv("GV_MARCH_LIMIT")) h->env_march_limit = (uint32_t)std::max(0, std::atoi(e));
     if (const char *e = std::getenv("GV_LOG2M")) h->env_log2m = std::min(9, std::max(4, std::atoi(e)));
+    if (const char *e = std::getenv("GV_SECTOR_REV")) h->env_sector_rev = std::atoi(e);
 #ifdef GV_DIAG
     if (const char *e = std::getenv("GV_ABLATE")) h->env_ablate = std::atoi(e);
     if (const char *e = std::getenv("GV_BIN_DBG")) {

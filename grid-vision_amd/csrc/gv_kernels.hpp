@@ -160,6 +160,7 @@ struct SectorArgs {
   RayOrigin org;
   uint8_t log2s_oct[8];   // sectors of octant o = 1 << log2s_oct[o]: short wedges get fewer, fatter sectors
   uint16_t wg_base[9];    // first workgroup of the k-th octant in dispatch order (oct_perm); [8] = grid size
+  uint16_t rev_oct[8];    // octant o, bit c: the threads hold row c of the wedge's columns (512 per row) in descending order
   int32_t cap;            // ends per LDS chunk (>= 2048)
   int32_t log2m;          // slope buckets per sector = 1 << log2m (<= 9)
   int32_t marks_words;    // >= max(nx, ny) + 1

@@ -141,7 +141,8 @@ __host__ __device__ inline SectorLds sector_lds_layout(int cap, int marks_words,
   size_t o = 0;
   L.tab = o;    o += (M * kSlots > (size_t)cap ? M * kSlots : (size_t)cap) * 4;   // [M][kSlots] packed ends (16-byte aligned rows); a crowded group: cap ends grouped by bucket
   L.raw = o;    o += (size_t)cap * 4;           // packed ends in scan order (staging list; the long-ray pass reads it too)
-  L.over = o;   o += (size_t)cap * 4;           // overflow entries: bucket << 16 | index into raw
+  L.over = o;   o += (size_t)(cap > 2 * kSlotTotal ? cap : 2 * kSlotTotal) * 4;   // overflow entries: bucket << 16 | index into raw -- two lists of
+                                                // kSlotTotal (as placed / after the same-slope merge); a crowded group: cap bucket numbers (16 bit)
   L.marks = o;  o += (size_t)marks_words * 4;
   L.cnt = o;    o += M * 4;                     // ends per bucket (may exceed kSlots); a crowded group: the end of every bucket's run
   L.bstart = o; o += M * 4;                     // a crowded group: the start of every bucket's run
@@ -213,6 +214,7 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
   const SectorLds L = sector_lds_layout(cap, A.marks_words, LM);
   unsigned *tab = reinterpret_cast<unsigned *>(smem + L.tab);          // packed ends by slope bucket: kSlots per bucket
   unsigned *over = reinterpret_cast<unsigned *>(smem + L.over);        // what does not fit: bucket << 16 | index into raw
+  unsigned *over2 = over + kSlotTotal;                                  // ... and what is left of it after the same-slope merge
   unsigned *marks = reinterpret_cast<unsigned *>(smem + L.marks);      // one word of cell bits per wedge column
   unsigned *cnt = reinterpret_cast<unsigned *>(smem + L.cnt);          // ends per bucket
   unsigned *bstart = reinterpret_cast<unsigned *>(smem + L.bstart);    // crowded group: bucket run starts
@@ -221,7 +223,7 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
   unsigned short *pfx = reinterpret_cast<unsigned short *>(smem + L.pfx);   // max from the block start to m
   unsigned short *sfx = reinterpret_cast<unsigned short *>(smem + L.sfx);   // max from m to the block end
   unsigned *raw = reinterpret_cast<unsigned *>(smem + L.raw);               // packed ends, scan order
-  __shared__ unsigned s_wsum[NT / 64], s_wsum2[NT / 64], s_blkmax[8], s_blkpfx[9], s_blksfx[9], s_lvlmin[10 * 8], s_nlong, s_nover, s_T, s_maxreach;
+  __shared__ unsigned s_wsum[NT / 64], s_wsum2[NT / 64], s_blkmax[8], s_blkpfx[9], s_blksfx[9], s_lvlmin[10 * 8], s_nlong, s_nover, s_nover2, s_T, s_maxreach;
   __shared__ unsigned long long s_wvis[NT / 64];
   __shared__ unsigned s_rowpart[CH][NT / 64];   // multi-group path: ends per (row, wavefront)
 
@@ -233,16 +235,24 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
     if (A.dbg && tid == 0 && stamp_n < 16) A.dbg[(size_t)wg * 16 + stamp_n] = __builtin_amdgcn_s_memtime();
     ++stamp_n;
   };
+  auto fstamp = [&](int n) {   // fine stamps: second half of the buffer
+    if (A.dbg && tid == 0) A.dbg[((size_t)16384 + wg) * 16 + n] = __builtin_amdgcn_s_memtime();
+  };
+  auto fnote = [&](int n, unsigned long long v) {
+    if (A.dbg && tid == 0) A.dbg[((size_t)16384 + wg) * 16 + n] = v;
+  };
   stamp();
   if (A.dbg && tid == 0) A.dbg[(size_t)wg * 16 + 14] = ((unsigned long long)o << 32) | (unsigned)s | ((unsigned long long)log2s << 40);
 #else
   auto stamp = []() {};
+  auto fstamp = [](int) {};
+  auto fnote = [](int, unsigned long long) {};
   (void)wg;
 #endif
   for (int i = tid; i <= oc.imax; i += NT) marks[i] = 0;
   if (tid < NT / 64) s_wvis[tid] = 0;
   for (int m = tid; m < M; m += NT) { cnt[m] = 0; bmax32[m] = 0; }
-  if (tid == 0) { s_nlong = 0; s_nover = 0; }
+  if (tid == 0) { s_nlong = 0; s_nover = 0; s_nover2 = 0; }
   // (no barrier here: nothing reads what was just cleared before the barrier behind the column scan below, and
   //  the scan's bitmap loads go out without waiting for the slowest wavefront's stores)
 #ifdef GV_DIAG
@@ -296,6 +306,14 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
   // overflow list is only looked at for a bucket that holds more than its row.
   // `mode`: std::true_type = the group's buckets are contiguous runs of `tab` (counting-sort placement, crowded
   // wedges), std::false_type = rows of kSlots + overflow list (everything else)
+  // the overflow list the walks scan: as placed (short lists) or after the same-slope merge
+  const unsigned *ovl = over;
+  unsigned novl = 0;
+#ifndef GV_MERGE_MIN
+#define GV_MERGE_MIN 16
+#endif
+  constexpr unsigned kMergeMin = GV_MERGE_MIN;   // a list shorter than this is scanned as it is: the merge pass is ~1.3 k cycles of
+                                                 // the workgroup's chain (profiles/r04/sector_round4.txt)
   auto walk_bucket = [&](auto mode, int m, unsigned e0, unsigned c, int Q, bool lo_open, int Plo, bool hi_open, int Phi) -> unsigned {
     constexpr bool sorted_mode = decltype(mode)::value;
     unsigned mx = 0;
@@ -319,11 +337,15 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
     const uint4 r1 = *reinterpret_cast<const uint4 *>(tab + ((unsigned)m << kSlotLog) + 4);
     take(r0.x, c > 0u); take(r0.y, c > 1u); take(r0.z, c > 2u); take(r0.w, c > 3u);
     if (c > 4u) { take(r1.x, true); take(r1.y, c > 5u); take(r1.z, c > 6u); take(r1.w, c > 7u); }
-    if (c > (unsigned)kSlots) {
-      const unsigned no = s_nover;
-      for (unsigned e = 0; e < no; ++e) {
-        const unsigned v = over[e];
-        if ((int)(v >> 16) == m) take(raw[v & 0xFFFFu], true);
+    if (c > (unsigned)kSlots && !GV_ABL(4096)) {
+      const unsigned no = novl;
+      for (unsigned e = 0; e < no; e += 4) {   // four entries per step, their reads issued together (the list's space is
+        unsigned v[4];                          // readable past the end: stale words are masked by e + q < no)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = ovl[e + (unsigned)q];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (e + (unsigned)q < no && (int)(v[q] >> 16) == m) take(raw[v[q] & 0xFFFFu], true);
       }
     }
     return mx;
@@ -360,7 +382,14 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
     blo = max(blo, oc.bmin);
     bhi = min(min(bhi, bmaxa), oc.jmaxo);
   };
-  // ---- scan: CH columns per thread (a = 1 + tid + NT*c), bitmap loads issued back to back.
+  // Column slot c of a thread: column 1 + NT*c + tid, or -- rows the host marks in rev_oct -- 1 + NT*c + (NT-1-tid).  A
+  // wavefront still holds 64 consecutive columns of a row (coalesced bitmap words), but the row's 8 blocks go to the
+  // wavefronts in descending order: far columns are wider (more cells, more ends), and with every row ascending the last
+  // wavefront of a 1000-column wedge held 2.5 x the ends of the first and the other seven waited ~3.8 k cycles at the barrier
+  // behind the append loop (profiles/r04/sector_phases_fine.txt).
+  const unsigned rev = A.rev_oct[o];
+  auto col_of = [&](int c) -> int { return 1 + NT * c + (((rev >> c) & 1u) ? NT - 1 - tid : tid); };
+  // ---- scan: CH columns per thread (a = col_of(c)), bitmap loads issued back to back.
   // ends / vcs live only from here to the staging loop of the group that consumes them; the
   // (rare) multi-group path re-reads its rows instead of keeping CH columns in registers.
   unsigned ends[CH], vcs[CH];
@@ -374,7 +403,7 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
       // a row of column slots that lies wholly beyond this octant's wedge (the kernel is instantiated for the
       // longest octant): nothing to load -- a wavefront-uniform skip
       if (NT * c >= oc.imax) continue;
-      const int a = 1 + tid + NT * c;
+      const int a = col_of(c);
       const bool in = (a <= oc.imax) && ((rowmask >> c) & 1u);
       const int ac = in ? a : 1;
       int blo, bhi;
@@ -404,7 +433,7 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
   scan_columns((1u << CH) - 1u);
   // one row only (multi-group path): the other rows read as empty
   auto scan_row = [&](int c) {
-    const int a = 1 + tid + NT * c;
+    const int a = col_of(c);
     unsigned e = 0, vc = 0;
     int blo, bhi;
     col_bounds(a, blo, bhi);
@@ -460,17 +489,19 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
   // evaluated exactly below (cell 1 resp. w-2), like the edge cells themselves.
   int xb0 = 0, xb1 = 0, xt0 = 0, xt1 = 0;   // excluded buckets [xb0, xb1) at the bottom, [xt0, xt1) at the top
   if (S >= 8) {
-    const long long SM = (long long)S << LM;
+    const unsigned SM = (unsigned)S << LM;   // S <= 2^12 (the host), M <= 2^9: 32 bits (a 64-bit division here was ~4 k cycles
+                                             // of these four sectors' -- the heaviest ones' -- chain)
     const int qlo = (s == 0) ? 1 : ((s == (S >> 1)) ? 2 : 0);
     const int qhi = (s == S - 1) ? 1 : ((s == (S >> 1) - 1) ? 2 : 0);
     if (qlo) {   // bucket k lies inside (0, Z) iff k + 1 <= Z*M; bucket 0 also holds the rational itself
       xb0 = (s == 0 && oc.bmin == 1) ? 0 : 1;
-      xb1 = (int)min((long long)M, SM / ((long long)qlo * oc.imax));
+      xb1 = (int)min((unsigned)M, SM / (unsigned)(qlo * oc.imax));
     }
     if (qhi) {   // bucket k lies inside (1 - Z, 1) iff k > M - Z*M; the last bucket of sector S-1 holds slope 1,
                  // which only the x-major octants own (the diagonal is theirs: bmaxa)
-      const long long c = (SM + (long long)qhi * oc.imax - 1) / ((long long)qhi * oc.imax);   // ceil(Z*M)
-      xt0 = (int)max(0ll, (long long)M - c + 1);
+      const unsigned den = (unsigned)(qhi * oc.imax);
+      const int c = (int)((SM + den - 1u) / den);   // ceil(Z*M)
+      xt0 = max(0, M - c + 1);
       xt1 = (s == S - 1 && oc.xmaj) ? M - 1 : M;
     }
   }
@@ -487,7 +518,7 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
     } else {
       __syncthreads();   // previous group fully done with the tables
       for (int m = tid; m < M; m += NT) { cnt[m] = 0; bmax32[m] = 0; }
-      if (tid == 0) { s_nlong = 0; s_nover = 0; }
+      if (tid == 0) { s_nlong = 0; s_nover = 0; s_nover2 = 0; }
       mycnt = 0;
 #pragma unroll
       for (int c = 0; c < CH; ++c)
@@ -496,6 +527,7 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
       if (lane == 63) s_wsum[wave] = incl;
       __syncthreads();
     }
+    fstamp(0);
     // slots of the dense staging list from the wavefront prefix sums
     unsigned slot = incl - mycnt;
     unsigned n = 0;
@@ -506,10 +538,11 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
     }
     // append the packed ends in scan order (a lane holds 0..32 ends of its columns: only the cheap packing runs
     // in this lane-unbalanced loop) ...
+    fstamp(1);
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
       if (!((rowmask >> c) & 1u) || !mine_w || NT * c >= oc.imax) continue;
-      const int a = 1 + tid + NT * c;
+      const int a = col_of(c);
       unsigned e = ends[c];
       int blo, bhi;
       col_bounds(a, blo, bhi);
@@ -520,7 +553,9 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
         raw[slot++] = pack_ab(a, b, (int)((vcs[c] >> t) & 1u));
       }
     }
+    fstamp(2);
     __syncthreads();
+    stamp();   // 3: ends appended
     // ... then, over the dense list with one end per lane and step: its slope bucket (an integer division), its place
     // in the bucket's row (or the overflow list), the bucket's max reach, the visit statistics
     {
@@ -544,7 +579,22 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
       if (lane == 0 && vis) s_wvis[wave] += vis;   // one owner per slot
     }
     __syncthreads();
-    stamp();   // 3: staged, placed
+    stamp();   // 4: placed
+#ifdef GV_DIAG
+    if (A.dbg) {   // largest bucket, buckets beyond their row
+      unsigned c0 = 0, big = 0;
+      for (int m = tid; m < M; m += NT) { c0 = max(c0, cnt[m]); big += cnt[m] > (unsigned)kSlots ? 1u : 0u; }
+      c0 = wave_reduce<OpMax>(c0); big = wave_reduce<OpAdd>(big);
+      if (lane == 0) { s_wsum2[wave] = c0 | (big << 16); }
+      __syncthreads();
+      if (tid == 0) {
+        unsigned mc = 0, nb = 0;
+        for (int wv = 0; wv < NT / 64; ++wv) { mc = max(mc, s_wsum2[wv] & 0xFFFFu); nb += s_wsum2[wv] >> 16; }
+        A.dbg[(size_t)wg * 16 + 15] = ((unsigned long long)(sorted_mode ? 1 : 0) << 32) | s_nover | ((unsigned long long)mc << 40) | ((unsigned long long)nb << 52);
+      }
+      __syncthreads();
+    }
+#endif
     // A crowded wedge (thousands of ends per group: most buckets hold more than their row) would push half its ends
     // into the overflow list, which every walk of a full bucket scans: it is placed by counting sort instead --
     // prefix over the bucket counts, every end into its bucket's contiguous run.
@@ -571,8 +621,49 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
       }
       __syncthreads();
     }
-    stamp();   // 4: (crowded groups: prefix + placement)
-    stamp();   // 5
+    // Row mode: what crowds a bucket beyond its row are ends on ONE rational slope p/q with a small q (every k-th lattice
+    // point of that line: imax / q candidates), and of ends with equal slope only the longest can decide a cell.  Every
+    // overflow entry whose slope a row entry shares is merged into that row entry (atomicMax on the packed word: equal
+    // slope, larger a = larger word, reach not smaller) and leaves the list; what stays -- ends of other slopes in a
+    // bucket that is simply full -- is a few entries per wedge, and a walk of a full bucket scans those instead of
+    // 40-180 (measured: that scan was 13-18 k of the 25-31 k cycles of the heaviest middle sectors' evaluation phase,
+    // profiles/r04/sector_overflow_merge.txt).  No barrier of its own: rows, list and counts are next read behind the
+    // barrier that follows the range-max build.
+    if constexpr (!sorted_mode) {
+      const unsigned no_all = s_nover;
+      const unsigned no = (no_all < kMergeMin || GV_ABL(8192)) ? 0u : no_all;
+      for (unsigned e0 = 0; e0 < no; e0 += NT) {
+        const unsigned e = e0 + tid;
+        bool live = false;
+        unsigned v = 0;
+        if (e < no) {
+          v = over[e];
+          const unsigned m = v >> 16, p = raw[v & 0xFFFFu];
+          const int a = ab_a(p), b = ab_b(p);
+          const uint4 r0 = *reinterpret_cast<const uint4 *>(tab + (m << kSlotLog));
+          const uint4 r1 = *reinterpret_cast<const uint4 *>(tab + (m << kSlotLog) + 4);
+          const unsigned row[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+          int hit = -1;
+#pragma unroll
+          for (int q = kSlots - 1; q >= 0; --q)
+            if (m24(b, ab_a(row[q])) == m24(ab_b(row[q]), a)) hit = q;
+          if (hit >= 0) {
+            atomicMax(&tab[(m << kSlotLog) + (unsigned)hit], p);
+            atomicSub(&cnt[m], 1u);
+          } else {
+            live = true;
+          }
+        }
+        const unsigned long long bm = __ballot(live);
+        if (bm) {
+          unsigned base = 0;
+          if (lane == 0) base = atomicAdd(&s_nover2, (unsigned)__popcll(bm));
+          base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+          if (live) over2[base + (unsigned)__popcll(bm & ((1ull << lane) - 1ull))] = v;
+        }
+      }
+    }
+    stamp();   // 5: (crowded groups: prefix + placement; the others: same-slope merge of the overflow list)
     // range-max structure: wavefront `wave` owns the 64-bucket block `wave` (cross-lane ops only)
     if (wave < NB) {
       const int m = wave * 64 + lane;
@@ -614,6 +705,12 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
       if (lane == 63) s_blkmax[wave] = p;
     }
     __syncthreads();
+    if constexpr (!sorted_mode) {
+      const unsigned no_all = s_nover;
+      const bool merged = no_all >= kMergeMin && !GV_ABL(8192);
+      ovl = merged ? over2 : over;
+      novl = merged ? s_nover2 : no_all;
+    }
     stamp();   // 6: range-max built
     // T = last column up to which every interior cell is known free from the level minima
     // (the test is monotone in i).  Columns beyond T are crossed only by the few rays with
@@ -782,8 +879,9 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
           const int a = ab_a(p), b = ab_b(p);
           const int rch = a + (int)(p & 1u);
           const int half = a >> 1;
-          for (int i = T + 1 + lane; i < rch; i += 64) {
-            if (nparts > 1 && (i & 1) != part) continue;   // the other workgroup of this sector marks that column
+          // (a sector run by two workgroups: the lanes step over this workgroup's columns only)
+          const int i0 = T + 1 + ((nparts > 1 && ((T + 1) & 1) != part) ? 1 : 0);
+          for (int i = i0 + m24(lane, nparts); i < rch; i += 64 * nparts) {
             // LineIterator stepping in closed form: j = (a/2 + i*b) / a
             const int num = half + m24(i, b);
             int q = (int)((float)num * __builtin_amdgcn_rcpf((float)a));
@@ -802,6 +900,7 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
     if (A.dbg) __syncthreads();
 #endif
     stamp();   // 9: tail marched (barrier only in the diagnostic build)
+    fstamp(4);
     // gather: one lane per column of the wedge
     const bool flat_tail = !march_tail && T < oc.imax && !GV_ABL(512);   // columns beyond T, every cell exactly
     const int gather_hi = (march_tail || flat_tail) ? T : oc.imax;
@@ -867,6 +966,7 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
       }
       if (mask) atomicOr(&marks[i], mask);   // no-return LDS OR: the lane does not wait for a read of the old word
     }
+    fstamp(5);
     if (flat_tail) {
       // Too many long rays to march them: every cell of the columns T+1 .. (largest reach - 1) is
       // evaluated exactly, one (column, cell) pair per lane -- balanced over the 512 lanes, where a
@@ -878,11 +978,16 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
         const int wlast = ((2 * last * (s + 1) + S) >> (log2s + 1)) - ((2 * last * s + S) >> (log2s + 1)) + 1;
         const int wfirst = ((2 * first * (s + 1) + S) >> (log2s + 1)) - ((2 * first * s + S) >> (log2s + 1)) + 1;
         const int wmax = max(wlast, wfirst) + 1;                 // w(i) grows with i, +-1 by rounding
-        const int lw = 32 - __clz(max(wmax - 1, 1));             // cells per column rounded up to a power of two
         const int ncol = (last - first) / nparts + 1;
-        const int ntask = ncol << lw;
+        const int ntask = m24(ncol, wmax);                       // (rounding wmax up to a power of two left up to half the lanes idle)
+        const float inv_w = __builtin_amdgcn_rcpf((float)wmax);
+        fnote(11, ((unsigned long long)ntask << 32) | ((unsigned)wmax << 16) | (unsigned)ncol);
         for (int t = tid; t < ntask; t += NT) {
-          const int i = first + m24(nparts, t >> lw), k = t & ((1 << lw) - 1);
+          int c = (int)((float)t * inv_w);                       // t / wmax: estimate + correction (t < 2^24)
+          int k = t - m24(c, wmax);
+          if (k < 0) { --c; k += wmax; }
+          else if (k >= wmax) { ++c; k -= wmax; }
+          const int i = first + m24(nparts, c);
           const int jlo = (m24(2 * i, s) + S) >> (log2s + 1);
           const int jhi = (m24(2 * i, s + 1) + S) >> (log2s + 1);
           if (k > jhi - jlo) continue;
@@ -890,6 +995,7 @@ __global__ void __launch_bounds__(kSecThreads, GV_SECTOR_WPE) k_ray_sectors(Sect
         }
       }
     }
+    fstamp(6);
     __syncthreads();
     stamp();   // 10: gather done
   };

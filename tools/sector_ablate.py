@@ -11,7 +11,7 @@ config = 3
 g = synth.CONFIGS[config]["grid"]
 tfs = synth.transforms(True)
 x, y, z, _ = (synth.cloud_lidar_like if "lidar" in sys.argv else synth.cloud_uniform)(config)
-names = {0: "nothing off", 8: "launch + init only", 16: "+ scan", 32: "+ nothing else (return before groups)", 2: "no gather loop", 1024: "no boundary walks",
+names = {0: "nothing off", 4096: "no overflow-list scans", 8: "launch + init only", 16: "+ scan", 32: "+ nothing else (return before groups)", 2: "no gather loop", 1024: "no boundary walks",
          2048: "no exact cells (todo)", 3072: "no walks, no exact cells", 4: "no flush", 256: "no marched tail (flat instead)",
          2 | 512 | 256: "no gather, no tails", 2 | 512 | 256 | 4: "no gather, no tails, no flush"}
 for abl, nm in names.items():

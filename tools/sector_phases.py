@@ -21,14 +21,15 @@ h.set_detections(gvamd.FRAME_BIN | gvamd.FRAME_RAYMARCH)
 for _ in range(3):
     h.enqueue_frame()
 h.synchronize()
-nwg = 8 << 9   # upper bound; unused slots stay zero
+nwg = 8 << 12   # the whole buffer: coarse stamps in the first half, fine ones (diag) from slot 16384 on
 buf = np.zeros((nwg, 16), np.uint64)
 rc = h._lib.gv_debug_sector_stamps(h._h, buf.ctypes.data_as(C.c_void_p), C.c_size_t(nwg))
 assert rc == 0, rc
-names = ["init", "scan", "stage", "cnt+pfx", "place", "rmq", "thresh", "compact", "march", "edge", "flush"]  # stamps 0..11
+names = ["init", "scan", "append", "dense", "merge", "rmq", "thresh", "compact", "march", "edge", "flush"]  # stamps 0..11
 t = buf.astype(np.int64)
 NS = len(names)
 full = t[:, NS] > 0
+full[16384:] = False   # (fine stamps)
 print("workgroups", nwg, "with ends", int(full.sum()))
 d = np.diff(t[full][:, :NS + 1], axis=1)
 for k, nme in enumerate(names):
@@ -43,7 +44,7 @@ if "detail" in sys.argv:
     for i in order:
         v12, v13 = int(buf[i, 12]), int(buf[i, 13])
         print(i, int(buf[i, 14]) >> 32 & 0xFF, int(buf[i, 14]) & 0xFFFFFFFF, "S", 1 << (int(buf[i, 14]) >> 40), "T", v12 >> 48, "maxreach", (v12 >> 32) & 0xFFFF, "imax", (v12 >> 16) & 0xFFFF, "n", v12 & 0xFFFF,
-              "nlong", v13 & 0xFFFFFFFF, "tail_steps", v13 >> 32, d[i].tolist())
+              "nlong", v13 & 0xFFFFFFFF, "tail_steps", v13 >> 32, "nover", int(buf[i, 15]) & 0xFFFFFFFF, "sorted", (int(buf[i, 15]) >> 32) & 1, "maxcnt", (int(buf[i, 15]) >> 40) & 0xFFF, "nbig", int(buf[i, 15]) >> 52, d[i].tolist())
     print("total percentiles", [int(np.percentile(tot, q)) for q in (10, 50, 90, 99, 100)])
     st = t[full][:, 0] - t0
     print("start-time percentiles", [int(np.percentile(st, q)) for q in (10, 50, 60, 90, 99, 100)], "last end", int((t[full][:, NS] - t0).max()))
@@ -54,6 +55,21 @@ if "detail" in sys.argv:
         if sel.any():
             print("octant", o, "workgroups", int(sel.sum()), "mean", int((t[sel][:, NS] - t[sel][:, 0]).mean()), "max", int((t[sel][:, NS] - t[sel][:, 0]).max()))
 
+    nov = (buf[:, 15] & np.uint64(0xFFFFFFFF)).astype(np.int64)[full]
+    print("overflow list: mean", nov.mean(), "p50", np.median(nov), "p90", np.percentile(nov, 90), "max", nov.max(), "sorted-mode wgs", int((((buf[:, 15] >> np.uint64(32)) & np.uint64(1)) > 0).sum()))
+    print("corr(edge cycles, nover)", np.corrcoef(d[:, 9], nov)[0, 1])
+    for o in range(8):
+        sel = (octs == o)[full]
+        if sel.any():
+            print("octant", o, "phase means", [int(v) for v in d[sel].mean(axis=0)])
+    idx_full = np.nonzero(full)[0]
+    for w in (169, 209, 38, 166, 384, 320):
+        j = np.nonzero(idx_full == w)[0]
+        if len(j):
+            print("wg", w, "phases", d[j[0]].tolist())
+        f = t[16384 + w]
+        print("   fine: slots", int(f[1] - f[0]), "append loop", int(f[2] - f[1]), "append barrier", int(t[w, 3] - f[2]), "| gather", int(f[5] - f[4]), "flat", int(f[6] - f[5]),
+              "end barrier", int(t[w, 10] - f[6]), "flat tasks", int(buf[16384 + w, 11]) >> 32, "lw", (int(buf[16384 + w, 11]) >> 16) & 0xFFFF, "ncol", int(buf[16384 + w, 11]) & 0xFFFF)
     b12 = buf[:, 12].astype(np.uint64)
     Tv = (b12 >> np.uint64(48)).astype(np.int64); mr = ((b12 >> np.uint64(32)) & np.uint64(0xFFFF)).astype(np.int64)
     im = ((b12 >> np.uint64(16)) & np.uint64(0xFFFF)).astype(np.int64); nn = (b12 & np.uint64(0xFFFF)).astype(np.int64)
