@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "gv_host_math.hpp"
+#include "gv_test_hooks.h"
 #include "gv_kernels.hpp"
 
 using namespace gv;
@@ -2929,7 +2930,7 @@ int64_t gv_shard_slice_words(int64_t words, int32_t world)
 // rank r takes points [n*r/world, n*(r+1)/world).  Every piece the ranks would run -- binning of a
 // slice, OR of the end-bitmap slices, every world-th sector workgroup, band packing, band OR, band grid
 // pass -- runs with its real (rank, world); the bands land in the one resident grid.
-int gv_debug_frame_sharded_emulated(gv_handle h, const gv_frame_desc *desc, int32_t world)
+int gv_test_frame_sharded_emulated(gv_handle h, const gv_frame_desc *desc, int32_t world)
 {
   if (!h || !desc || world < 1 || world > 16) return GV_ERR_BAD_ARG;
   if (!sector_path(h)) return GV_ERR_STATE;

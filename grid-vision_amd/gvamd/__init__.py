@@ -46,7 +46,7 @@ ABI_SYMBOLS = [
     "gv_time_frame_stages", "gv_comm_unique_id", "gv_comm_init", "gv_comm_destroy",
     "gv_process_frame_sharded", "gv_comm_band",
     "gv_cloud_upload_xyz_async", "gv_cloud_upload_pointcloud2_async", "gv_cloud_upload_wait", "gv_host_alloc",
-    "gv_host_free", "gv_frame_set_detections_async", "gv_frame_fence", "gv_debug_frame_sharded_emulated",
+    "gv_host_free", "gv_frame_set_detections_async", "gv_frame_fence",
     "gv_to_occupancy_grid_async", "gv_frame_enqueue_sharded", "gv_time_frame_sharded_stages", "gv_shard_band_rows",
     "gv_shard_slice_words", "gv_device_layers", "gv_tick_enqueue", "gv_tick_wait", "gv_tick",
     "gv_comm_info", "gv_publish_grid_async",
@@ -565,7 +565,7 @@ class GridVisionHIP:
 
     def frame_sharded_emulated(self, world, flags, bboxes=None, poses=None, net=None):
         d = self._desc(flags, bboxes, poses, net)
-        self._ck(self._lib.gv_debug_frame_sharded_emulated(self._h, C.byref(d), C.c_int32(world)), "frame_sharded_emulated")
+        self._ck(self._lib.gv_test_frame_sharded_emulated(self._h, C.byref(d), C.c_int32(world)), "frame_sharded_emulated")
 
     def time_frames(self, frames):
         ms = C.c_float(0)

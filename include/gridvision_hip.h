@@ -412,11 +412,6 @@ int gv_shard_band_rows(int32_t rank, int32_t world, int32_t ny, int32_t *y0, int
 int64_t gv_shard_slice_words(int64_t words, int32_t world);
 /* Band of cells [begin,end) this rank finalises (linear cell indices): whole 64-row blocks. */
 int gv_comm_band(gv_handle h, int64_t *begin, int64_t *end);
-/* Test hook (no RCCL, one device): runs the sharded frame for EVERY rank of a `world`-GPU job on
- * this handle -- the resident cloud is the whole cloud, rank r takes points [n*r/world, n*(r+1)/world)
- * -- with the exchanges done by device copies; the result must equal gv_process_frame's. */
-int gv_debug_frame_sharded_emulated(gv_handle h, const gv_frame_desc *desc, int32_t world);
-
 #ifdef __cplusplus
 }
 #endif

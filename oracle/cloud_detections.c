@@ -49,6 +49,7 @@ void gvo_depth_for_bboxes(const float *u, const float *v, const float *depth, si
   for (int32_t b = 0; b < nb; ++b) {
     depths[b] = -1.0f;                                         /* :49 */
     if (knn_d2) for (int32_t j = 0; j < k; ++j) knn_d2[(size_t)b * k + j] = INFINITY;
+    /* Promotion: the box fields are doubles: difference, / 2.0f and sum in fp64; pcl::PointXYZ::x is a float: narrowed once. */
     const float qx = (float)(bboxes[b].x_min + ((bboxes[b].x_max - bboxes[b].x_min) / 2.0f)); /* :57 */
     const float qy = (float)(bboxes[b].y_min + ((bboxes[b].y_max - bboxes[b].y_min) / 2.0f)); /* :58 */
     const float qz = 0.0f;                                     /* :59 */

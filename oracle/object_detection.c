@@ -96,6 +96,8 @@ int32_t gvo_nms(gvo_bbox *b, int32_t n, float iou_threshold, gvo_bbox *out)
 /* denormalizeAndScaleBoundingBox :226-239 */
 void gvo_denormalize(gvo_bbox *b, int32_t n, int32_t orig_w, int32_t orig_h, int32_t resize)
 {
+  /* Promotion (:229-237): float / int -> float scale; box.x_min is a DOUBLE field, so x_min * resize * scale_x is
+   * double * int * float = fp64 throughout; static_cast<int> truncates towards zero; the int goes back into the double. */
   const float scale_x = (float)orig_w / resize;
   const float scale_y = (float)orig_h / resize;
   for (int32_t i = 0; i < n; ++i) {

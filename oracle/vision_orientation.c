@@ -17,6 +17,7 @@
 /* generateBins  :241-258 */
 void gvo_generate_bins(int32_t bins, float *out)
 {
+  /* Promotion: M_PI is a double, so 2.0f * M_PI and the division by the int are fp64; narrowed once on assignment. */
   const float interval = (float)(2.0f * M_PI / bins);          /* :244 */
   for (int32_t i = 0; i < bins; ++i) out[i] = 0.0f;
   for (int32_t i = 1; i < bins; ++i) out[i] = i * interval;    /* :248 */
@@ -38,6 +39,8 @@ float gvo_compute_alpha(const float orient[4], int32_t argmax, const float *bins
 float gvo_compute_theta_ray(const gvo_cam *cam, const gvo_bbox *b)
 {
   const float fx = cam->fx;                                    /* proj_mat_(0,0) */
+  /* Promotion: orig_w_ is an int and fx a float: int / float -> float, std::atan(float) is the float overload: fp32
+   * throughout.  :282 adds two DOUBLE box fields and divides by 2.0f in fp64, narrowed on assignment; the rest is fp32. */
   const float fovx = 2.0f * atanf(cam->orig_w / (2.0f * fx));  /* :280 */
   const float box_center_x = (float)((b->x_min + b->x_max) / 2.0f);   /* :282 */
   float dx = box_center_x - (cam->orig_w / 2.0f);              /* :283 */
@@ -163,6 +166,8 @@ static void calc_location_impl(const gvo_cam *cam, const double dimension[3], co
   const float Rm[9] = {c, 0, s, 0, 1, 0, -s, 0, c};
   const float box[4] = {(float)bbox->x_min, (float)bbox->y_min,
                         (float)bbox->x_max, (float)bbox->y_max};   /* :301-303 */
+  /* Promotion: dimension is std::array<double, 3>: double / 2.0f is an fp64 division, narrowed on assignment;
+   * 88 * M_PI / 180.0f is int * double / float = fp64, narrowed once (:311-313). */
   const float dx = (float)(dimension[0] / 2.0f);               /* :306 */
   const float dy = (float)(dimension[1] / 2.0f);               /* :307 */
   const float dz = (float)(dimension[2] / 2.0f);               /* :308 */
