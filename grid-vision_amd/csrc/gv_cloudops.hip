@@ -838,6 +838,8 @@ constexpr int kRadPts = GV_RAD_PTS;         // points per wavefront and pass
 constexpr int kRadLanes = GV_RAD_LANES;     // lanes per point in phase B
 constexpr int kRadCand = GV_RAD_CAND;       // candidates per lane and step
 constexpr int kRadRuns = 20;                // own cell + 2 beside it + 8 rows x 2 runs, the empty ones dropped
+constexpr int kRadTab = 64;                 // boxes whose sums a workgroup keeps in LDS (more: global atomics); 25.6 KB of LDS in all:
+                                            // six workgroups per CU (80 VGPRs: six wavefronts per SIMD)
 constexpr int kBoffLds = 256;               // block offsets of the bucket scan kept in LDS (n_buckets < 1 M: clouds up to
                                             // 2 M points; beyond that they are read from global memory)
 
@@ -846,11 +848,11 @@ __global__ void __launch_bounds__(256, GV_RAD_OCC) k_radius_sorted(const CellNod
                                                        float r2f, int min_pts, uint8_t *__restrict__ keep,
                                                        long long *__restrict__ acc, int nb)
 {
-  __shared__ long long s_acc[kPcaTab][4];
+  __shared__ long long s_acc[kRadTab][4];
   __shared__ uint2 s_run[4][kRadRuns][kRadPts];   // [begin, end) of a point's non-empty runs in visiting order
   __shared__ float4 s_pt[4][kRadPts];
   __shared__ uint32_t s_boff[kBoffLds];
-  const bool tab = nb <= kPcaTab;
+  const bool tab = nb <= kRadTab;
   const uint32_t n_off = n_buckets >> 12;
   // n_off + 1 entries: the end of the LAST bucket is start_of(n_buckets) = pre[n_buckets] (0) + the total
   const bool staged = n_off + 1u <= (uint32_t)kBoffLds;
@@ -865,6 +867,8 @@ __global__ void __launch_bounds__(256, GV_RAD_OCC) k_radius_sorted(const CellNod
   const uint32_t g = (uint32_t)lane & (uint32_t)(kRadLanes - 1);
   const float4 *nodes = reinterpret_cast<const float4 *>(sorted);
   const uint32_t n_pass = (n_sel + kRadPts - 1) / kRadPts;
+  // (Passes handed out through a counter to a launch as large as the chip holds, instead of this fixed stride: 131 us
+  // against 59, profiles/r04/radius_filter_ab.txt.)
   for (uint32_t pass = blockIdx.x * 4u + (uint32_t)w; pass < n_pass; pass += gridDim.x * 4u) {
     const uint32_t t0 = pass * kRadPts;
     // ---- phase A: lane p < 32 prepares point t0 + p
