@@ -1724,6 +1724,25 @@ def test_publish_grid_every_frame_while_clouds_stream(gvamd):
             p.close()
 
 
+def test_publish_grid_size_not_a_multiple_of_16(gvamd):
+    """gv_publish_grid_async on a grid whose byte count is no multiple of 16 (the kernel moves 16 bytes per lane, the tail
+    goes by a copy command) and off the tile path (nx % 4 != 0): equals gv_to_occupancy_grid byte for byte"""
+    h = gvamd.GridVisionHIP(21, 19, 0.1)   # 210 x 190 cells = 39900 bytes = 16 * 2493 + 12
+    assert h.G % 16 != 0
+    tfs = synth.transforms(True)
+    h.set_transforms(tfs["cam_lidar"], tfs["base_cam"], tfs["base_lidar"])
+    h.update_map_poses(synth.lshape_poses(1, 6))
+    h.update_map_poses(synth.lshape_poses(1, 4, seed_extra=3))
+    pin = gvamd.PinnedI8(h.G)
+    pin.array[:] = 77
+    h.publish_grid_async(pin.array)
+    h.synchronize()
+    want = h.to_occupancy_grid()[0]
+    assert np.array_equal(pin.array, want) and not np.any(want == 77)
+    pin.close()
+    h.close()
+
+
 def test_device_layers_are_the_resident_grid(gvamd):
     """gv_device_layers: the device pointers a device-side consumer reads behind a frame on gv_stream hold what the
     host getters return"""
