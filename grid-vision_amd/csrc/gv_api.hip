@@ -2185,8 +2185,9 @@ static int publish_by_kernel(gv_context *h, int8_t *data, hipStream_t s, bool *d
 {
   *done = false;
   hipPointerAttribute_t at{};
-  if (hipPointerGetAttributes(&at, data) != hipSuccess || at.type != hipMemoryTypeHost || !at.devicePointer) {
-    (void)hipGetLastError();   // pageable memory: the caller gets the copy command instead
+  if (hipPointerGetAttributes(&at, data) != hipSuccess || at.type != hipMemoryTypeHost || !at.devicePointer ||
+      (reinterpret_cast<uintptr_t>(at.devicePointer) & 15u) != 0) {
+    (void)hipGetLastError();   // pageable memory, or not 16-byte aligned (the kernel stores 16 bytes per lane): the copy command instead
     return GV_OK;
   }
   const size_t G = (size_t)h->g.G, body = G & ~(size_t)15;

@@ -241,7 +241,8 @@ int gv_to_occupancy_grid_async(gv_handle h, int8_t *data);
  * grid_vision_node.cpp:240, :265-278).  data must be pinned (gv_host_alloc): the grid is then written there by a small
  * kernel on gv_stream(h) instead of a copy command, so the copy engines stay with the cloud uploads and PCIe carries
  * both directions at once -- 262 us per frame, steady, against 292-349 us and erratic for the copy command beside an
- * upload (profiles/r04/publish_variants.txt).  Pageable memory falls back to the copy command.  Same completion rule as
+ * upload (profiles/r04/publish_variants.txt).  Pageable memory, or a destination that is not 16-byte aligned, falls back to the
+ * copy command.  Same completion rule as
  * gv_to_occupancy_grid_async. */
 int gv_publish_grid_async(gv_handle h, int8_t *data);
 /* Layer read-back (grid_map_["log_odds"], ["occupancy"]; occupancy_grid.hpp:22) */

@@ -1739,6 +1739,13 @@ def test_publish_grid_size_not_a_multiple_of_16(gvamd):
     h.synchronize()
     want = h.to_occupancy_grid()[0]
     assert np.array_equal(pin.array, want) and not np.any(want == 77)
+    # a destination inside pinned memory that is not 16-byte aligned takes the copy command
+    big = gvamd.PinnedI8(h.G + 16)
+    big.array[:] = 77
+    h.publish_grid_async(big.array[3:3 + h.G])
+    h.synchronize()
+    assert np.array_equal(big.array[3:3 + h.G], want) and np.all(big.array[:3] == 77) and np.all(big.array[3 + h.G:] == 77)
+    big.close()
     pin.close()
     h.close()
 
