@@ -568,7 +568,8 @@ int upload_det(gv_context *h, DetSet &d, const gv_bbox *bboxes, int32_t nb, cons
 int upload_scratch_bboxes(gv_context *h, const gv_bbox *b, int32_t nb, bool masks = true)
 {
   DetSet &d = h->det[2];
-  int rc = upload_det(h, d, b, nb, nullptr, 0, nullptr, nullptr, nullptr, h->stream, masks);
+  // (fused: the table kernel reads the pinned staging itself -- one launch instead of a copy command + a kernel: 6 us)
+  int rc = upload_det(h, d, b, nb, nullptr, 0, nullptr, nullptr, nullptr, h->stream, masks, -1, -1, true);
   if (rc) return rc;
   GV_HIP(hipEventRecord(d.ready, h->stream));
   return GV_OK;
