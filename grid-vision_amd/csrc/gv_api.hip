@@ -567,6 +567,7 @@ int upload_det(gv_context *h, DetSet &d, const gv_bbox *bboxes, int32_t nb, cons
 // bboxes only, synchronously, into the standalone set (extractCloudPerBBox and friends)
 int upload_scratch_bboxes(gv_context *h, const gv_bbox *b, int32_t nb, bool masks = true)
 {
+  if (h->tick.pending) { h->err = "a tick is pending: call gv_tick_wait first"; return GV_ERR_STATE; }
   DetSet &d = h->det[2];
   // (fused: the table kernel reads the pinned staging itself -- one launch instead of a copy command + a kernel: 6 us)
   int rc = upload_det(h, d, b, nb, nullptr, 0, nullptr, nullptr, nullptr, h->stream, masks, -1, -1, true);
@@ -2501,6 +2502,9 @@ constexpr size_t kResHeader = 64;
 // a block with room for `bytes` of payload; the CallDone of the call about to be enqueued
 static int begin_result(gv_context *h, size_t bytes, CallDone &done)
 {
+  // a tick between gv_tick_enqueue and gv_tick_wait owns the result block (and the standalone detection set): the
+  // calls that would reuse them are refused until the tick has been waited for
+  if (h->tick.pending) { h->err = "a tick is pending: call gv_tick_wait first"; return GV_ERR_STATE; }
   if (bytes + kResHeader > h->res_cap) {
     GV_HIP(hipStreamSynchronize(h->stream));   // nothing in flight writes the old block
     if (h->res_host) { GV_HIP(hipHostFree(h->res_host)); h->res_host = nullptr; }

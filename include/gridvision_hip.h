@@ -346,6 +346,10 @@ typedef struct {
   int32_t n_poses;                   /* out */
   int32_t pca_empty;                 /* out: 1 = computeBBoxPose returned {} (no plane / empty segmented cloud)      */
 } gv_tick_result;
+/* One tick at a time (the reference's timer is single threaded): a second gv_tick_enqueue before gv_tick_wait returns
+ * GV_ERR_STATE, and so do, between the two, the synchronous calls that would reuse the tick's result block or its
+ * detection set (gv_compute_depth_for_bboxes, gv_compute_bbox_pose*, gv_segment_ground_plane, gv_extract_cloud_per_bbox,
+ * ...).  Cloud uploads, gv_frame_* and the grid getters may be called; they are ordered behind the tick on gv_stream(h). */
 int gv_tick_enqueue(gv_handle h, const gv_tick_desc *d);
 int gv_tick_wait(gv_handle h, gv_tick_result *r);
 int gv_tick(gv_handle h, const gv_tick_desc *d, gv_tick_result *r);   /* = enqueue + wait */

@@ -1398,7 +1398,13 @@ def test_tick_lidar_extension_and_error_paths(gvamd):
     with pytest.raises(gvamd.GVError) as e:
         hA.tick_enqueue(b, k_near=4)           # one tick at a time
     assert e.value.code == 5
-    hA.tick_wait()
+    for call in (lambda: hA.compute_depth_for_bboxes(b, 4), lambda: hA.compute_bbox_pose(b), lambda: hA.segment_ground_plane()):
+        with pytest.raises(gvamd.GVError) as e:
+            call()                             # would reuse the pending tick's result block / detection set
+        assert e.value.code == 5
+    want = hA.tick_wait()
+    assert len(want["depths"]) > 0 and len(want["poses"]) > 0
+    hA.compute_depth_for_bboxes(b, 4)          # fine again
     with pytest.raises(gvamd.GVError) as e:
         hA.tick_wait()
     assert e.value.code == 5
