@@ -1370,6 +1370,35 @@ def test_tick_fused_equals_call_sequence_and_oracle(gvamd):
     hA.close(); hB.close()
 
 
+def test_tick_equals_call_sequence_at_ten_million_points(gvamd):
+    """BASELINE configs[4]'s point count through the tick: a scene with objects of 10 M points (60 000 per object: boxes
+    of tens of thousands of kept points, a bucket table of 4 M entries whose block offsets no longer fit the kernels'
+    LDS copy).  The oracle does not finish at this size; the size-independent property is that the fused tick and the
+    call-by-call sequence over the same library agree bit for bit -- depths, poses, both layers -- and that every dynamic
+    box with an object yields a pose."""
+    hA, tfs = make_handle(gvamd, 3, perturbed=True)
+    hB, _ = make_handle(gvamd, 3, perturbed=True)
+    x, y, z, b = synth.scene_with_objects(tfs, n_total=10_000_000, seed=23, per=60_000)
+    for h in (hA, hB):
+        h.upload_xyz(x, y, z)
+    st, dy = gvamd.filter_bboxes(b)
+    assert len(st) >= 5 and len(dy) >= 20
+    for rep in range(2):
+        r = hA.tick(b, k_near=4)
+        bdepth = hB.compute_depth_for_bboxes(st, 4)[0]
+        pp, valid, npz = hB.compute_bbox_pose_ground_removed(b)
+        assert npz >= 20
+        bposes = hB.transform_lshape_objects(pp[valid.astype(bool)])
+        hB.update_map_poses(bposes)
+        assert r["depths"].tobytes() == bdepth.tobytes()
+        assert r["poses"].tobytes() == bposes.tobytes()
+        assert np.array_equal(hA.log_odds(), hB.log_odds())
+        assert np.array_equal(hA.to_occupancy_grid()[0], hB.to_occupancy_grid()[0])
+    # (at ten times the density the clutter inside a box's frustum survives the radius filter: the rectangles span it)
+    assert len(r["poses"]) >= 20 and np.all(r["poses"]["length"] > 0.5) and np.all(np.isfinite(r["poses"]["px"]))
+    hA.close(); hB.close()
+
+
 def test_tick_lidar_extension_and_error_paths(gvamd):
     """the tick with the [EXTENSION] map update (hit counts + free space inside the same batch) equals the fused frame
     fed with the tick's own poses; argument / state errors; a tick while frames are in flight drains them first"""
