@@ -653,7 +653,7 @@ def leg_pca_path(gvamd, synth, g, tfs, config, bboxes, local_rank, reps=10, cpu_
         res["points"] = len(x)
         res["bboxes"] = len(bboxes)
         h.close()
-        if name == "objects" and cpu_seconds > 0:
+        if cpu_seconds > 0:
             # the oracle's same calls on this box's host cores, one thread (kind "port"): median of a few runs each
             ct = CpuTick(synth, g, tfs, x, y, z, bboxes)
             cx, cy, cz = ct.ol.transform_cloud(ct.m_cam, x, y, z)
@@ -676,7 +676,7 @@ def leg_pca_path(gvamd, synth, g, tfs, config, bboxes, local_rank, reps=10, cpu_
             bboxes = bboxes_saved
         out[name] = res
     out["note"] = ("host-observed milliseconds per C-ABI call (median of %d), results back on the host; "
-                   "compute_bbox_pose_ground_removed = RANSAC + bbox test + stable split + radius filter + PCA; "
+                   "compute_bbox_pose_ground_removed = RANSAC + bbox test + radius filter + PCA rectangle; "
                    "objects = synth.scene_with_objects (40 dense objects, each in a box of its own); the uniform cloud of earlier "
                    "rounds loses every point to the radius filter (valid_poses 0) and is no longer timed" % reps)
     return out
