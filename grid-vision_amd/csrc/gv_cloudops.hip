@@ -890,26 +890,41 @@ __global__ void __launch_bounds__(256, GV_RAD_OCC) k_radius_sorted(const CellNod
       // cells x0..x1 are one run, or two when they straddle a multiple of 8
       const int xs = ((x0 >> 3) != (x1 >> 3)) ? (x1 & ~7) : x1 + 1;   // first cell of the second run (none: x1 + 1)
       const bool two = xs <= x1;
+      // bucket_of for the (up to 35) cells a point looks up, without its four 32-bit multiplies per cell: the hash is an
+      // xor of per-axis terms, and every cell here lies within one of the point's own in each axis -- ten products per
+      // point instead of a hundred (v_mul_lo_u32 issues at half rate)
+      const uint32_t hid = (uint32_t)myid * 0x27D4EB2Fu;
+      const uint32_t hxv[3] = {(uint32_t)((ix - 1) >> 3) * 0x9E3779B1u, (uint32_t)(ix >> 3) * 0x9E3779B1u, (uint32_t)((ix + 1) >> 3) * 0x9E3779B1u};
+      const uint32_t hyv[3] = {(uint32_t)((iy - 1) >> 3) * 0x85EBCA77u, (uint32_t)(iy >> 3) * 0x85EBCA77u, (uint32_t)((iy + 1) >> 3) * 0x85EBCA77u};
+      const uint32_t hzv[3] = {(uint32_t)((iz - 1) >> 3) * 0xC2B2AE3Du, (uint32_t)(iz >> 3) * 0xC2B2AE3Du, (uint32_t)((iz + 1) >> 3) * 0xC2B2AE3Du};
+      auto bkt = [&](int cx, int dy, int dz) -> uint32_t {   // = bucket_of(cx, iy + dy, iz + dz, myid, hi_mask) for |cx - ix| <= 1
+        const int cy = iy + dy, cz = iz + dz;
+        const uint32_t lo = ((uint32_t)cx & 7u) | (((uint32_t)cy & 7u) << 3) | (((uint32_t)cz & 7u) << 6);
+        uint32_t h = (cx < ix ? hxv[0] : (cx > ix ? hxv[2] : hxv[1])) ^ hyv[dy + 1] ^ hzv[dz + 1] ^ hid;
+        h ^= h >> 15;
+        return lo | ((h & hi_mask) << 9);
+      };
       uint2 own = make_uint2(0u, 0u), lft = make_uint2(0u, 0u), rgt = make_uint2(0u, 0u);
       if (live) {
-        const uint32_t b = bucket_of(ix, iy, iz, myid, hi_mask);
+        const uint32_t b = bkt(ix, 0, 0);
         own = make_uint2(start_of(b), start_of(b + 1u));
-        if (x0 < ix) { const uint32_t bl = bucket_of(ix - 1, iy, iz, myid, hi_mask); lft = make_uint2(start_of(bl), start_of(bl + 1u)); }
-        if (x1 > ix) { const uint32_t br = bucket_of(ix + 1, iy, iz, myid, hi_mask); rgt = make_uint2(start_of(br), start_of(br + 1u)); }
+        if (x0 < ix) { const uint32_t bl = bkt(ix - 1, 0, 0); lft = make_uint2(start_of(bl), start_of(bl + 1u)); }
+        if (x1 > ix) { const uint32_t br = bkt(ix + 1, 0, 0); rgt = make_uint2(start_of(br), start_of(br + 1u)); }
       }
       uint4 rr[8];
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
         const int q = k + (k >= 4 ? 1 : 0);   // the eight rows around the centre
-        const int cy = iy + (q % 3) - 1, cz = iz + (q / 3) - 1;
+        const int dy = (q % 3) - 1, dz = (q / 3) - 1;
+        const int cy = iy + dy, cz = iz + dz;
         const bool in = live && cy >= y0 && cy <= y1 && cz >= z0 && cz <= z1;
         uint4 r = make_uint4(0u, 0u, 0u, 0u);
         if (in) {
-          r.x = start_of(bucket_of(x0, cy, cz, myid, hi_mask));
-          r.y = start_of(bucket_of(min(xs - 1, x1), cy, cz, myid, hi_mask) + 1u);
+          r.x = start_of(bkt(x0, dy, dz));
+          r.y = start_of(bkt(min(xs - 1, x1), dy, dz) + 1u);
           if (two) {
-            r.z = start_of(bucket_of(xs, cy, cz, myid, hi_mask));
-            r.w = start_of(bucket_of(x1, cy, cz, myid, hi_mask) + 1u);
+            r.z = start_of(bkt(xs, dy, dz));
+            r.w = start_of(bkt(x1, dy, dz) + 1u);
           }
         }
         rr[k] = r;
